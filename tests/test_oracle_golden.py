@@ -1,0 +1,139 @@
+"""Pin the CPU oracle (oracle/) against golden vectors recorded from the imported reference."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss as oloss
+from oracle import postprocess as opost
+from oracle.net import OracleNet
+from pqdet_amd.model import zoo
+from seedfill import seeded_boxes, seeded_fill, seeded_images
+
+REF_CFG = '/root/reference/model/cfg'
+
+
+def test_g2_decode(golden):
+    for tag in 'ab':
+        ncls, stride = golden['g2_%s_meta' % tag]
+        got = OracleNet.decode(torch.from_numpy(golden['g2_%s_in' % tag]), int(ncls), int(stride))
+        np.testing.assert_allclose(got.numpy(), golden['g2_%s_out' % tag], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('kind', ['l1', 'giou', 'diou', 'iou'])
+def test_g3_loss_forward_and_grad(golden, kind):
+    raw = torch.from_numpy(golden['g3_raw']).requires_grad_(True)
+    label, boxes = torch.from_numpy(golden['g3_label']), torch.from_numpy(golden['g3_boxes'])
+    opt = {'stride': 16, 'bbox_loss': kind, 'ignore_thresh': 0.5, 'l1_loss_gain': 0.05, 'classes': 3}
+    pred = OracleNet.decode(raw, 3, 16)
+    pred.retain_grad()
+    out = oloss.loss_per_scale(pred, label, boxes, opt)
+    out[0].sum().backward()
+    np.testing.assert_allclose(np.concatenate([o.detach().numpy() for o in out]), golden['g3_%s_losses' % kind],
+                               rtol=1e-6)
+    np.testing.assert_allclose(pred.grad.numpy(), golden['g3_%s_dpred' % kind], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(raw.grad.numpy(), golden['g3_%s_draw' % kind], rtol=1e-5, atol=1e-7)
+
+
+def test_g3_ciou_raises_nan_like_the_reference(golden):
+    assert golden['g3_ciou_raises'][0] == 1
+    raw = torch.from_numpy(golden['g3_raw'])
+    opt = {'stride': 16, 'bbox_loss': 'ciou', 'ignore_thresh': 0.5, 'l1_loss_gain': 0.05, 'classes': 3}
+    with pytest.raises(RuntimeError, match='NaN in loss'):
+        oloss.loss_per_scale(OracleNet.decode(raw, 3, 16), torch.from_numpy(golden['g3_label']),
+                             torch.from_numpy(golden['g3_boxes']), opt)
+
+
+def test_g4_iou_family(golden):
+    b1, b2 = torch.from_numpy(golden['g4_b1']), torch.from_numpy(golden['g4_b2'])
+    fns = {'iou_calc3': oloss.pair_iou, 'giou': oloss.giou, 'diou': oloss.diou, 'ciou': oloss.ciou}
+    for name, fn in fns.items():
+        np.testing.assert_array_equal(fn(b1, b2).numpy(), golden['g4_' + name])
+        np.testing.assert_array_equal(fn(b1[:, None, :], b2[None, :, :]).numpy(), golden['g4_bc_' + name])
+    np.testing.assert_array_equal(opost.iou_xyxy_np(golden['g4_b1'], golden['g4_b2']), golden['g4_iou_calc1'])
+    np.testing.assert_array_equal(oloss.iou_xywh_np(golden['g4_xywh1'], golden['g4_xywh2']), golden['g4_iou_xywh'])
+
+
+def test_g6_recover(golden):
+    pred = torch.from_numpy(golden['g6_pred'])
+    insz = torch.FloatTensor([512, 512])
+    orig = torch.from_numpy(golden['g6_orig'])
+    np.testing.assert_array_equal(opost.recover_boxes(pred, insz, orig, 'voc').numpy(), golden['g6_voc'])
+    np.testing.assert_array_equal(opost.recover_boxes(pred, insz, orig[0], 'voc').numpy(), golden['g6_voc_single'])
+    np.testing.assert_array_equal(opost.recover_boxes(pred, insz, orig, 'visdrone').numpy(), golden['g6_visdrone'])
+
+
+def test_g7_nms(golden):
+    nb = golden['g7_in']
+    np.testing.assert_array_equal(opost.numpy_nms(nb.copy(), 0.1, 0.45), golden['g7_nms'])
+    np.testing.assert_array_equal(opost.numpy_nms(nb.copy(), 0.1, 0.45, method='soft-nms'), golden['g7_softnms'])
+    pb, ps, pc, _ = opost.nms_candidates(golden['g7_ml_in'], 0.4)
+    np.testing.assert_array_equal(ps, golden['g7_ml_scores'])
+    np.testing.assert_array_equal(pc, golden['g7_ml_cls'])
+    np.testing.assert_array_equal(pb, golden['g7_ml_boxes'])
+    # the restated torchvision greedy rule agrees with the in-repo greedy rule on arg-maxed, tie-free input
+    keep = opost.batched_nms_f32(nb[:, :4], nb[:, 4], nb[:, 5].astype(np.int64), 0.45)
+    mine = nb[keep]
+    ref = golden['g7_nms']
+    ref_sorted = ref[np.argsort(-ref[:, 4], kind='stable')]
+    np.testing.assert_array_equal(mine[mine[:, 4] > 0.1], ref_sorted)
+
+
+def test_g8_create_label(golden):
+    out = opost.create_label(golden['g8_boxes'], np.array([[16, 16], [8, 8], [4, 4]]), 5)
+    for i in range(3):
+        np.testing.assert_array_equal(out[i], golden['g8_label%d' % i])
+        np.testing.assert_array_equal(np.asarray(out[3 + i], np.float32).reshape(-1, 4), golden['g8_list%d' % i])
+    np.testing.assert_array_equal(opost.pad_boxes([[], out[3], out[4]]), golden['g8_padded'])
+
+
+def _targets(batch, size, ncls, seed=1):
+    bl = seeded_boxes(batch, size, ncls, seed)
+    hw = np.array([[size // s, size // s] for s in (8, 16, 32)])
+    per = [opost.create_label(bb, hw, ncls) for bb in bl]
+    labels = [torch.from_numpy(np.stack([p[i] for p in per])) for i in range(3)]
+    boxes = [torch.from_numpy(opost.pad_boxes([p[3 + i] for p in per])) for i in range(3)]
+    return labels + boxes
+
+
+def _cfg_source(tag):
+    if tag.startswith('mbv2'):
+        return io.StringIO(zoo.cfg_text('mobilenetv2-fpn'))
+    import os
+    rel = {'rxfpn': 'regnetx-600m-fpn.cfg', 'rxpan': 'regnetx-600m-pan.cfg'}[tag.split('_')[0]]
+    path = os.path.join(REF_CFG, rel)
+    if not os.path.exists(path):
+        pytest.skip('reference cfg only in the build container')
+    return path
+
+
+@pytest.mark.parametrize('tag,size', [('mbv2_64', 64), ('rxfpn_64', 64), ('rxpan_64', 64), ('mbv2_512', 512)])
+def test_g5_full_model(golden, g5_names, tag, size):
+    torch.set_num_threads(8)
+    net = OracleNet(_cfg_source(tag))
+    seeded_fill(net, 0)
+    x = seeded_images(2, size, size, 0)
+    tgt = _targets(2, size, 20)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+    if 'g5_%s_eval' % tag in golden:
+        np.testing.assert_allclose(ev.numpy(), golden['g5_%s_eval' % tag], rtol=1e-4, atol=1e-4)
+    else:
+        np.testing.assert_allclose(ev[:, :64].numpy(), golden['g5_%s_eval_head' % tag], rtol=1e-4, atol=1e-4)
+    net.train()
+    out = net(x, tgt)
+    out['loss'].mean().backward()
+    got = np.array([out[k].item() for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss')]
+                   + [v.item() for v in out['loss_per_branch']])
+    np.testing.assert_allclose(got, golden['g5_%s_loss' % tag], rtol=1e-4)
+    names = [k for k, _ in net.named_parameters()]
+    assert names == g5_names[tag]
+    gn = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
+    np.testing.assert_allclose(gn, golden['g5_%s_gradnorm' % tag], rtol=2e-3, atol=1e-6)
+    sd = net.state_dict()
+    rm = [k for k in sd if k.endswith('running_mean')]
+    np.testing.assert_allclose(sd[rm[0]].numpy(), golden['g5_%s_rmean_first' % tag], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sd[rm[-1].replace('running_mean', 'running_var')].numpy(),
+                               golden['g5_%s_rvar_last' % tag], rtol=1e-5, atol=1e-6)

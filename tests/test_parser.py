@@ -1,0 +1,83 @@
+"""Host-side cfg reader / module builder against golden fixture G1 (recorded from the reference parser)."""
+import io
+import os
+
+import pytest
+import torch
+
+from pqdet_amd.model import cfgtext
+from pqdet_amd.model import zoo
+from pqdet_amd.model.parser import Parser
+
+REF_CFG = '/root/reference/model/cfg'
+
+
+def _norm(v):
+    """json round trip turns tuples into lists etc."""
+    import json
+    return json.loads(json.dumps(v))
+
+
+def test_lexer_corner_cases(g1):
+    for name, text in g1['snippets'].items():
+        want = g1['corner'][name]
+        try:
+            got = {'ok': _norm(list(cfgtext.iter_sections(io.StringIO(text))))}
+        except Exception as e:  # noqa: BLE001
+            got = {'err': type(e).__name__, 'msg': str(e)}
+        assert got == want, name
+
+
+def _describe(mods):
+    out = []
+    for m in mods:
+        d = {'type': m._type, 'stride': m._stride, 'out': m._output_channels,
+             'notprune': bool(getattr(m, '_notprune', False))}
+        if m._type == 'convolutional':
+            c = m.conv
+            d['conv'] = [c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], c.groups,
+                         c.bias is not None, hasattr(m, 'bn'), type(m.act).__name__ if hasattr(m, 'act') else 'none']
+        if hasattr(m, '_from'):
+            d['from'] = m._from
+        if hasattr(m, '_layers'):
+            d['layers'] = list(m._layers)
+        if m._type == 'yolo':
+            d['opt'] = dict(m.opt)
+        out.append(d)
+    return _norm(out)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason='reference cfg files only exist in the build container')
+def test_all_reference_cfgs_parse_like_the_reference(g1):
+    assert len(g1['cfgs']) == 26
+    for rel, want in g1['cfgs'].items():
+        with open(os.path.join(REF_CFG, rel)) as f:
+            specs = list(Parser(f).gen_layers())
+        assert _norm(specs) == want['specs'], rel
+        with open(os.path.join(REF_CFG, rel)) as f:
+            mods = Parser(f).torch_layers()
+        assert len(mods) == want['n_layers']
+        assert _describe(mods) == want['layers'], rel
+        assert sum(p.numel() for m in mods for p in m.parameters()) == want['params'], rel
+
+
+@pytest.mark.parametrize('name,rel', [('mobilenetv2-fpn', 'mobilenetv2-fpn.cfg'),
+                                      ('regnetx-600m-fpn', 'regnetx-600m-fpn.cfg'),
+                                      ('regnetx-600m-pan', 'regnetx-600m-pan.cfg')])
+def test_zoo_cfg_text_builds_the_reference_topology(g1, name, rel):
+    """Our generated cfg text (no reference file shipped) must build the same layer list."""
+    if name not in zoo.available():
+        pytest.skip('generator not written yet')
+    want = g1['cfgs'][rel]
+    mods = Parser(io.StringIO(zoo.cfg_text(name))).torch_layers()
+    assert _describe(mods) == want['layers']
+    assert sum(p.numel() for m in mods for p in m.parameters()) == want['params']
+
+
+def test_state_dict_key_layout():
+    mods = Parser(io.StringIO(zoo.cfg_text('mobilenetv2-fpn'))).torch_layers()
+    ml = torch.nn.ModuleList(mods)
+    keys = list(ml.state_dict().keys())
+    assert keys[0] == '0.conv.weight' and '0.bn.running_var' in keys and '0.bn.num_batches_tracked' in keys
+    assert len(keys) == 492
+    assert '71.conv.bias' in keys
