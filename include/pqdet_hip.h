@@ -1,0 +1,341 @@
+/*
+ * pqdet_hip.h -- C-ABI of libpqdet_hip.so (gfx950 / MI355X), the drop-in compute boundary of pqdet_amd.
+ *
+ * The reference (eleflea/PQDet) is pure Python on PyTorch and has no FFI of its own: every entry point below
+ * replaces arithmetic that the reference delegates to ATen/cuDNN/torchvision from the Python call sites cited
+ * next to it (paths are relative to the reference repo).  The host side (pqdet_amd/, Python, mirroring the
+ * reference's Python API) binds these with ctypes on raw device pointers; see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - all tensors fp32, activations NHWC with an explicit channel pitch `ld` (floats) so a tensor may live
+ *     inside a wider (concat / padded) buffer; weights keep PyTorch's OIHW layout (checkpoint compatible);
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*), never synchronises, never
+ *     allocates: scratch is passed in (`pq_*_scratch_bytes` gives sizes);
+ *   - return 0 on success, a negative PQ_E* code on bad arguments / launch failure (pq_last_error() has text);
+ *   - "virtual tensors": a conv+BN(+act) output is stored RAW (pre-BN) and consumers apply the per-channel affine
+ *     and activation while loading (pq_src).  Gradients w.r.t. a raw tensor are likewise applied on load from
+ *     (g, y) pairs (pq_gsrc):  dy = p*g + q*(y-mu) + r, the closed form of BatchNorm's backward.
+ */
+#ifndef PQDET_HIP_H
+#define PQDET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQ_OK 0
+#define PQ_EINVAL (-1)
+#define PQ_ELAUNCH (-2)
+#define PQ_EUNSUPPORTED (-3)
+
+/* activation codes -- reference model/parser.py:106-112 (ACTIVATION_MAP) + 'linear' */
+enum { PQ_ACT_LINEAR = 0, PQ_ACT_RELU = 1, PQ_ACT_RELU6 = 2, PQ_ACT_LEAKY = 3, PQ_ACT_LOGISTIC = 4, PQ_ACT_TANH = 5 };
+/* box loss kinds -- reference model/loss.py:62-81 */
+enum { PQ_BOX_L1 = 0, PQ_BOX_GIOU = 1, PQ_BOX_DIOU = 2, PQ_BOX_CIOU = 3, PQ_BOX_IOU = 4 };
+
+/* forward-value operand:  v[row][c] = act(scale[c] * x[row*ld + c] + shift[c]);  scale==NULL => identity affine */
+typedef struct pq_src {
+    const float* x;
+    const float* scale;
+    const float* shift;
+    int32_t ld;
+    int32_t act;
+} pq_src;
+
+/* gradient operand: v[row][c] = p[c]*g[row*ldg+c] + q[c]*(y[row*ldy+c] - mu[c]) + r[c];  y==NULL => v = g */
+typedef struct pq_gsrc {
+    const float* g;
+    const float* y;
+    const float* p;
+    const float* q;
+    const float* mu;
+    const float* r;
+    int32_t ldg;
+    int32_t ldy;
+} pq_gsrc;
+
+/* gradient destination for a (possibly virtual) tensor T = act(scale*y + shift):
+ *   dz arrives from a consumer; if accumulate, dz += g[...]; if finalize, g = dz * act'(scale*y+shift) and, when
+ *   mean!=NULL, per-channel partial sums  S1 = sum g,  S2 = sum g*(y-mean)*invstd  are written to
+ *   partial[block][0|1][ldp]  (one row pair per row-block; reduced by pq_bn_bwd_finalize). */
+typedef struct pq_gsink {
+    float* g;
+    const float* y;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+    float* partial;
+    int32_t ldg;
+    int32_t ldy;
+    int32_t act;
+    int32_t accumulate;
+    int32_t finalize;
+    int32_t ldp;
+} pq_gsink;
+
+/* ------------------------------------------------------------------ 1x1 convolution = fp32 MFMA GEMM
+ * replaces nn.Conv2d(k=1) forward/backward inside the conv blocks built at model/parser.py:389-410 and run by
+ * AnyModel.forward (model/interpreter.py:45-46).
+ *   fwd  : out[m][o] = sum_i in'[m][i] * w[o][i] (+ bias[o]);  rows m = B*H*W, optional spatial subsampling
+ *          (sub>1: row (b,oy,ox) reads input pixel (b,oy*sub,ox*sub) -- strided 1x1 conv);
+ *          partial!=NULL: also emit per-channel partial sums of out and out^2 (train-mode BN statistics).
+ *   dgrad: dz[m][i] = sum_o dy'[m][o] * w[o][i]  -> sink
+ *   wgrad: dw[o][i] = sum_m dy'[m][o] * in'[m][i]   (split over m into `splits` slabs, then reduced) */
+typedef struct pq_conv1x1_fwd_args {
+    pq_src in;
+    const float* w;      /* [O][I] */
+    const float* bias;   /* [O] or NULL */
+    float* out;          /* [M][ldo] raw */
+    float* partial;      /* [ceil(M/128)][2][ldp] or NULL */
+    int32_t M, I, O, ldo, ldp;
+    int32_t sub, OH, OW, IH, IW;   /* sub==1: plain; else strided gather of input rows */
+} pq_conv1x1_fwd_args;
+int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream);
+
+typedef struct pq_conv1x1_dgrad_args {
+    pq_gsrc dy;
+    const float* w;      /* [O][I] */
+    pq_gsink dx;
+    int32_t M, I, O;
+} pq_conv1x1_dgrad_args;
+int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream);
+
+typedef struct pq_conv1x1_wgrad_args {
+    pq_gsrc dy;
+    pq_src in;
+    float* dw;           /* [O][I] */
+    float* dbias;        /* [O] or NULL: column sums of dy' */
+    float* scratch;      /* >= pq_conv1x1_wgrad_scratch_bytes(M,I,O) */
+    int32_t M, I, O;
+} pq_conv1x1_wgrad_args;
+int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream);
+int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t O);
+
+/* ------------------------------------------------------------------ depthwise 3x3 (groups == channels), pad 1
+ * replaces nn.Conv2d(groups=C, k=3) fwd/bwd (mobilenetv2-fpn: 26 layers).  w is OIHW [C][1][3][3]. */
+typedef struct pq_dw3x3_fwd_args {
+    pq_src in;
+    const float* w;
+    float* out;          /* raw, pitch ldo */
+    float* partial;      /* [nblk][2][ldp] or NULL; nblk = pq_dw3x3_blocks(...) */
+    int32_t B, IH, IW, OH, OW, C, stride, ldo, ldp;
+} pq_dw3x3_fwd_args;
+int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream);
+int32_t pq_dw3x3_blocks(int32_t B, int32_t H, int32_t W, int32_t C);   /* row-blocks used for (B,H,W,C) outputs */
+
+typedef struct pq_dw3x3_dgrad_args {
+    pq_gsrc dy;          /* at output resolution */
+    const float* w;
+    pq_gsink dx;         /* at input resolution */
+    int32_t B, IH, IW, OH, OW, C, stride;
+} pq_dw3x3_dgrad_args;
+int pq_dw3x3_dgrad(const pq_dw3x3_dgrad_args* a, void* stream);
+
+typedef struct pq_dw3x3_wgrad_args {
+    pq_gsrc dy;
+    pq_src in;
+    float* dw;           /* [C][9] */
+    float* scratch;      /* >= pq_dw3x3_wgrad_scratch_bytes */
+    int32_t B, IH, IW, OH, OW, C, stride;
+} pq_dw3x3_wgrad_args;
+int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream);
+int64_t pq_dw3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_t OW, int32_t C);
+
+/* ------------------------------------------------------------------ network stem: dense 3x3 conv on the NCHW image
+ * (3 input channels, pad 1, stride 1|2), the first section of every shipped detector cfg. */
+typedef struct pq_stem3x3_fwd_args {
+    const float* image;  /* NCHW [B][CI][IH][IW] (dataset/augment.py:396 ToTensor layout) */
+    const float* w;      /* [O][CI][3][3] */
+    float* out;          /* NHWC raw, pitch ldo */
+    float* partial;
+    int32_t B, CI, IH, IW, OH, OW, O, stride, ldo, ldp;
+} pq_stem3x3_fwd_args;
+int pq_stem3x3_fwd(const pq_stem3x3_fwd_args* a, void* stream);
+
+typedef struct pq_stem3x3_wgrad_args {
+    pq_gsrc dy;
+    const float* image;
+    float* dw;
+    float* scratch;
+    int32_t B, CI, IH, IW, OH, OW, O, stride;
+} pq_stem3x3_wgrad_args;
+int pq_stem3x3_wgrad(const pq_stem3x3_wgrad_args* a, void* stream);
+int64_t pq_stem3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_t OW, int32_t O, int32_t CI);
+
+/* ------------------------------------------------------------------ BatchNorm2d statistics (train / eval)
+ * replaces nn.BatchNorm2d (model/parser.py:404-405): eps 1e-5, momentum 0.1, biased variance for normalisation,
+ * unbiased for running_var, num_batches_tracked += 1. */
+typedef struct pq_bn_fwd_finalize_args {
+    const float* partial;   /* [nblk][2][ldp]: sum x, sum x^2 */
+    const float* gamma;
+    const float* beta;
+    float* running_mean;    /* updated in place (train) / read (eval) */
+    float* running_var;
+    int64_t* num_batches_tracked;   /* may be NULL */
+    float* mean;            /* out [C] */
+    float* invstd;          /* out [C] */
+    float* scale;           /* out [C]: gamma*invstd */
+    float* shift;           /* out [C]: beta - mean*scale */
+    int32_t nblk, ldp, C, train;
+    float count, eps, momentum;
+} pq_bn_fwd_finalize_args;
+int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream);
+
+typedef struct pq_bn_bwd_finalize_args {
+    const float* partial;   /* [nblk][2][ldp]: sum g, sum g*xhat */
+    const float* gamma;
+    const float* invstd;
+    float* dgamma;
+    float* dbeta;
+    float* p;               /* out [C]: coefficient vectors of pq_gsrc */
+    float* q;
+    float* r;
+    int32_t nblk, ldp, C, train;
+    float count;
+} pq_bn_bwd_finalize_args;
+int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream);
+
+/* ------------------------------------------------------------------ shortcut / route / upsample
+ * forward  (model/parser.py:149-156 ShortCut, :178-183 Route, :450-452 UpsamplingNearest2d):
+ *   out[b,y,x,coff+c] = a'[b,y/up,x/up,c] (+ b'[b,y,x,c])
+ * backward: dz[b,ys,xs,c] = sum_{dy,dx<up} gout[b,ys*up+dy,xs*up+dx,coff+c]  -> sink */
+typedef struct pq_copy_args {
+    pq_src a;
+    pq_src b;            /* b.x == NULL: no second addend */
+    float* out;
+    int32_t B, H, W, C, ldo, coff, up;   /* H,W = OUTPUT size */
+} pq_copy_args;
+int pq_copy_fwd(const pq_copy_args* a, void* stream);
+
+typedef struct pq_route_bwd_args {
+    const float* gout;
+    pq_gsink dx;
+    int32_t B, H, W, C, ldgo, coff, up;  /* H,W = SOURCE (dx) size */
+} pq_route_bwd_args;
+int pq_route_bwd(const pq_route_bwd_args* a, void* stream);
+int32_t pq_ew_blocks(int32_t rows, int32_t C);   /* row-blocks used by elementwise sinks (partial rows) */
+
+/* ------------------------------------------------------------------ YOLO head: decode + loss
+ * decode: model/parser.py:206-235; loss: model/loss.py:22-115 (+ tools.py:357-477 IoU family).
+ * Element (b,h,w,a,k) of the head lives at  base[b*sb + h*sh + w*sw + (a*(5+C)+k)*sc]  (floats), so both the
+ * engine's NHWC head buffer and an NCHW tensor (standalone Decode/YOLOLayer API) are addressed in place. */
+typedef struct pq_head_view {
+    const float* base;
+    int64_t sb, sh, sw, sc;
+} pq_head_view;
+
+typedef struct pq_decode_args {
+    pq_head_view raw;
+    float* out;          /* [B][rows_total][5+C], this head starts at row `row0`, cells in (h,w,a) order */
+    int32_t B, H, W, A, C, stride, rows_total, row0;
+} pq_decode_args;
+int pq_decode(const pq_decode_args* a, void* stream);
+/* gradient of decode for the standalone API: draw = dpred * d(decode)/d(raw); `pred` is the decoded output */
+typedef struct pq_decode_bwd_args {
+    const float* pred;
+    const float* dpred;  /* [B][H][W][A][5+C] */
+    float* draw;         /* addressed through `view` (base ignored) */
+    pq_head_view view;
+    int32_t B, H, W, A, C, stride;
+} pq_decode_bwd_args;
+int pq_decode_bwd(const pq_decode_bwd_args* a, void* stream);
+
+typedef struct pq_yolo_loss_args {
+    pq_head_view in;     /* raw head (from_raw=1) or decoded pred (from_raw=0; then sb.. describe pred) */
+    const float* label;  /* [B][H][W][A][6+C] */
+    const float* boxes;  /* [B][M][4] zero padded */
+    float* partial;      /* scratch: [B][nblk][3] floats, nblk = pq_yolo_loss_blocks(H,W,A) */
+    float* losses;       /* out [4]: loss, box, conf, cls  (each already .mean over batch) */
+    int32_t* nan_flag;   /* out: set to 1 when loss is NaN (model/loss.py:110-114), may be NULL */
+    /* backward only */
+    const float* gscale; /* [3] upstream weights for (box, conf, cls) */
+    float* grad;         /* gradient w.r.t. `in` (same addressing as `in`) */
+    int64_t gsb, gsh, gsw, gsc;
+    int32_t B, H, W, A, C, M, stride, box_loss, from_raw;
+    float ignore_thresh, l1_gain;
+} pq_yolo_loss_args;
+int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream);
+int pq_yolo_loss_bwd(const pq_yolo_loss_args* a, void* stream);
+int32_t pq_yolo_loss_blocks(int32_t H, int32_t W, int32_t A);
+
+/* broadcast IoU family on (n,4) x (n,4) pairs (tools.py:357-477), kind = PQ_BOX_IOU/GIOU/DIOU/CIOU */
+int pq_iou_pairs(const float* b1, const float* b2, float* out, int32_t n, int32_t kind, void* stream);
+
+/* ------------------------------------------------------------------ Adam (trainer.py:160-163, torch.optim.Adam)
+ * one launch over the flat parameter / gradient / moment buffers. */
+typedef struct pq_adam_args {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, grad_scale;
+} pq_adam_args;
+int pq_adam_step(const pq_adam_args* a, void* stream);
+/* trainer.py:236-239 sparse-L1 on BN gammas: grad += ratio*sign(weight) over [n] */
+int pq_sign_l1(float* grad, const float* weight, int64_t n, float ratio, void* stream);
+int pq_fill(float* dst, float value, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ post-process
+ * recover: dataset/base_sample.py:98-139 (+ voc/coco/visdrone affine); in place like the reference:
+ *   coords -= [dx,dy,dx,dy]; /= ratio; clamp to [0, orig-1]; prob *= conf.  out (B,N,4+C). */
+typedef struct pq_recover_args {
+    float* pred;         /* [B][N][5+C]; when mutate!=0 it is also updated in place like the reference does */
+    const float* delta;  /* [B][2] (dy,dx) as returned by the affine fn, or [1][2] with per_image=0 */
+    const float* ratio;  /* [B] or [1] */
+    const float* orig;   /* [B][2] (h,w) or [1][2] */
+    float* out;          /* [B][N][4+C] */
+    int32_t B, N, C, per_image, mutate;
+} pq_recover_args;
+int pq_recover(const pq_recover_args* a, void* stream);
+
+/* NMS: tools.py:540-566 torch_nms (+ torchvision batched_nms, restated).  One image per call.
+ *   in  : bboxes [N][4+C] (recovered), score_thr, iou_thr
+ *   out : dets [cap][6] rows (x1,y1,x2,y2,score,class) in score-descending order, *count = K (device int32)
+ *   scratch sized by pq_nms_scratch_bytes(N, C).  Entirely on device, no host sync. */
+typedef struct pq_nms_args {
+    const float* bboxes;
+    float* dets;
+    int32_t* count;
+    void* scratch;
+    int64_t scratch_bytes;
+    int32_t N, C, cap;
+    float score_thr, iou_thr;
+} pq_nms_args;
+int pq_nms(const pq_nms_args* a, void* stream);
+int64_t pq_nms_scratch_bytes(int32_t N, int32_t C);
+
+/* ------------------------------------------------------------------ batched executor
+ * The engine compiles one training / inference step into an array of pq_op and replays it with ONE host call. */
+enum {
+    PQ_OP_CONV1X1_FWD = 1, PQ_OP_CONV1X1_DGRAD, PQ_OP_CONV1X1_WGRAD, PQ_OP_DW_FWD, PQ_OP_DW_DGRAD, PQ_OP_DW_WGRAD,
+    PQ_OP_STEM_FWD, PQ_OP_STEM_WGRAD, PQ_OP_BN_FWD_FIN, PQ_OP_BN_BWD_FIN, PQ_OP_COPY_FWD, PQ_OP_ROUTE_BWD,
+    PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL
+};
+typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
+typedef struct pq_op {
+    int32_t code;
+    int32_t pad;
+    union {
+        pq_conv1x1_fwd_args c1f; pq_conv1x1_dgrad_args c1d; pq_conv1x1_wgrad_args c1w;
+        pq_dw3x3_fwd_args dwf; pq_dw3x3_dgrad_args dwd; pq_dw3x3_wgrad_args dww;
+        pq_stem3x3_fwd_args stf; pq_stem3x3_wgrad_args stw;
+        pq_bn_fwd_finalize_args bnf; pq_bn_bwd_finalize_args bnb;
+        pq_copy_args cp; pq_route_bwd_args rb;
+        pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill;
+    } u;
+} pq_op;
+int pq_run_ops(const pq_op* ops, int32_t n, void* stream);
+/* index of the first failing op of the last pq_run_ops (or -1) and its message */
+int pq_last_failed_op(void);
+const char* pq_last_error(void);
+const char* pq_version(void);
+/* sizeof() of the argument struct of op `code` (0: pq_op, 100: pq_recover_args, 101: pq_nms_args,
+ * 102: pq_decode_bwd_args) -- lets a foreign-language binding verify its struct layout at load time */
+int32_t pq_abi_sizeof(int32_t code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+// Error plumbing and the batched op executor of libpqdet_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+static thread_local int g_failed_op = -1;
+
+void pq_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* pq_last_error(void) { return g_err; }
+extern "C" int pq_last_failed_op(void) { return g_failed_op; }
+extern "C" const char* pq_version(void) { return "pqdet_hip 0.1 (gfx950)"; }
+
+static int run_one(const pq_op& op, void* stream) {
+    switch (op.code) {
+        case PQ_OP_CONV1X1_FWD: return pq_conv1x1_fwd(&op.u.c1f, stream);
+        case PQ_OP_CONV1X1_DGRAD: return pq_conv1x1_dgrad(&op.u.c1d, stream);
+        case PQ_OP_CONV1X1_WGRAD: return pq_conv1x1_wgrad(&op.u.c1w, stream);
+        case PQ_OP_DW_FWD: return pq_dw3x3_fwd(&op.u.dwf, stream);
+        case PQ_OP_DW_DGRAD: return pq_dw3x3_dgrad(&op.u.dwd, stream);
+        case PQ_OP_DW_WGRAD: return pq_dw3x3_wgrad(&op.u.dww, stream);
+        case PQ_OP_STEM_FWD: return pq_stem3x3_fwd(&op.u.stf, stream);
+        case PQ_OP_STEM_WGRAD: return pq_stem3x3_wgrad(&op.u.stw, stream);
+        case PQ_OP_BN_FWD_FIN: return pq_bn_fwd_finalize(&op.u.bnf, stream);
+        case PQ_OP_BN_BWD_FIN: return pq_bn_bwd_finalize(&op.u.bnb, stream);
+        case PQ_OP_COPY_FWD: return pq_copy_fwd(&op.u.cp, stream);
+        case PQ_OP_ROUTE_BWD: return pq_route_bwd(&op.u.rb, stream);
+        case PQ_OP_DECODE: return pq_decode(&op.u.dec, stream);
+        case PQ_OP_LOSS_FWD: return pq_yolo_loss_fwd(&op.u.loss, stream);
+        case PQ_OP_LOSS_BWD: return pq_yolo_loss_bwd(&op.u.loss, stream);
+        case PQ_OP_ADAM: return pq_adam_step(&op.u.adam, stream);
+        case PQ_OP_FILL: return pq_fill(op.u.fill.dst, op.u.fill.value, op.u.fill.n, stream);
+        default:
+            pq_set_error("pq_run_ops: unknown op code %d", op.code);
+            return PQ_EINVAL;
+    }
+}
+
+extern "C" int pq_run_ops(const pq_op* ops, int32_t n, void* stream) {
+    g_failed_op = -1;
+    if (!ops || n < 0) { pq_set_error("pq_run_ops: bad arguments"); return PQ_EINVAL; }
+    for (int i = 0; i < n; ++i) {
+        const int rc = run_one(ops[i], stream);
+        if (rc != PQ_OK) { g_failed_op = i; return rc; }
+    }
+    return PQ_OK;
+}
+
+extern "C" int32_t pq_abi_sizeof(int32_t code) {
+    switch (code) {
+        case 0: return (int32_t)sizeof(pq_op);
+        case PQ_OP_CONV1X1_FWD: return (int32_t)sizeof(pq_conv1x1_fwd_args);
+        case PQ_OP_CONV1X1_DGRAD: return (int32_t)sizeof(pq_conv1x1_dgrad_args);
+        case PQ_OP_CONV1X1_WGRAD: return (int32_t)sizeof(pq_conv1x1_wgrad_args);
+        case PQ_OP_DW_FWD: return (int32_t)sizeof(pq_dw3x3_fwd_args);
+        case PQ_OP_DW_DGRAD: return (int32_t)sizeof(pq_dw3x3_dgrad_args);
+        case PQ_OP_DW_WGRAD: return (int32_t)sizeof(pq_dw3x3_wgrad_args);
+        case PQ_OP_STEM_FWD: return (int32_t)sizeof(pq_stem3x3_fwd_args);
+        case PQ_OP_STEM_WGRAD: return (int32_t)sizeof(pq_stem3x3_wgrad_args);
+        case PQ_OP_BN_FWD_FIN: return (int32_t)sizeof(pq_bn_fwd_finalize_args);
+        case PQ_OP_BN_BWD_FIN: return (int32_t)sizeof(pq_bn_bwd_finalize_args);
+        case PQ_OP_COPY_FWD: return (int32_t)sizeof(pq_copy_args);
+        case PQ_OP_ROUTE_BWD: return (int32_t)sizeof(pq_route_bwd_args);
+        case PQ_OP_DECODE: return (int32_t)sizeof(pq_decode_args);
+        case PQ_OP_LOSS_FWD: case PQ_OP_LOSS_BWD: return (int32_t)sizeof(pq_yolo_loss_args);
+        case PQ_OP_ADAM: return (int32_t)sizeof(pq_adam_args);
+        case PQ_OP_FILL: return (int32_t)sizeof(pq_fill_args);
+        case 100: return (int32_t)sizeof(pq_recover_args);
+        case 101: return (int32_t)sizeof(pq_nms_args);
+        case 102: return (int32_t)sizeof(pq_decode_bwd_args);
+        default: return -1;
+    }
+}

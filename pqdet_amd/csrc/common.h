@@ -1,0 +1,219 @@
+// Shared device helpers for the gfx950 kernels of libpqdet_hip.so.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pqdet_hip.h"
+
+#define PQ_WAVE 64
+
+namespace pq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- activations (reference model/parser.py:106-112) -------------------------------------------------------
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    switch (act) {
+        case PQ_ACT_RELU: return fmaxf(u, 0.f);
+        case PQ_ACT_RELU6: return fminf(fmaxf(u, 0.f), 6.f);
+        case PQ_ACT_LEAKY: return u > 0.f ? u : 0.1f * u;
+        case PQ_ACT_LOGISTIC: return 1.f / (1.f + __expf(-u));
+        case PQ_ACT_TANH: return tanhf(u);
+        default: return u;
+    }
+}
+// derivative w.r.t. the pre-activation u (ATen: threshold_backward / hardtanh_backward use strict bounds)
+__device__ __forceinline__ float act_bwd(float u, int act) {
+    switch (act) {
+        case PQ_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case PQ_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
+        case PQ_ACT_LEAKY: return u > 0.f ? 1.f : 0.1f;
+        case PQ_ACT_LOGISTIC: { float s = 1.f / (1.f + __expf(-u)); return s * (1.f - s); }
+        case PQ_ACT_TANH: { float t = tanhf(u); return 1.f - t * t; }
+        default: return 1.f;
+    }
+}
+
+// ---- operand loaders -----------------------------------------------------------------------------------------
+// Per-thread cached coefficient pack for 4 consecutive channels of a pq_src.
+struct SrcCoef4 {
+    float a[4], b[4];
+    int act;
+    bool affine;
+};
+__device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C) {
+    SrcCoef4 k;
+    k.act = s.act;
+    k.affine = s.scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = c0 + j;
+        bool ok = k.affine && c < C;
+        k.a[j] = ok ? s.scale[c] : 1.f;
+        k.b[j] = ok ? s.shift[c] : 0.f;
+    }
+    return k;
+}
+__device__ __forceinline__ float4 src_apply4(float4 v, const SrcCoef4& k) {
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float u = k.affine ? fmaf(k.a[j], r[j], k.b[j]) : r[j];
+        r[j] = act_fwd(u, k.act);
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+struct GsrcCoef4 {
+    float p[4], q[4], mu[4], r[4];
+    bool two;
+};
+__device__ __forceinline__ GsrcCoef4 gsrc_coef4(const pq_gsrc& s, int c0, int C) {
+    GsrcCoef4 k;
+    k.two = s.y != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = c0 + j;
+        bool ok = k.two && c < C;
+        k.p[j] = ok ? s.p[c] : 1.f;
+        k.q[j] = ok ? s.q[c] : 0.f;
+        k.mu[j] = ok ? s.mu[c] : 0.f;
+        k.r[j] = ok ? s.r[c] : 0.f;
+    }
+    return k;
+}
+__device__ __forceinline__ float4 gsrc_apply4(float4 g, float4 y, const GsrcCoef4& k) {
+    if (!k.two) return g;
+    float gg[4] = {g.x, g.y, g.z, g.w}, yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gg[j] = fmaf(k.p[j], gg[j], fmaf(k.q[j], yy[j] - k.mu[j], k.r[j]));
+    return make_float4(gg[0], gg[1], gg[2], gg[3]);
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+
+// ---- per-channel sink coefficients for 4 consecutive channels ------------------------------------------------
+struct SinkCoef4 {
+    float a[4], b[4], mean[4], inv[4];
+    bool affine, stats;
+    int act;
+};
+__device__ __forceinline__ SinkCoef4 sink_coef4(const pq_gsink& s, int c0, int C) {
+    SinkCoef4 k;
+    k.affine = s.scale != nullptr;
+    k.stats = s.mean != nullptr && s.partial != nullptr;
+    k.act = s.act;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = c0 + j;
+        bool ok = c < C;
+        k.a[j] = (k.affine && ok) ? s.scale[c] : 1.f;
+        k.b[j] = (k.affine && ok) ? s.shift[c] : 0.f;
+        k.mean[j] = (k.stats && ok) ? s.mean[c] : 0.f;
+        k.inv[j] = (k.stats && ok) ? s.invstd[c] : 0.f;
+    }
+    return k;
+}
+// Emit 4 channels of one row into the sink; returns g and accumulates the two statistics.
+__device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k, size_t row, int c0, float4 dz,
+                                           float4& s1, float4& s2) {
+    float* gp = s.g + row * (size_t)s.ldg + c0;
+    if (s.accumulate) dz = f4add(dz, ldg4(gp));
+    if (s.finalize && (k.act != PQ_ACT_LINEAR || k.stats)) {
+        float4 y4 = ldg4(s.y + row * (size_t)s.ldy + c0);
+        float d[4] = {dz.x, dz.y, dz.z, dz.w}, y[4] = {y4.x, y4.y, y4.z, y4.w};
+        float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float u = k.affine ? fmaf(k.a[j], y[j], k.b[j]) : y[j];
+            float g = d[j] * act_bwd(u, k.act);
+            d[j] = g;
+            if (k.stats) {
+                t1[j] += g;
+                t2[j] = fmaf(g, (y[j] - k.mean[j]) * k.inv[j], t2[j]);
+            }
+        }
+        dz = make_float4(d[0], d[1], d[2], d[3]);
+        s1 = make_float4(t1[0], t1[1], t1[2], t1[3]);
+        s2 = make_float4(t2[0], t2[1], t2[2], t2[3]);
+    }
+    stg4(gp, dz);
+}
+
+// ---- 2-D thread layout used by the NHWC elementwise / depthwise kernels ----------------------------------------
+// blockDim = (CX, PY): CX lanes walk channel quads (float4), PY walks rows / pixel groups.
+// Reduce two float4 accumulators over threadIdx.y and store to partial[blockIdx.x][0|1][ldp].
+template <int MAXT>
+__device__ __forceinline__ void block_reduce_store_stats(float4 s1, float4 s2, float* partial, int ldp, int c0, int C,
+                                                         float* lds /* >= MAXT*8 floats */) {
+    const int tx = threadIdx.x, ty = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
+    float* slot = lds + (size_t)(ty * nx + tx) * 8;
+    slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
+    slot[4] = s2.x; slot[5] = s2.y; slot[6] = s2.z; slot[7] = s2.w;
+    __syncthreads();
+    if (ty == 0 && c0 < C) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int y = 0; y < ny; ++y) {
+            const float* o = lds + (size_t)(y * nx + tx) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += o[j];
+        }
+        float* dst = partial + (size_t)blockIdx.x * 2 * ldp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < C) { dst[c0 + j] = acc[j]; dst[ldp + c0 + j] = acc[4 + j]; }
+    }
+}
+
+// Largest divisor of c4 that is <= 64 (channel-quad lanes per block row).
+inline int pick_cx(int c4) {
+    int best = 1;
+    for (int d = 1; d <= 64 && d <= c4; ++d)
+        if (c4 % d == 0) best = d;
+    return best;
+}
+
+// Launch geometry shared by every kernel that uses the (CX, PY) layout: gx row-blocks x gy channel chunks.
+struct EwGeom { int cx, py, gy, gx; };
+inline EwGeom ew_geom(long items, int C) {
+    EwGeom g;
+    const int c4 = (C + 3) / 4;
+    g.cx = pick_cx(c4);
+    g.py = 256 / g.cx;
+    if (g.py < 1) g.py = 1;
+    g.gy = (c4 + g.cx - 1) / g.cx;
+    long want = (items + g.py - 1) / g.py;
+    long cap = 2048 / g.gy;
+    if (cap < 64) cap = 64;
+    g.gx = (int)(want < cap ? want : cap);
+    if (g.gx < 1) g.gx = 1;
+    return g;
+}
+
+}  // namespace pq
+
+// host-side error plumbing (api.hip)
+void pq_set_error(const char* fmt, ...);
+#define PQ_CHECK_ARG(cond, msg)                         \
+    do {                                                \
+        if (!(cond)) {                                  \
+            pq_set_error("%s: %s", __func__, msg);      \
+            return PQ_EINVAL;                           \
+        }                                               \
+    } while (0)
+#define PQ_CHECK_LAUNCH()                                                   \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) {                                             \
+            pq_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return PQ_ELAUNCH;                                              \
+        }                                                                   \
+    } while (0)

@@ -1,0 +1,269 @@
+// Elementwise / reduction kernels: BatchNorm statistics finalisation (fwd + bwd), shortcut / route / upsample
+// forward copy and backward routing, Adam, fill.  All HBM-bound; float4 per lane, rows contiguous across lanes.
+#include "common.h"
+
+namespace pq {
+
+// ------------------------------------------------------------------------------------------------ BN finalize
+// One block of 256 threads = 16 channels x 16 row-lanes; partial is [nblk][2][ldp].
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize_args a) {
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    if (a.train) {
+        double s1 = 0.0, s2 = 0.0;
+        if (c < a.C)
+            for (int k = rl; k < a.nblk; k += 16) {
+                const float* row = a.partial + (size_t)k * 2 * a.ldp;
+                s1 += (double)row[c];
+                s2 += (double)row[a.ldp + c];
+            }
+        sh[0][cl][rl] = s1;
+        sh[1][cl][rl] = s2;
+        __syncthreads();
+        if (rl == 0 && c < a.C) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int k = 0; k < 16; ++k) { t1 += sh[0][cl][k]; t2 += sh[1][cl][k]; }
+            const double n = (double)a.count;
+            const double mean = t1 / n;
+            double var = t2 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float inv = (float)(1.0 / sqrt(var + (double)a.eps));
+            const float g = a.gamma[c], b = a.beta[c];
+            a.mean[c] = (float)mean;
+            a.invstd[c] = inv;
+            const float sc = g * inv;
+            a.scale[c] = sc;
+            a.shift[c] = b - (float)mean * sc;
+            if (a.running_mean) {
+                const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    } else if (rl == 0 && c < a.C) {
+        const float inv = 1.f / sqrtf(a.running_var[c] + a.eps);
+        const float sc = a.gamma[c] * inv;
+        a.mean[c] = a.running_mean[c];
+        a.invstd[c] = inv;
+        a.scale[c] = sc;
+        a.shift[c] = a.beta[c] - a.running_mean[c] * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize_args a) {
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < a.C)
+        for (int k = rl; k < a.nblk; k += 16) {
+            const float* row = a.partial + (size_t)k * 2 * a.ldp;
+            s1 += (double)row[c];
+            s2 += (double)row[a.ldp + c];
+        }
+    sh[0][cl][rl] = s1;
+    sh[1][cl][rl] = s2;
+    __syncthreads();
+    if (rl == 0 && c < a.C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < 16; ++k) { t1 += sh[0][cl][k]; t2 += sh[1][cl][k]; }
+        const float inv = a.invstd[c];
+        const float pc = a.gamma[c] * inv;
+        a.dbeta[c] = (float)t1;
+        a.dgamma[c] = (float)t2;
+        a.p[c] = pc;
+        if (a.train) {
+            a.q[c] = (float)(-(double)pc * (double)inv * t2 / (double)a.count);
+            a.r[c] = (float)(-(double)pc * t1 / (double)a.count);
+        } else {   // statistics frozen: dy = gamma*invstd*g
+            a.q[c] = 0.f;
+            a.r[c] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ copy / route
+struct CopyP { pq_copy_args a; int C4; };
+
+__global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
+    const pq_copy_args& a = p.a;
+    const int c4 = blockIdx.y * blockDim.x + threadIdx.x, c0 = c4 * 4;
+    if (c4 >= p.C4) return;
+    const SrcCoef4 ka = src_coef4(a.a, c0, a.C);
+    const SrcCoef4 kb = src_coef4(a.b, c0, a.C);
+    const bool two = a.b.x != nullptr;
+    const long rows = (long)a.B * a.H * a.W;
+    const int SH = a.H / a.up, SW = a.W / a.up;
+    for (long r = (long)blockIdx.x * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.x * blockDim.y) {
+        size_t sr = (size_t)r;
+        if (a.up > 1) {
+            const int x = (int)(r % a.W);
+            const long t2 = r / a.W;
+            const int y = (int)(t2 % a.H);
+            const long b = t2 / a.H;
+            sr = ((size_t)b * SH + y / a.up) * SW + x / a.up;
+        }
+        float4 v = src_apply4(ldg4(a.a.x + sr * a.a.ld + c0), ka);
+        if (two) v = f4add(v, src_apply4(ldg4(a.b.x + (size_t)r * a.b.ld + c0), kb));
+        stg4(a.out + (size_t)r * a.ldo + a.coff + c0, v);
+    }
+}
+
+struct RouteP { pq_route_bwd_args a; int C4; };
+
+__global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pq_route_bwd_args& a = p.a;
+    const int c4 = blockIdx.y * blockDim.x + threadIdx.x, c0 = c4 * 4;
+    const bool cok = c4 < p.C4;
+    const SinkCoef4 sk = sink_coef4(a.dx, c0, a.C);
+    const long rows = (long)a.B * a.H * a.W;
+    const int OH = a.H * a.up, OW = a.W * a.up;
+    float4 s1 = f4zero(), s2 = f4zero();
+    for (long r = (long)blockIdx.x * blockDim.y + threadIdx.y; r < rows && cok; r += (long)gridDim.x * blockDim.y) {
+        float4 dz = f4zero();
+        if (a.up == 1) {
+            dz = ldg4(a.gout + (size_t)r * a.ldgo + a.coff + c0);
+        } else {
+            const int x = (int)(r % a.W);
+            const long t2 = r / a.W;
+            const int y = (int)(t2 % a.H);
+            const long b = t2 / a.H;
+            for (int dy = 0; dy < a.up; ++dy)
+                for (int dx = 0; dx < a.up; ++dx) {
+                    const size_t orow = ((size_t)b * OH + (size_t)y * a.up + dy) * OW + (size_t)x * a.up + dx;
+                    dz = f4add(dz, ldg4(a.gout + orow * a.ldgo + a.coff + c0));
+                }
+        }
+        sink_emit4(a.dx, sk, (size_t)r, c0, dz, s1, s2);
+    }
+    float* part = (a.dx.finalize && a.dx.mean) ? a.dx.partial : nullptr;
+    if (part) block_reduce_store_stats<256>(s1, s2, part, a.dx.ldp, c0, a.C, lds);
+}
+
+// ------------------------------------------------------------------------------------------------ Adam etc.
+__global__ __launch_bounds__(256) void adam_kernel(pq_adam_args a) {
+    const int64_t n4 = a.n / 4;
+    const float step = a.lr / a.bias_correction1;
+    const float rs2 = 1.f / sqrtf(a.bias_correction2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 p4 = ldg4(a.param + 4 * i), g4 = ldg4(a.grad + 4 * i), m4 = ldg4(a.exp_avg + 4 * i), v4 = ldg4(a.exp_avg_sq + 4 * i);
+        float pp[4] = {p4.x, p4.y, p4.z, p4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float g = gg[j] * a.grad_scale;
+            if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, pp[j], g);
+            mm[j] = a.beta1 * mm[j] + (1.f - a.beta1) * g;
+            vv[j] = a.beta2 * vv[j] + (1.f - a.beta2) * g * g;
+            const float denom = sqrtf(vv[j]) * rs2 + a.eps;
+            pp[j] -= step * (mm[j] / denom);
+        }
+        stg4(a.param + 4 * i, make_float4(pp[0], pp[1], pp[2], pp[3]));
+        stg4(a.exp_avg + 4 * i, make_float4(mm[0], mm[1], mm[2], mm[3]));
+        stg4(a.exp_avg_sq + 4 * i, make_float4(vv[0], vv[1], vv[2], vv[3]));
+    }
+    // tail (n not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        float g = a.grad[i] * a.grad_scale;
+        if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, a.param[i], g);
+        const float m = a.beta1 * a.exp_avg[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.exp_avg_sq[i] + (1.f - a.beta2) * g * g;
+        a.exp_avg[i] = m;
+        a.exp_avg_sq[i] = v;
+        a.param[i] -= step * (m / (sqrtf(v) * rs2 + a.eps));
+    }
+}
+
+__global__ void fill_kernel(float* dst, float v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+__global__ void sign_l1_kernel(float* grad, const float* w, int64_t n, float ratio) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = w[i];
+        grad[i] += ratio * (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f));
+    }
+}
+
+}  // namespace pq
+
+using namespace pq;
+
+extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->gamma && a->beta && a->mean && a->invstd && a->scale && a->shift, "null pointer");
+    PQ_CHECK_ARG(a->C > 0, "empty");
+    PQ_CHECK_ARG(!a->train || (a->partial && a->nblk > 0 && a->count > 0.f), "train mode needs partial sums");
+    PQ_CHECK_ARG(a->train || (a->running_mean && a->running_var), "eval mode needs running statistics");
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + 15) / 16), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->partial && a->gamma && a->invstd && a->dgamma && a->dbeta && a->p && a->q && a->r, "null pointer");
+    PQ_CHECK_ARG(a->C > 0 && a->nblk > 0 && a->count > 0.f, "empty");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->C + 15) / 16), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_copy_fwd(const pq_copy_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->a.x && a->out, "null pointer");
+    PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->up >= 1, "bad shape");
+    PQ_CHECK_ARG(a->C % 4 == 0 && a->coff % 4 == 0 && a->ldo % 4 == 0 && a->a.ld % 4 == 0, "channels / offsets / pitches must be multiples of 4");
+    PQ_CHECK_ARG(a->H % a->up == 0 && a->W % a->up == 0, "output size must be a multiple of the upsample factor");
+    PQ_CHECK_ARG(!(a->b.x && a->up != 1), "second addend needs up==1");
+    CopyP p{*a, a->C / 4};
+    EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
+    hipLaunchKernelGGL(copy_fwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), 0, (hipStream_t)stream, p);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->gout && a->dx.g, "null pointer");
+    PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->up >= 1, "bad shape");
+    PQ_CHECK_ARG(a->C % 4 == 0 && a->coff % 4 == 0 && a->ldgo % 4 == 0 && a->dx.ldg % 4 == 0, "channels / offsets / pitches must be multiples of 4");
+    PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    RouteP p{*a, a->C / 4};
+    EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
+    hipLaunchKernelGGL(route_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float),
+                       (hipStream_t)stream, p);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_adam_step(const pq_adam_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->param && a->grad && a->exp_avg && a->exp_avg_sq, "null pointer");
+    PQ_CHECK_ARG(a->n > 0, "empty");
+    PQ_CHECK_ARG(((uintptr_t)a->param & 15) == 0 && ((uintptr_t)a->grad & 15) == 0 && ((uintptr_t)a->exp_avg & 15) == 0 &&
+                 ((uintptr_t)a->exp_avg_sq & 15) == 0, "buffers must be 16B aligned");
+    int64_t nb = (a->n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_fill(float* dst, float value, int64_t n, void* stream) {
+    PQ_CHECK_ARG(dst && n >= 0, "bad args");
+    if (n == 0) return PQ_OK;
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dst, value, n);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_sign_l1(float* grad, const float* weight, int64_t n, float ratio, void* stream) {
+    PQ_CHECK_ARG(grad && weight && n > 0, "bad args");
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(sign_l1_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, grad, weight, n, ratio);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}

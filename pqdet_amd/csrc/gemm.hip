@@ -1,0 +1,533 @@
+// 1x1 convolution as exact-fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+//   gemm_nt : C[m][n] = sum_k A'[m][k] * Bop[n][k]      forward (A' = act(bn(x)), Bop = W[O][I])
+//                                                        dgrad   (A' = dy',        Bop = W read as [k=o][n=i])
+//   gemm_tn : C[o][i] = sum_m dY'[m][o] * X'[m][i]       wgrad, split over m into slabs
+//
+// Tiles are staged global -> registers (operand transform applied here, once per element) -> LDS, with the next
+// k-tile's global loads in flight during the MFMA phase.  LDS rows are padded to 36 floats so the ds_read_b128
+// fragment reads of a 32x32x2 operand (lane = row, 4 consecutive k per lane half) are bank-conflict free.
+// The k index inside an 8-wide group is permuted identically for A and B (lane half h owns k = 4h..4h+3), which
+// leaves the contraction unchanged.
+#include "common.h"
+
+namespace pq {
+
+constexpr int BK = 32;
+constexpr int LDT = BK + 4;   // padded LDS row (floats)
+
+struct GemmP {
+    // A operand
+    const float* a0; const float* a1;          // x | g , y
+    const float* c0; const float* c1; const float* c2; const float* c3;   // scale,shift | p,q,mu,r
+    int lda0, lda1, act;
+    int sub, OH, OW, IH, IW;                    // strided row gather (forward only)
+    // B operand
+    const float* b; int ldb;
+    int M, N, K;
+    // epilogue 0/1
+    float* out; const float* bias; float* partial; int ldo, ldp;
+    // epilogue 2
+    pq_gsink sink;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// AMODE: 0 plain, 1 forward affine+act, 2 gradient pair.  BKN: B stored [k][n].  EMODE: 0 store(+bias), 1 store+stats, 2 sink
+template <int BM, int BN, int WM, int WN, int AMODE, bool BKN, int EMODE>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
+    constexpr int NWN = BN / WN;
+    constexpr int TI = WM / 32, TJ = WN / 32;
+    constexpr int AI = BM / 32;            // float4 A loads per thread per k-tile
+    constexpr int BI = BN / 32;            // float4 B loads per thread per k-tile
+    static_assert((BM / WM) * NWN == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    __shared__ float red[2 * 4 * 128];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w / NWN, wn = w % NWN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int M = p.M, N = p.N, K = p.K;
+
+    // ---- A load plan
+    const int ac4 = t & 7, ar0 = t >> 3;
+    const float* arow0[AI];
+    const float* arow1[AI];
+    bool avalid[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        int m = m0 + ar0 + 32 * i;
+        avalid[i] = m < M;
+        size_t src = (size_t)(avalid[i] ? m : 0);
+        if (p.sub > 1) {
+            int ox = (int)(src % p.OW); size_t tt = src / p.OW; int oy = (int)(tt % p.OH); size_t bb = tt / p.OH;
+            src = (bb * p.IH + (size_t)oy * p.sub) * p.IW + (size_t)ox * p.sub;
+        }
+        arow0[i] = p.a0 + src * (size_t)p.lda0;
+        arow1[i] = (AMODE == 2) ? p.a1 + src * (size_t)p.lda1 : nullptr;
+    }
+    // ---- B load plan
+    constexpr int BNQ = BN / 4;                 // float4 per k-row (BKN)
+    constexpr int BKROWS = 256 / BNQ;           // k rows per pass (BKN)
+    const int bc4 = BKN ? (t % BNQ) : (t & 7);
+    const int br0 = BKN ? (t / BNQ) : (t >> 3);
+    const bool bvec = BKN ? ((N & 3) == 0 && (p.ldb & 3) == 0) : ((p.ldb & 3) == 0);
+
+    float4 ra[AI], ra1[AI], rb[BI];
+    float4 rc0, rc1, rc2, rc3;
+    const int Kpad = (K + 3) & ~3;
+
+    auto load_tiles = [&](int k0) {
+        const int ka = k0 + 4 * ac4;
+        const bool kin = ka < Kpad;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            ra[i] = (avalid[i] && kin) ? ldg4(arow0[i] + ka) : f4zero();
+            if (AMODE == 2) ra1[i] = (avalid[i] && kin) ? ldg4(arow1[i] + ka) : f4zero();
+        }
+        if (AMODE == 1) {
+            rc0 = (kin && p.c0) ? ldg4(p.c0 + ka) : f4zero();
+            rc1 = (kin && p.c0) ? ldg4(p.c1 + ka) : f4zero();
+        } else if (AMODE == 2) {
+            rc0 = kin ? ldg4(p.c0 + ka) : f4zero();
+            rc1 = kin ? ldg4(p.c1 + ka) : f4zero();
+            rc2 = kin ? ldg4(p.c2 + ka) : f4zero();
+            rc3 = kin ? ldg4(p.c3 + ka) : f4zero();
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            if (!BKN) {
+                int n = n0 + br0 + 32 * i, kb = k0 + 4 * bc4;
+                const float* src = p.b + (size_t)n * p.ldb + kb;
+                if (n < N && kb < K) {
+                    if (bvec && kb + 3 < K) rb[i] = ldg4(src);
+                    else rb[i] = make_float4(src[0], kb + 1 < K ? src[1] : 0.f, kb + 2 < K ? src[2] : 0.f, kb + 3 < K ? src[3] : 0.f);
+                } else rb[i] = f4zero();
+            } else {
+                int k = k0 + br0 + BKROWS * i, n = n0 + 4 * bc4;
+                const float* src = p.b + (size_t)k * p.ldb + n;
+                if (k < K && n < N) {
+                    if (bvec) rb[i] = ldg4(src);
+                    else rb[i] = make_float4(src[0], n + 1 < N ? src[1] : 0.f, n + 2 < N ? src[2] : 0.f, n + 3 < N ? src[3] : 0.f);
+                } else rb[i] = f4zero();
+            }
+        }
+    };
+
+    auto store_tiles = [&](int k0) {
+        const int ka = k0 + 4 * ac4;
+        float c0[4] = {rc0.x, rc0.y, rc0.z, rc0.w}, c1[4] = {rc1.x, rc1.y, rc1.z, rc1.w};
+        float c2[4] = {rc2.x, rc2.y, rc2.z, rc2.w}, c3[4] = {rc3.x, rc3.y, rc3.z, rc3.w};
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            float y[4] = {0.f, 0.f, 0.f, 0.f};
+            if (AMODE == 2) { y[0] = ra1[i].x; y[1] = ra1[i].y; y[2] = ra1[i].z; y[3] = ra1[i].w; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float r = v[j];
+                if (AMODE == 1) {
+                    if (p.c0 != nullptr) r = fmaf(c0[j], r, c1[j]);
+                    r = act_fwd(r, p.act);
+                } else if (AMODE == 2) {
+                    r = fmaf(c0[j], r, fmaf(c1[j], y[j] - c2[j], c3[j]));
+                }
+                v[j] = (avalid[i] && ka + j < K) ? r : 0.f;
+            }
+            *reinterpret_cast<float4*>(&As[(ar0 + 32 * i) * LDT + 4 * ac4]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            if (!BKN) {
+                *reinterpret_cast<float4*>(&Bs[(br0 + 32 * i) * LDT + 4 * bc4]) = rb[i];
+            } else {
+                int kr = br0 + BKROWS * i;
+                Bs[(4 * bc4 + 0) * LDT + kr] = rb[i].x;
+                Bs[(4 * bc4 + 1) * LDT + kr] = rb[i].y;
+                Bs[(4 * bc4 + 2) * LDT + kr] = rb[i].z;
+                Bs[(4 * bc4 + 3) * LDT + kr] = rb[i].w;
+            }
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    rc0 = rc1 = rc2 = rc3 = f4zero();
+    // AMODE 2 with y == NULL never reaches this kernel (host dispatches AMODE 0 instead).
+    const int nk = (K + BK - 1) / BK;
+    load_tiles(0);
+    const int lrow = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        store_tiles(kt * BK);
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float4 af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + 32 * i + lrow) * LDT + ks * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + 32 * j + lrow) * LDT + ks * 8 + lh * 4]);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[i][j] = mfma32(af[i].x, bf[j].x, acc[i][j]);
+                    acc[i][j] = mfma32(af[i].y, bf[j].y, acc[i][j]);
+                    acc[i][j] = mfma32(af[i].z, bf[j].z, acc[i][j]);
+                    acc[i][j] = mfma32(af[i].w, bf[j].w, acc[i][j]);
+                }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    float s1[TJ], s2[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) s1[j] = s2[j] = 0.f;
+    bool want_stats = false;
+
+    if (EMODE == 2) {
+        const pq_gsink& sk = p.sink;
+        const bool affine = sk.scale != nullptr;
+        const bool stats = sk.mean != nullptr && sk.partial != nullptr;
+        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
+        want_stats = sk.finalize && stats;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int n = n0 + wn * WN + 32 * j + lrow;
+            const bool nok = n < N;
+            const float ca = (affine && nok) ? sk.scale[n] : 1.f, cb = (affine && nok) ? sk.shift[n] : 0.f;
+            const float cm = (stats && nok) ? sk.mean[n] : 0.f, ci = (stats && nok) ? sk.invstd[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M && nok) {
+                        float* gp = sk.g + (size_t)m * sk.ldg + n;
+                        float dz = acc[i][j][r];
+                        if (sk.accumulate) dz += *gp;
+                        if (need_y) {
+                            const float y = sk.y[(size_t)m * sk.ldy + n];
+                            const float u = affine ? fmaf(ca, y, cb) : y;
+                            dz *= act_bwd(u, sk.act);
+                            if (stats) { s1[j] += dz; s2[j] = fmaf(dz, (y - cm) * ci, s2[j]); }
+                        }
+                        *gp = dz;
+                    }
+                }
+        }
+    } else {
+        want_stats = (EMODE == 1) && p.partial != nullptr;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int n = n0 + wn * WN + 32 * j + lrow;
+            const bool nok = n < N;
+            const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M && nok) {
+                        const float v = acc[i][j][r] + bias;
+                        p.out[(size_t)m * p.ldo + n] = v;
+                        if (EMODE == 1) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                    }
+                }
+        }
+    }
+
+    if (want_stats) {   // uniform across the block
+        float* part = (EMODE == 2) ? p.sink.partial : p.partial;
+        const int ldp = (EMODE == 2) ? p.sink.ldp : p.ldp;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+            if (lh == 0) {
+                red[(0 * 4 + wm) * 128 + wn * WN + 32 * j + lrow] = s1[j];
+                red[(1 * 4 + wm) * 128 + wn * WN + 32 * j + lrow] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (t < BN) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int q = 0; q < BM / WM; ++q) { a += red[(0 * 4 + q) * 128 + t]; b += red[(1 * 4 + q) * 128 + t]; }
+            const int n = n0 + t;
+            if (n < N) {
+                float* dst = part + (size_t)blockIdx.y * 2 * ldp;
+                dst[n] = a;
+                dst[ldp + n] = b;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad (TN)
+struct GemmTP {
+    pq_gsrc dy; pq_src x;
+    float* slab;       // [splits][O*I (+O bias)] or final when splits==1
+    int M, O, I, rows_per_split, want_bias;
+    size_t slab_stride;
+};
+
+template <int BO, int BIc>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTP p) {
+    constexpr int WO = BO / 2, WI = BIc / 2, TO = WO / 32, TI = WI / 32;
+    constexpr int OQ = BO / 4, IQ = BIc / 4;               // float4 per tile row
+    constexpr int ORP = 256 / OQ, IRP = 256 / IQ;          // rows per pass
+    constexpr int OL = 32 / ORP, IL = 32 / IRP;            // passes
+    __shared__ __attribute__((aligned(16))) float Ys[32 * BO];
+    __shared__ __attribute__((aligned(16))) float Xs[32 * BIc];
+    __shared__ float bred[256 * 4];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wo = w >> 1, wi = w & 1;
+    const int tiles_i = (p.I + BIc - 1) / BIc;
+    const int to = blockIdx.x / tiles_i, ti = blockIdx.x % tiles_i;
+    const int o0 = to * BO, i0 = ti * BIc;
+    const int split = blockIdx.y;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+
+    const int yc4 = t % OQ, yr0 = t / OQ, xc4 = t % IQ, xr0 = t / IQ;
+    const int oc = o0 + 4 * yc4, ic = i0 + 4 * xc4;
+    const GsrcCoef4 gk = gsrc_coef4(p.dy, oc, p.O);
+    const SrcCoef4 xk = src_coef4(p.x, ic, p.I);
+    const bool ovec = oc + 3 < p.O, ivec = ic + 3 < p.I;
+    const bool do_bias = p.want_bias && ti == 0;
+
+    float4 ry[OL], ry1[OL], rx[IL];
+    float4 bsum = f4zero();
+
+    auto ld4 = [](const float* base, bool vec, int c, int C) -> float4 {
+        if (vec) return ldg4(base);
+        float4 v = f4zero();
+        if (c < C) v.x = base[0];
+        if (c + 1 < C) v.y = base[1];
+        if (c + 2 < C) v.z = base[2];
+        return v;
+    };
+    auto load_tiles = [&](int mb) {
+#pragma unroll
+        for (int l = 0; l < OL; ++l) {
+            int m = mb + yr0 + ORP * l;
+            bool ok = m < mend && oc < p.O;
+            ry[l] = ok ? ld4(p.dy.g + (size_t)m * p.dy.ldg + oc, ovec, oc, p.O) : f4zero();
+            ry1[l] = (ok && gk.two) ? ld4(p.dy.y + (size_t)m * p.dy.ldy + oc, ovec, oc, p.O) : f4zero();
+        }
+#pragma unroll
+        for (int l = 0; l < IL; ++l) {
+            int m = mb + xr0 + IRP * l;
+            bool ok = m < mend && ic < p.I;
+            rx[l] = ok ? ld4(p.x.x + (size_t)m * p.x.ld + ic, ivec, ic, p.I) : f4zero();
+        }
+    };
+    auto store_tiles = [&](int mb) {
+#pragma unroll
+        for (int l = 0; l < OL; ++l) {
+            int r = yr0 + ORP * l;
+            bool ok = (mb + r) < mend;
+            float4 v = gsrc_apply4(ry[l], ry1[l], gk);
+            float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (ok && oc + j < p.O) ? e[j] : 0.f;
+            v = make_float4(e[0], e[1], e[2], e[3]);
+            bsum = f4add(bsum, v);
+            *reinterpret_cast<float4*>(&Ys[r * BO + 4 * yc4]) = v;
+        }
+#pragma unroll
+        for (int l = 0; l < IL; ++l) {
+            int r = xr0 + IRP * l;
+            bool ok = (mb + r) < mend;
+            float4 v = src_apply4(rx[l], xk);
+            float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (ok && ic + j < p.I) ? e[j] : 0.f;
+            *reinterpret_cast<float4*>(&Xs[r * BIc + 4 * xc4]) = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    };
+
+    f32x16 acc[TO][TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    if (mbeg < mend) load_tiles(mbeg);
+    for (int mb = mbeg; mb < mend; mb += 32) {
+        __syncthreads();
+        store_tiles(mb);
+        __syncthreads();
+        if (mb + 32 < mend) load_tiles(mb + 32);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float af[TO], bf[TI];
+#pragma unroll
+            for (int a = 0; a < TO; ++a) af[a] = Ys[(2 * kk + lh) * BO + wo * WO + 32 * a + lrow];
+#pragma unroll
+            for (int b = 0; b < TI; ++b) bf[b] = Xs[(2 * kk + lh) * BIc + wi * WI + 32 * b + lrow];
+#pragma unroll
+            for (int a = 0; a < TO; ++a)
+#pragma unroll
+                for (int b = 0; b < TI; ++b) acc[a][b] = mfma32(af[a], bf[b], acc[a][b]);
+        }
+    }
+
+    float* dst = p.slab + (size_t)split * p.slab_stride;
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b) {
+            const int i = i0 + wi * WI + 32 * b + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo * WO + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < p.O && i < p.I) dst[(size_t)o * p.I + i] = acc[a][b][r];
+            }
+        }
+    if (do_bias) {   // uniform per block
+        __syncthreads();
+        bred[t * 4 + 0] = bsum.x; bred[t * 4 + 1] = bsum.y; bred[t * 4 + 2] = bsum.z; bred[t * 4 + 3] = bsum.w;
+        __syncthreads();
+        if (t < OQ) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int q = t; q < 256; q += OQ)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += bred[q * 4 + j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (o0 + 4 * t + j < p.O) dst[(size_t)p.O * p.I + o0 + 4 * t + j] = s[j];
+        }
+    }
+}
+
+// out[j] = sum_s slab[s*stride + j]
+__global__ void slab_reduce_kernel(const float* slab, size_t stride, int splits, float* out0, int n0, float* out1, int n1) {
+    const int n = n0 + n1;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(size_t)k * stride + j];
+        if (j < n0) out0[j] = s; else out1[j - n0] = s;
+    }
+}
+
+}  // namespace pq
+
+using namespace pq;
+
+// ------------------------------------------------------------------------------------------------ host dispatch
+template <int AMODE, bool BKN, int EMODE>
+static void launch_nt(const GemmP& p, hipStream_t st) {
+    const int N = p.N;
+    auto cost = [&](int bn, float pen) { return (float)(((N + bn - 1) / bn) * bn) * pen; };
+    const float c128 = cost(128, 1.0f), c64 = cost(64, 1.04f), c32 = cost(32, 1.10f);
+    dim3 blk(256);
+    if (c128 <= c64 && c128 <= c32) {
+        dim3 grid((N + 127) / 128, (p.M + 127) / 128);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, AMODE, BKN, EMODE>), grid, blk, 0, st, p);
+    } else if (c64 <= c32) {
+        dim3 grid((N + 63) / 64, (p.M + 127) / 128);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 64, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p);
+    } else {
+        dim3 grid((N + 31) / 32, (p.M + 127) / 128);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p);
+    }
+}
+
+extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->in.x && a->w && a->out, "null pointer");
+    PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
+    PQ_CHECK_ARG((a->in.ld & 3) == 0 && (((uintptr_t)a->in.x) & 15) == 0, "input pitch/pointer must be 16B aligned");
+    PQ_CHECK_ARG(a->ldo >= a->O && a->in.ld >= a->I, "pitch smaller than channel count");
+    PQ_CHECK_ARG(a->partial == nullptr || a->ldp >= a->O, "stats pitch too small");
+    PQ_CHECK_ARG(a->sub >= 1, "sub must be >= 1");
+    GemmP p{};
+    p.a0 = a->in.x; p.lda0 = a->in.ld; p.c0 = a->in.scale; p.c1 = a->in.shift; p.act = a->in.act;
+    p.sub = a->sub; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
+    p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->O; p.K = a->I;
+    p.out = a->out; p.bias = a->bias; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
+    hipStream_t st = (hipStream_t)stream;
+    const bool xform = a->in.scale != nullptr || a->in.act != PQ_ACT_LINEAR;
+    if (xform) {
+        if (a->partial) launch_nt<1, false, 1>(p, st); else launch_nt<1, false, 0>(p, st);
+    } else {
+        if (a->partial) launch_nt<0, false, 1>(p, st); else launch_nt<0, false, 0>(p, st);
+    }
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->dy.g && a->w && a->dx.g, "null pointer");
+    PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
+    PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "gradient pitch must be a multiple of 4");
+    PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    GemmP p{};
+    p.a0 = a->dy.g; p.a1 = a->dy.y; p.lda0 = a->dy.ldg; p.lda1 = a->dy.ldy;
+    p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
+    p.sub = 1;
+    p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->I; p.K = a->O;
+    p.sink = a->dx;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dy.y) launch_nt<2, true, 2>(p, st); else launch_nt<0, true, 2>(p, st);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, int& rows) {
+    big = (O >= 96 && I >= 96);
+    const int b = big ? 128 : 64;
+    tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
+    int want = (1024 + tiles - 1) / tiles;
+    int maxs = (M + 255) / 256;
+    splits = want < 1 ? 1 : (want > maxs ? maxs : want);
+    if (splits < 1) splits = 1;
+    rows = (((M + splits - 1) / splits) + 31) / 32 * 32;
+    splits = (M + rows - 1) / rows;
+}
+
+extern "C" int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t O) {
+    bool big; int tiles, splits, rows;
+    wgrad_plan(M, I, O, big, tiles, splits, rows);
+    return (int64_t)splits * ((int64_t)O * I + O) * 4;
+}
+
+extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->dw && a->scratch, "null pointer");
+    PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
+    PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->in.ld & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "pitches must be multiples of 4");
+    bool big; int tiles, splits, rows;
+    wgrad_plan(a->M, a->I, a->O, big, tiles, splits, rows);
+    GemmTP p{};
+    p.dy = a->dy; p.x = a->in; p.slab = a->scratch; p.M = a->M; p.O = a->O; p.I = a->I;
+    p.rows_per_split = rows; p.want_bias = a->dbias != nullptr;
+    p.slab_stride = (size_t)a->O * a->I + a->O;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(tiles, splits), blk(256);
+    if (big) hipLaunchKernelGGL((gemm_tn_kernel<128, 128>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
+    PQ_CHECK_LAUNCH();
+    const int n0 = a->O * a->I, n1 = a->dbias ? a->O : 0;
+    int rb = (n0 + n1 + 255) / 256; if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)a->scratch, p.slab_stride, splits,
+                       a->dw, n0, a->dbias, n1);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}

@@ -1,0 +1,320 @@
+// Post-process on device: box recovery (reference dataset/base_sample.py:98-139) and multi-label class-aware NMS
+// (reference tools.py:540-566 + torchvision.ops.boxes.batched_nms, restated -- see oracle/postprocess.py).
+//
+// NMS pipeline, one image, no host synchronisation:
+//   1. mark    : every (box, class) score > thr becomes a candidate; key = score (non-candidates -inf), value = the
+//                row-major element index; also count candidates and take the max coordinate over candidate boxes.
+//   2. sort    : stable descending radix sort by score (rocPRIM device primitive) -> rank order = torchvision's
+//                processing order (ties keep ascending candidate index).
+//   3. bucket  : stable sort of ranks by class -> per-class lists in rank order (+ class histogram / offsets).
+//   4. greedy  : one 256-thread workgroup per class walks its list 64 candidates at a time: all four waves test the
+//                chunk against the boxes kept so far (kept list striped over waves), wave 0 resolves the 64x64
+//                intra-chunk dependencies with ballot masks; arithmetic is torchvision's, bit for bit:
+//                boxes + cls*(max+1), area = (x2-x1)*(y2-y1), suppress iff inter/(a_i+a_j-inter) > thr
+//                (compiled with -ffp-contract=off so no FMA contraction changes a comparison).
+//   5. compact : kept flags are compacted in rank order -> dets rows (x1,y1,x2,y2,score,class), count.
+#include <cstring>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+#include "common.h"
+
+namespace pq {
+
+__global__ __launch_bounds__(256) void recover_kernel(pq_recover_args a) {
+    const int nv = 5 + a.C, no = 4 + a.C;
+    const long rows = (long)a.B * a.N;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const int b = (int)(r / a.N);
+        const int bi = a.per_image ? b : 0;
+        float* src = a.pred + (size_t)r * nv;
+        float* dst = a.out + (size_t)r * no;
+        const float dyv = a.delta[bi * 2 + 0], dxv = a.delta[bi * 2 + 1];
+        const float ratio = a.ratio[bi];
+        const float mh = a.orig[bi * 2 + 0] - 1.f, mw = a.orig[bi * 2 + 1] - 1.f;
+        float x1 = (src[0] - dxv) / ratio, y1 = (src[1] - dyv) / ratio;
+        float x2 = (src[2] - dxv) / ratio, y2 = (src[3] - dyv) / ratio;
+        x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f);
+        x2 = fminf(x2, mw); y2 = fminf(y2, mh);
+        const float conf = src[4];
+        dst[0] = x1; dst[1] = y1; dst[2] = x2; dst[3] = y2;
+        if (a.mutate) { src[0] = x1; src[1] = y1; src[2] = x2; src[3] = y2; }
+        for (int k = 0; k < a.C; ++k) {
+            const float v = src[5 + k] * conf;
+            dst[4 + k] = v;
+            if (a.mutate) src[5 + k] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NMS
+struct NmsMeta { unsigned count; unsigned maxbits; unsigned kept; unsigned pad; };
+
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned o) { unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; return __uint_as_float(u); }
+
+__global__ __launch_bounds__(256) void nms_mark_kernel(const float* bboxes, int N, int C, float thr, float* keys, unsigned* vals,
+                                                        NmsMeta* meta) {
+    const long E = (long)N * C;
+    unsigned cnt = 0, mx = 0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long)gridDim.x * 256) {
+        const int i = (int)(e / C), c = (int)(e % C);
+        const float* row = bboxes + (size_t)i * (4 + C);
+        const float s = row[4 + c];
+        const bool hit = s > thr;
+        keys[e] = hit ? s : -INFINITY;
+        vals[e] = (unsigned)e;
+        if (hit) {
+            ++cnt;
+            const float m = fmaxf(fmaxf(row[0], row[1]), fmaxf(row[2], row[3]));
+            const unsigned o = f2ord(m);
+            mx = o > mx ? o : mx;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_xor(cnt, off);
+        const unsigned o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(&meta->count, cnt);
+        if (mx) atomicMax(&meta->maxbits, mx);
+    }
+}
+
+// class key per rank (0xFFFF for non-candidates) + histogram
+__global__ __launch_bounds__(256) void nms_classkey_kernel(const unsigned* sorted_vals, long E, int C, const NmsMeta* meta,
+                                                            unsigned* ckeys, unsigned* ranks, unsigned* hist) {
+    const unsigned K = meta->count;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < E; r += (long)gridDim.x * 256) {
+        ranks[r] = (unsigned)r;
+        if (r < K) {
+            const unsigned c = sorted_vals[r] % (unsigned)C;
+            ckeys[r] = c;
+            atomicAdd(&hist[c], 1u);
+        } else {
+            ckeys[r] = 0xFFFFu;
+        }
+    }
+}
+
+__global__ void nms_offsets_kernel(const unsigned* hist, int C, unsigned* offs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned s = 0;
+        for (int c = 0; c < C; ++c) { offs[c] = s; s += hist[c]; }
+        offs[C] = s;
+    }
+}
+
+__device__ __forceinline__ bool nms_overlap(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2,
+                                            float by2, float barea, float thr) {
+    const float w = fmaxf(0.f, fminf(ax2, bx2) - fmaxf(ax1, bx1));
+    const float h = fmaxf(0.f, fminf(ay2, by2) - fmaxf(ay1, by1));
+    const float inter = w * h;
+    const float ovr = inter / (aarea + barea - inter);
+    return ovr > thr;
+}
+
+__global__ __launch_bounds__(256) void nms_greedy_kernel(const float* bboxes, int C, const unsigned* sorted_vals,
+                                                          const unsigned* class_ranks, const unsigned* offs, const NmsMeta* meta,
+                                                          float thr, float* keptbuf, unsigned* keepflag) {
+    __shared__ unsigned sdead[4][64];
+    __shared__ unsigned s_nk;
+    const int c = blockIdx.x;
+    const unsigned beg = offs[c], end = offs[c + 1];
+    if (beg == end) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float off = (float)c * (ord2f(meta->maxbits) + 1.f);
+    float* kept = keptbuf + (size_t)beg * 5;
+    if (threadIdx.x == 0) s_nk = 0;
+    __syncthreads();
+    for (unsigned base = beg; base < end; base += 64) {
+        const unsigned j = base + lane;
+        const bool valid = j < end;
+        unsigned rank = 0;
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, area = 0.f;
+        if (valid) {
+            rank = class_ranks[j];
+            const unsigned e = sorted_vals[rank];
+            const float* row = bboxes + (size_t)(e / (unsigned)C) * (4 + C);
+            x1 = row[0] + off; y1 = row[1] + off; x2 = row[2] + off; y2 = row[3] + off;
+            area = (x2 - x1) * (y2 - y1);
+        }
+        const unsigned nk = s_nk;
+        unsigned dead = 0;
+        for (unsigned k = w; k < nk; k += 4) {
+            const float kx1 = __hip_atomic_load(&kept[k * 5 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float ky1 = __hip_atomic_load(&kept[k * 5 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float kx2 = __hip_atomic_load(&kept[k * 5 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float ky2 = __hip_atomic_load(&kept[k * 5 + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float ka = __hip_atomic_load(&kept[k * 5 + 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nms_overlap(kx1, ky1, kx2, ky2, ka, x1, y1, x2, y2, area, thr)) dead = 1;
+        }
+        sdead[w][lane] = dead;
+        __syncthreads();
+        if (w == 0) {
+            bool alive = valid && !(sdead[0][lane] | sdead[1][lane] | sdead[2][lane] | sdead[3][lane]);
+            // which earlier lanes of this chunk would suppress me
+            unsigned long long supp = 0ull;
+            for (int i = 0; i < 64; ++i) {
+                const float ix1 = __shfl(x1, i), iy1 = __shfl(y1, i), ix2 = __shfl(x2, i), iy2 = __shfl(y2, i), ia = __shfl(area, i);
+                if (i < lane && nms_overlap(ix1, iy1, ix2, iy2, ia, x1, y1, x2, y2, area, thr)) supp |= (1ull << i);
+            }
+            unsigned long long am = __ballot(alive);
+            for (int i = 0; i < 63; ++i) {
+                if ((am >> i) & 1ull) {
+                    if ((supp >> i) & 1ull) alive = false;
+                    am = __ballot(alive);
+                }
+            }
+            const unsigned long long below = (lane == 0) ? 0ull : (am & ((1ull << lane) - 1ull));
+            if (alive) {
+                const unsigned pos = nk + (unsigned)__popcll(below);
+                __hip_atomic_store(&kept[pos * 5 + 0], x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&kept[pos * 5 + 1], y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&kept[pos * 5 + 2], x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&kept[pos * 5 + 3], y2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&kept[pos * 5 + 4], area, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                keepflag[rank] = 1u;
+            }
+            if (lane == 0) s_nk = nk + (unsigned)__popcll(am);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+}
+
+// single workgroup: ordered compaction of keepflag[0..K) -> dets
+__global__ __launch_bounds__(1024) void nms_compact_kernel(const float* bboxes, int C, const float* sorted_keys, const unsigned* sorted_vals,
+                                                            const unsigned* keepflag, NmsMeta* meta, float* dets, int cap, int32_t* count) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned running;
+    const unsigned K = meta->count;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < K; base += 1024) {
+        const unsigned r = base + threadIdx.x;
+        const bool keep = r < K && keepflag[r] != 0u;
+        const unsigned long long bal = __ballot(keep);
+        const unsigned inwave = (unsigned)__popcll(bal & ((lane == 0) ? 0ull : ((1ull << lane) - 1ull)));
+        if (lane == 0) wsum[w] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = running;
+        for (int q = 0; q < w; ++q) before += wsum[q];
+        if (keep) {
+            const unsigned pos = before + inwave;
+            if ((int)pos < cap) {
+                const unsigned e = sorted_vals[r];
+                const float* row = bboxes + (size_t)(e / (unsigned)C) * (4 + C);
+                float* d = dets + (size_t)pos * 6;
+                d[0] = row[0]; d[1] = row[1]; d[2] = row[2]; d[3] = row[3];
+                d[4] = sorted_keys[r];
+                d[5] = (float)(e % (unsigned)C);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (int q = 0; q < 16; ++q) tot += wsum[q];
+            running += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        meta->kept = running;
+        *count = (int32_t)running;
+    }
+}
+
+}  // namespace pq
+
+using namespace pq;
+
+extern "C" int pq_recover(const pq_recover_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->pred && a->delta && a->ratio && a->orig && a->out, "null pointer");
+    PQ_CHECK_ARG(a->B > 0 && a->N > 0 && a->C > 0, "bad shape");
+    long rows = (long)a->B * a->N;
+    long nb = (rows + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(recover_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct NmsLayout {
+    size_t keys0, keys1, vals0, vals1, ckeys0, ckeys1, rk0, rk1, keep, kept, hist, offs, meta, tmp, total;
+};
+static NmsLayout nms_layout(long E, int C) {
+    NmsLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    L.meta = take(sizeof(NmsMeta));
+    L.hist = take((size_t)(C + 1) * 4);
+    L.offs = take((size_t)(C + 2) * 4);
+    L.keep = take((size_t)E * 4);
+    L.keys0 = take((size_t)E * 4); L.keys1 = take((size_t)E * 4);
+    L.vals0 = take((size_t)E * 4); L.vals1 = take((size_t)E * 4);
+    L.ckeys0 = take((size_t)E * 4); L.ckeys1 = take((size_t)E * 4);
+    L.rk0 = take((size_t)E * 4); L.rk1 = take((size_t)E * 4);
+    L.kept = take((size_t)E * 5 * 4);
+    L.tmp = o;
+    L.total = o;
+    return L;
+}
+
+extern "C" int64_t pq_nms_scratch_bytes(int32_t N, int32_t C) {
+    const long E = (long)N * C;
+    NmsLayout L = nms_layout(E, C);
+    // rocPRIM radix-sort temporary storage: double buffers for keys+values plus histograms; bounded generously
+    return (int64_t)(L.total + (size_t)E * 24 + (8u << 20));
+}
+
+extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->bboxes && a->dets && a->count && a->scratch, "null pointer");
+    PQ_CHECK_ARG(a->N > 0 && a->C > 0 && a->C < 65535 && a->cap > 0, "bad shape");
+    const long E = (long)a->N * a->C;
+    PQ_CHECK_ARG(E < (1l << 31), "too many (box, class) pairs");
+    hipStream_t st = (hipStream_t)stream;
+    NmsLayout L = nms_layout(E, a->C);
+    PQ_CHECK_ARG((int64_t)L.total < a->scratch_bytes, "scratch too small");
+    char* base = (char*)a->scratch;
+    NmsMeta* meta = (NmsMeta*)(base + L.meta);
+    unsigned* hist = (unsigned*)(base + L.hist);
+    unsigned* offs = (unsigned*)(base + L.offs);
+    unsigned* keep = (unsigned*)(base + L.keep);
+    float* keys0 = (float*)(base + L.keys0); float* keys1 = (float*)(base + L.keys1);
+    unsigned* vals0 = (unsigned*)(base + L.vals0); unsigned* vals1 = (unsigned*)(base + L.vals1);
+    unsigned* ck0 = (unsigned*)(base + L.ckeys0); unsigned* ck1 = (unsigned*)(base + L.ckeys1);
+    unsigned* rk0 = (unsigned*)(base + L.rk0); unsigned* rk1 = (unsigned*)(base + L.rk1);
+    float* kept = (float*)(base + L.kept);
+    void* tmp = base + L.tmp;
+    const size_t tmp_avail = (size_t)a->scratch_bytes - L.tmp;
+
+    // zero meta + hist + offs + keep (contiguous prefix of the layout)
+    if (hipMemsetAsync(base, 0, L.keys0, st) != hipSuccess) { pq_set_error("pq_nms: memset failed"); return PQ_ELAUNCH; }
+    long nb = (E + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(nms_mark_kernel, dim3((unsigned)nb), dim3(256), 0, st, a->bboxes, a->N, a->C, a->score_thr, keys0, vals0, meta);
+    PQ_CHECK_LAUNCH();
+    size_t need = 0;
+    hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, need, keys0, keys1, vals0, vals1, (size_t)E, 0, 32, st);
+    if (e != hipSuccess || need > tmp_avail) { pq_set_error("pq_nms: sort scratch (%zu needed, %zu available)", need, tmp_avail); return PQ_EINVAL; }
+    e = rocprim::radix_sort_pairs_desc(tmp, need, keys0, keys1, vals0, vals1, (size_t)E, 0, 32, st);
+    if (e != hipSuccess) { pq_set_error("pq_nms: radix sort failed: %s", hipGetErrorString(e)); return PQ_ELAUNCH; }
+    hipLaunchKernelGGL(nms_classkey_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const unsigned*)vals1, E, a->C, (const NmsMeta*)meta, ck0, rk0, hist);
+    PQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)hist, a->C, offs);
+    PQ_CHECK_LAUNCH();
+    size_t need2 = 0;
+    e = rocprim::radix_sort_pairs(nullptr, need2, ck0, ck1, rk0, rk1, (size_t)E, 0, 16, st);
+    if (e != hipSuccess || need2 > tmp_avail) { pq_set_error("pq_nms: class-sort scratch (%zu needed, %zu available)", need2, tmp_avail); return PQ_EINVAL; }
+    e = rocprim::radix_sort_pairs(tmp, need2, ck0, ck1, rk0, rk1, (size_t)E, 0, 16, st);
+    if (e != hipSuccess) { pq_set_error("pq_nms: class sort failed: %s", hipGetErrorString(e)); return PQ_ELAUNCH; }
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a->C), dim3(256), 0, st, a->bboxes, a->C, (const unsigned*)vals1, (const unsigned*)rk1,
+                       (const unsigned*)offs, (const NmsMeta*)meta, a->iou_thr, kept, keep);
+    PQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(1024), 0, st, a->bboxes, a->C, (const float*)keys1, (const unsigned*)vals1,
+                       (const unsigned*)keep, meta, a->dets, a->cap, a->count);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}

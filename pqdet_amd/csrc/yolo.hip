@@ -1,0 +1,353 @@
+// YOLO head: box decode (reference model/parser.py:206-235), fused per-cell loss forward / backward
+// (reference model/loss.py:22-115) and the IoU family (reference tools.py:357-477), gfx950.
+//
+// One lane owns one (b, h, w, anchor) cell: it streams the cell's 5+C head values and 6+C label values once,
+// evaluates box / objectness / class terms and -- in the backward kernel -- writes the gradient w.r.t. the raw head
+// directly (the (B,H,W,A,M) IoU tensor, the focal / BCE temporaries and the decoded prediction of the eager
+// reference are never materialised).  Gradients follow ATen's formulas exactly: BCE backward is
+// (p - t) / max((1 - p) * p, 1e-12) (not the derivative of the clamped logs), focal weights are differentiated,
+// the ignore mask is not, ciou's alpha is a constant.
+#include "common.h"
+
+namespace pq {
+
+struct D4 { float v; float d[4]; };
+__device__ __forceinline__ D4 dvar(float v, int k) { D4 r; r.v = v; r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0.f; r.d[k] = 1.f; return r; }
+__device__ __forceinline__ D4 dcst(float v) { D4 r; r.v = v; r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0.f; return r; }
+__device__ __forceinline__ D4 operator+(D4 a, D4 b) { D4 r; r.v = a.v + b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D4 operator-(D4 a, D4 b) { D4 r; r.v = a.v - b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D4 operator*(D4 a, D4 b) { D4 r; r.v = a.v * b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
+    D4 r; r.v = a.v / b.v;
+    const float ib = 1.f / b.v;
+    for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    return r;
+}
+__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return (a.v >= b.v) ? a : b; }
+__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return (a.v <= b.v) ? a : b; }
+__device__ __forceinline__ D4 datan(D4 a) { D4 r; r.v = atanf(a.v); const float g = 1.f / (1.f + a.v * a.v); for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * g; return r; }
+
+// IoU-family value (and derivative w.r.t. box 1) -- tools.py:357-477, no epsilon anywhere.
+__device__ __forceinline__ D4 iou_family(const D4 (&b1)[4], const float (&b2)[4], int kind) {
+    const D4 t0 = dcst(b2[0]), t1 = dcst(b2[1]), t2 = dcst(b2[2]), t3 = dcst(b2[3]);
+    const D4 zero = dcst(0.f);
+    const D4 w1 = b1[2] - b1[0], h1 = b1[3] - b1[1];
+    const D4 a1 = w1 * h1;
+    const float w2 = b2[2] - b2[0], h2 = b2[3] - b2[1];
+    const D4 a2 = dcst(w2 * h2);
+    const D4 iw = dmax(dmin(b1[2], t2) - dmax(b1[0], t0), zero);
+    const D4 ih = dmax(dmin(b1[3], t3) - dmax(b1[1], t1), zero);
+    const D4 inter = iw * ih;
+    const D4 uni = a1 + a2 - inter;
+    const D4 iou = inter / uni;
+    if (kind == PQ_BOX_IOU) return iou;
+    const D4 elx = dmin(b1[0], t0), ely = dmin(b1[1], t1), ehx = dmax(b1[2], t2), ehy = dmax(b1[3], t3);
+    const D4 ew = dmax(ehx - elx, zero), eh = dmax(ehy - ely, zero);
+    const D4 earea = ew * eh;
+    const D4 g = iou - (earea - uni) / earea;
+    if (kind == PQ_BOX_GIOU) return g;
+    const D4 half = dcst(0.5f);                       // (a + b) / 2 == (a + b) * 0.5 exactly in binary fp
+    const D4 cx = (b1[0] + b1[2]) * half - dcst((b2[0] + b2[2]) / 2.f);
+    const D4 cy = (b1[1] + b1[3]) * half - dcst((b2[1] + b2[3]) / 2.f);
+    const D4 dc = cx * cx + cy * cy;
+    const D4 ex = elx - ehx, ey = ely - ehy;
+    const D4 de = ex * ex + ey * ey;
+    const D4 dterm = g + dc / de;                     // '+' as written in the reference (tools.py:437)
+    if (kind == PQ_BOX_DIOU) return dterm;
+    const D4 at = datan(w1 / h1) - dcst(atanf(w2 / h2));
+    const D4 v = dcst(4.f / (3.14159265358979323846f * 3.14159265358979323846f)) * (at * at);
+    const float alpha = v.v / ((1.f - iou.v) + v.v);  // no_grad in the reference (tools.py:473-475)
+    return dterm + dcst(alpha) * v;
+}
+
+__device__ __forceinline__ float plain_iou(float x1, float y1, float x2, float y2, float a1, const float* bx) {
+    const float a2 = (bx[2] - bx[0]) * (bx[3] - bx[1]);
+    const float iw = fmaxf(fminf(x2, bx[2]) - fmaxf(x1, bx[0]), 0.f);
+    const float ih = fmaxf(fminf(y2, bx[3]) - fmaxf(y1, bx[1]), 0.f);
+    const float inter = iw * ih;
+    return inter / (a1 + a2 - inter);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float bce_val(float p, float t) {
+    return (t - 1.f) * fmaxf(logf(1.f - p), -100.f) - t * fmaxf(logf(p), -100.f);
+}
+__device__ __forceinline__ float bce_grad(float p, float t) { return (p - t) / fmaxf((1.f - p) * p, 1e-12f); }
+
+// ------------------------------------------------------------------------------------------------ loss kernel
+template <bool GRAD>
+__global__ __launch_bounds__(256) void yolo_loss_kernel(pq_yolo_loss_args a) {
+    __shared__ float sbox[128 * 4];
+    __shared__ float wred[4][3];
+    const int b = blockIdx.y;
+    const int cells = a.H * a.W * a.A;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    const int nv = 5 + a.C;
+    const bool boxes_in_lds = a.M <= 128;
+    if (boxes_in_lds)
+        for (int i = threadIdx.x; i < a.M * 4; i += 256) sbox[i] = a.boxes[(size_t)b * a.M * 4 + i];
+    __syncthreads();
+    float lbox = 0.f, lconf = 0.f, lcls = 0.f;
+    if (cell < cells) {
+        const int an = cell % a.A;
+        const int wq = (cell / a.A) % a.W;
+        const int hq = cell / (a.A * a.W);
+        const float* in = a.in.base + (size_t)b * a.in.sb + (size_t)hq * a.in.sh + (size_t)wq * a.in.sw + (size_t)(an * nv) * a.in.sc;
+        const float* lab = a.label + ((size_t)b * cells + cell) * (6 + a.C);
+        float* gout = nullptr;
+        if (GRAD) gout = a.grad + (size_t)b * a.gsb + (size_t)hq * a.gsh + (size_t)wq * a.gsw + (size_t)(an * nv) * a.gsc;
+        const float fs = (float)a.stride;
+        const float gx = (float)wq + 0.5f, gy = (float)hq + 0.5f;
+        float pc[4], dpc[4];   // decoded corners and d(corner)/d(raw)
+        float pconf, dconf;
+        if (a.from_raw) {
+            const float e0 = expf(in[0]), e1 = expf(in[a.in.sc]), e2 = expf(in[2 * a.in.sc]), e3 = expf(in[3 * a.in.sc]);
+            pc[0] = (gx - e0) * fs; pc[1] = (gy - e1) * fs; pc[2] = (gx + e2) * fs; pc[3] = (gy + e3) * fs;
+            dpc[0] = -e0 * fs; dpc[1] = -e1 * fs; dpc[2] = e2 * fs; dpc[3] = e3 * fs;
+            pconf = sigmoidf_(in[4 * a.in.sc]);
+            dconf = pconf * (1.f - pconf);
+        } else {
+            for (int k = 0; k < 4; ++k) { pc[k] = in[k * a.in.sc]; dpc[k] = 1.f; }
+            pconf = in[4 * a.in.sc];
+            dconf = 1.f;
+        }
+        const float t0 = lab[0], t1 = lab[1], t2 = lab[2], t3 = lab[3];
+        const float respond = lab[4];
+        const float mixw = lab[5 + a.C];
+        const float in_area = (float)(a.stride * a.H) * (float)(a.stride * a.W);
+        const float scale = 2.0f - 1.0f * (t2 - t0) * (t3 - t1) / in_area;
+        const float invB = 1.f / (float)a.B;
+        float gs_box = 0.f, gs_conf = 0.f, gs_cls = 0.f;
+        if (GRAD) { gs_box = a.gscale[0] * invB; gs_conf = a.gscale[1] * invB; gs_cls = a.gscale[2] * invB; }
+
+        // ---- box term
+        float gcorner[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.box_loss == PQ_BOX_L1) {
+            const float tt[4] = {t0, t1, t2, t3};
+            const float beta = 1.f / 9.f;
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) {
+                const float d = pc[k] - tt[k];
+                const float n = fabsf(d);
+                const bool small = n < beta;
+                s += small ? (0.5f * n * n / beta) : (n - 0.5f * beta);
+                const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                gcorner[k] = (small ? (n / beta) * sg : sg) * 0.25f;
+            }
+            const float mean4 = s * 0.25f;
+            lbox = respond * scale * mean4 * a.l1_gain;
+            for (int k = 0; k < 4; ++k) gcorner[k] *= respond * scale * a.l1_gain;
+        } else {
+            D4 b1[4] = {dvar(pc[0], 0), dvar(pc[1], 1), dvar(pc[2], 2), dvar(pc[3], 3)};
+            const float b2[4] = {t0, t1, t2, t3};
+            const D4 x = iou_family(b1, b2, a.box_loss);
+            lbox = respond * scale * (1.0f - x.v);
+            for (int k = 0; k < 4; ++k) gcorner[k] = respond * scale * (-x.d[k]);
+        }
+        lbox *= mixw;
+
+        // ---- objectness term with the ignore mask (max IoU against every ground-truth box of the image)
+        const float a1 = (pc[2] - pc[0]) * (pc[3] - pc[1]);
+        float best = -INFINITY;
+        bool sawnan = false;
+        for (int m = 0; m < a.M; ++m) {
+            const float* bx = boxes_in_lds ? &sbox[m * 4] : &a.boxes[((size_t)b * a.M + m) * 4];
+            const float v = plain_iou(pc[0], pc[1], pc[2], pc[3], a1, bx);
+            sawnan |= (v != v);
+            best = fmaxf(best, v);
+        }
+        if (sawnan) best = NAN;   // torch.max propagates NaN; (NaN < thr) is false
+        const float bgd = (1.0f - respond) * ((best < a.ignore_thresh) ? 1.f : 0.f);
+        {
+            const float t = respond, p = pconf;
+            const float alpha_t = 2.f * fabsf(t - 1.f + 0.75f);
+            const float ad = fabsf(t - p);
+            const float focal = alpha_t * (ad * ad);
+            const float bce = bce_val(p, t);
+            lconf = 1.f * focal * (respond * bce + bgd * bce) * mixw;
+            if (GRAD) {
+                const float dfocal = -2.f * alpha_t * (t - p);
+                const float dl = (respond + bgd) * (dfocal * bce + focal * bce_grad(p, t));
+                gout[4 * a.gsc] = dl * dconf * mixw * gs_conf;
+            }
+        }
+        if (GRAD)
+            for (int k = 0; k < 4; ++k) gout[k * a.gsc] = gcorner[k] * dpc[k] * mixw * gs_box;
+
+        // ---- class term
+        for (int k = 0; k < a.C; ++k) {
+            const float raw = in[(size_t)(5 + k) * a.in.sc];
+            const float q = a.from_raw ? sigmoidf_(raw) : raw;
+            const float t = lab[5 + k];
+            const float alpha_t = 2.f * fabsf(t - 1.f + 0.5f);
+            const float ad = fabsf(t - q);
+            const float focal = alpha_t * (ad * ad);
+            const float bce = bce_val(q, t);
+            lcls += 2.f * focal * respond * bce;
+            if (GRAD) {
+                const float dfocal = -2.f * alpha_t * (t - q);
+                const float dl = 2.f * respond * (dfocal * bce + focal * bce_grad(q, t));
+                const float dq = a.from_raw ? q * (1.f - q) : 1.f;
+                gout[(size_t)(5 + k) * a.gsc] = dl * dq * mixw * gs_cls;
+            }
+        }
+        lcls *= mixw;
+    }
+    if (!GRAD) {
+        // block reduction of the three sums -> partial[b][blockIdx.x][3]
+        for (int off = 32; off > 0; off >>= 1) {
+            lbox += __shfl_xor(lbox, off);
+            lconf += __shfl_xor(lconf, off);
+            lcls += __shfl_xor(lcls, off);
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { wred[wv][0] = lbox; wred[wv][1] = lconf; wred[wv][2] = lcls; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const float s = wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
+            a.partial[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void yolo_loss_finalize_kernel(const float* partial, int B, int nblk, float* losses, int32_t* nan_flag) {
+    // lanes 0..2 own one loss term each; sum blocks per image in double, then mean over the batch
+    const int k = threadIdx.x;
+    double acc = 0.0;
+    if (k < 3) {
+        for (int b = 0; b < B; ++b) {
+            double s = 0.0;
+            for (int j = 0; j < nblk; ++j) s += (double)partial[((size_t)b * nblk + j) * 3 + k];
+            acc += (double)(float)s;
+        }
+        acc /= (double)B;
+    }
+    const float mine = (float)acc;
+    const float box = __shfl(mine, 0), conf = __shfl(mine, 1), cls = __shfl(mine, 2);
+    if (k == 0) {
+        const float total = box + conf + cls;
+        losses[0] = total; losses[1] = box; losses[2] = conf; losses[3] = cls;
+        if (nan_flag) *nan_flag = (total != total) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ decode
+__global__ __launch_bounds__(256) void decode_kernel(pq_decode_args a) {
+    const int nv = 5 + a.C;
+    const long per_img = (long)a.H * a.W * a.A * nv;
+    const long total = per_img * a.B;
+    const float fs = (float)a.stride;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / per_img);
+        long r = i % per_img;
+        const int k = (int)(r % nv); r /= nv;
+        const int an = (int)(r % a.A); r /= a.A;
+        const int wq = (int)(r % a.W);
+        const int hq = (int)(r / a.W);
+        const float raw = a.raw.base[(size_t)b * a.raw.sb + (size_t)hq * a.raw.sh + (size_t)wq * a.raw.sw + (size_t)(an * nv + k) * a.raw.sc];
+        float v;
+        if (k < 4) {
+            const float g = ((k & 1) ? (float)hq : (float)wq) + 0.5f;
+            const float e = expf(raw);
+            v = (k < 2 ? (g - e) : (g + e)) * fs;
+        } else {
+            v = sigmoidf_(raw);
+        }
+        const size_t row = (size_t)a.row0 + ((size_t)hq * a.W + wq) * a.A + an;
+        a.out[((size_t)b * a.rows_total + row) * nv + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void decode_bwd_kernel(pq_decode_bwd_args a) {
+    const int nv = 5 + a.C;
+    const long per_img = (long)a.H * a.W * a.A * nv;
+    const long total = per_img * a.B;
+    const float fs = (float)a.stride;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / per_img);
+        long r = i % per_img;
+        const int k = (int)(r % nv); r /= nv;
+        const int an = (int)(r % a.A); r /= a.A;
+        const int wq = (int)(r % a.W);
+        const int hq = (int)(r / a.W);
+        const float p = a.pred[i], dp = a.dpred[i];
+        float g;
+        if (k < 4) {
+            const float c = (((k & 1) ? (float)hq : (float)wq) + 0.5f) * fs;
+            g = dp * (p - c);                 // d/draw of (c/s -+ e^raw) * s  =  -+ e^raw * s  =  pred - c
+        } else {
+            g = dp * p * (1.f - p);
+        }
+        a.draw[(size_t)b * a.view.sb + (size_t)hq * a.view.sh + (size_t)wq * a.view.sw + (size_t)(an * nv + k) * a.view.sc] = g;
+    }
+}
+
+__global__ void iou_pairs_kernel(const float* b1, const float* b2, float* out, int n, int kind) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    D4 x[4] = {dvar(b1[4 * i], 0), dvar(b1[4 * i + 1], 1), dvar(b1[4 * i + 2], 2), dvar(b1[4 * i + 3], 3)};
+    const float y[4] = {b2[4 * i], b2[4 * i + 1], b2[4 * i + 2], b2[4 * i + 3]};
+    out[i] = iou_family(x, y, kind).v;
+}
+
+}  // namespace pq
+
+using namespace pq;
+
+extern "C" int32_t pq_yolo_loss_blocks(int32_t H, int32_t W, int32_t A) { return (H * W * A + 255) / 256; }
+
+static int loss_check(const pq_yolo_loss_args* a, bool bwd) {
+    if (!a || !a->in.base || !a->label || !a->boxes) return 0;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->A <= 0 || a->C <= 0 || a->M <= 0) return 0;
+    if (a->box_loss < PQ_BOX_L1 || a->box_loss > PQ_BOX_IOU) return 0;
+    if (bwd) return a->grad != nullptr && a->gscale != nullptr;
+    return a->partial != nullptr && a->losses != nullptr;
+}
+
+extern "C" int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream) {
+    PQ_CHECK_ARG(loss_check(a, false), "bad arguments");
+    const int nblk = pq_yolo_loss_blocks(a->H, a->W, a->A);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((yolo_loss_kernel<false>), dim3(nblk, a->B), dim3(256), 0, st, *a);
+    PQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)a->partial, a->B, nblk, a->losses, a->nan_flag);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_yolo_loss_bwd(const pq_yolo_loss_args* a, void* stream) {
+    PQ_CHECK_ARG(loss_check(a, true), "bad arguments");
+    const int nblk = pq_yolo_loss_blocks(a->H, a->W, a->A);
+    hipLaunchKernelGGL((yolo_loss_kernel<true>), dim3(nblk, a->B), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_decode(const pq_decode_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->raw.base && a->out, "null pointer");
+    PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->A > 0 && a->C > 0, "bad shape");
+    PQ_CHECK_ARG(a->row0 >= 0 && a->row0 + a->H * a->W * a->A <= a->rows_total, "rows out of range");
+    long total = (long)a->B * a->H * a->W * a->A * (5 + a->C);
+    long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_decode_bwd(const pq_decode_bwd_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->pred && a->dpred && a->draw, "null pointer");
+    PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->A > 0 && a->C > 0, "bad shape");
+    long total = (long)a->B * a->H * a->W * a->A * (5 + a->C);
+    long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(decode_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_iou_pairs(const float* b1, const float* b2, float* out, int32_t n, int32_t kind, void* stream) {
+    PQ_CHECK_ARG(b1 && b2 && out && n > 0, "bad arguments");
+    PQ_CHECK_ARG(kind >= PQ_BOX_GIOU && kind <= PQ_BOX_IOU, "kind must be giou/diou/ciou/iou");
+    hipLaunchKernelGGL(iou_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, b1, b2, out, n, kind);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}

@@ -1,0 +1,574 @@
+"""Step compiler / executor: turns the parsed layer list into a flat array of ``pq_op`` kernel descriptors per
+(input shape, mode) and replays it with ONE ``pq_run_ops`` call for the forward and ONE for the backward.
+
+MI355X-first design notes (see DESIGN.md for the long form)
+* activations are NHWC fp32, kept RAW (pre-BatchNorm); the BN affine + activation of a producer is applied by every
+  consumer while it loads ("virtual tensors"), so train-mode BN costs no extra pass over the activation;
+* BN batch statistics are emitted by the producing conv kernel as per-block partial sums and finalised by a tiny kernel
+  (deterministic, no float atomics);
+* backward keeps one gradient buffer per tensor; each consumer's dgrad kernel accumulates into it and the last one
+  applies act' and emits the BN-backward sums in its epilogue; the BN backward itself is the closed form
+  dy = p*g + q*(y-mu) + r applied on load by the producer's wgrad / dgrad kernels;
+* parameters and gradients live in two flat buffers (``nn.Parameter.data`` are views), so Adam is one launch and the
+  data-parallel gradient exchange is a handful of large RCCL all-reduces over contiguous ranges;
+* the step never synchronises with the host: loss scalars stay on the device, the NaN trap is polled one step late.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import abi
+from .abi import check, lib, ptr
+from .model.parser import act_code_of
+
+ALIGN = 16           # floats; every per-channel vector / parameter starts on a 64-byte boundary
+
+
+def _round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class FlatParams:
+    """All parameters of a model as views into one flat fp32 buffer (+ a parallel flat gradient buffer)."""
+
+    def __init__(self, model: nn.Module, device):
+        params = [p for p in model.parameters()]
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += _round_up(p.numel(), ALIGN)
+        self.flat = torch.zeros(total, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=device, dtype=torch.float32)
+        self.params, self.offsets = params, offs
+        self.views, self.grad_views = [], []
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                v = self.flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = v
+                self.views.append(v)
+                self.grad_views.append(self.grad[o:o + p.numel()].view(p.shape))
+                p._pq_flat = (self, o)
+        self.index = {id(p): i for i, p in enumerate(params)}
+
+    def still_valid(self) -> bool:
+        return all(p.data.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+
+    def grad_ptr(self, p) -> int:
+        return self.grad_views[self.index[id(p)]].data_ptr()
+
+    def assign_grads(self):
+        for p, gv in zip(self.params, self.grad_views):
+            if p.grad is None:
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                p.grad.add_(gv)
+
+
+class _Coef:
+    """Arena of small per-channel fp32 vectors (16-float aligned, zero padded)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.req: List[Tuple[object, str, int]] = []
+        self.buf = None
+
+    def want(self, owner, name: str, n: int):
+        self.req.append((owner, name, n))
+
+    def commit(self):
+        total, offs = 0, []
+        for _, _, n in self.req:
+            offs.append(total)
+            total += _round_up(n, ALIGN) + ALIGN
+        self.buf = torch.zeros(max(total, ALIGN), device=self.device, dtype=torch.float32)
+        for (owner, name, n), o in zip(self.req, offs):
+            setattr(owner, name, self.buf[o:o + n])
+
+
+class BnState:
+    def __init__(self, module: nn.BatchNorm2d, C_: int):
+        self.module = module
+        self.C = C_
+        self.count = 0.0
+        self.fwd_nblk = 0
+        self.bwd_nblk = 0
+        self.ldp = _round_up(C_, ALIGN)
+        self.fwd_partial = None
+        self.bwd_partial = None
+        # coefficient vectors are attached by _Coef.commit(): mean, invstd, scale, shift, p, q, r
+
+
+class TensorRef:
+    """A layer output: raw NHWC buffer (+ BN affine + activation applied by consumers)."""
+
+    def __init__(self, raw, B, H, W, C_, ld, bn: Optional[BnState], act: int):
+        self.raw, self.B, self.H, self.W, self.C, self.ld, self.bn, self.act = raw, B, H, W, C_, ld, bn, act
+        self.grad = None
+        self.n_consumers = 0
+        self.received = 0
+        self.needs_grad = True
+
+    @property
+    def rows(self):
+        return self.B * self.H * self.W
+
+    def src(self) -> abi.Src:
+        if self.bn is not None:
+            return abi.Src(ptr(self.raw), ptr(self.bn.scale), ptr(self.bn.shift), self.ld, self.act)
+        return abi.Src(ptr(self.raw), None, None, self.ld, self.act)
+
+    def gsrc(self, bn_train: bool) -> abi.GSrc:
+        if self.bn is not None:
+            b = self.bn
+            return abi.GSrc(ptr(self.grad), ptr(self.raw), ptr(b.p), ptr(b.q), ptr(b.mean), ptr(b.r), self.ld, self.ld)
+        return abi.GSrc(ptr(self.grad), None, None, None, None, None, self.ld, 0)
+
+
+class Plan:
+    """Compiled forward (+ backward) op arrays for one input shape and mode."""
+
+    def __init__(self, model, x_shape, bn_train: bool, with_loss: bool):
+        self.model = model
+        self.bn_train = bn_train
+        self.with_loss = with_loss
+        self.device = model._flat.flat.device
+        self.B, _, self.IH, self.IW = x_shape
+        self.fwd: List[abi.Op] = []
+        self.bwd: List[abi.Op] = []
+        self.keep = []                 # tensors that must stay alive
+        self.patch_x: List[Tuple[str, int, str]] = []       # (which, op index, field path)
+        self.loss_ops_f: List[Tuple[int, int]] = []          # (fwd op index, head slot)
+        self.loss_ops_b: List[Tuple[int, int]] = []
+        self.segments: List[Tuple[int, int, int]] = []       # backward: (op_end, flat_lo, flat_hi) gradient-ready marks
+        self._build()
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _new(self, *shape, fill=None):
+        t = torch.empty(*shape, device=self.device, dtype=torch.float32) if fill is None else \
+            torch.full(shape, fill, device=self.device, dtype=torch.float32)
+        self.keep.append(t)
+        return t
+
+    def _op(self, lst, code, args) -> int:
+        op = abi.Op()
+        op.code = code
+        setattr(op.u, abi.OP_FIELD[code], args)
+        lst.append(op)
+        return len(lst) - 1
+
+    def _sink(self, t: TensorRef, nblk: int) -> abi.GSink:
+        if t.grad is None:
+            t.grad = self._new(t.rows, t.ld, fill=0.0) if t.ld != t.C else self._new(t.rows, t.ld)
+        accumulate = t.received > 0
+        finalize = (t.received + 1 == t.n_consumers)
+        t.received += 1
+        stats = finalize and t.bn is not None and self.bn_train
+        if stats:
+            b = t.bn
+            b.bwd_nblk = nblk
+            b.bwd_partial = self._new(nblk * 2 * b.ldp)
+        bn = t.bn
+        return abi.GSink(ptr(t.grad), ptr(t.raw), ptr(bn.scale) if bn else None, ptr(bn.shift) if bn else None,
+                         ptr(bn.mean) if stats else None, ptr(bn.invstd) if stats else None,
+                         ptr(bn.bwd_partial) if stats else None, t.ld, t.ld, t.act, int(accumulate), int(finalize),
+                         bn.ldp if bn else 0)
+
+    # ------------------------------------------------------------------------------------------ build
+    def _build(self):
+        model, l = self.model, lib()
+        mods = list(model.module_list)
+        flat = model._flat
+        B = self.B
+        coef = _Coef(self.device)
+        # ---- pass 0: shapes + consumer counts -------------------------------------------------------
+        specs = []
+        h, w, c = self.IH, self.IW, 3
+        shapes: List[Tuple[int, int, int]] = []
+        consumers: Dict[int, int] = {}
+
+        def use(idx):
+            consumers[idx] = consumers.get(idx, 0) + 1
+
+        alias: Dict[int, int] = {}
+
+        def resolve(i, where):
+            j = i if i >= 0 else where + i
+            while j in alias:
+                j = alias[j]
+            return j
+
+        for i, m in enumerate(mods):
+            t = m._type
+            if t == 'convolutional':
+                conv = m.conv
+                k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+                if i > 0:
+                    use(resolve(i - 1, i))
+                h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+                c = conv.out_channels
+            elif t == 'shortcut':
+                use(resolve(i - 1, i))
+                use(resolve(m._from, i))
+            elif t == 'route':
+                srcs = [resolve(j, i) for j in m._layers]
+                if m.single:
+                    alias[i] = srcs[0]
+                    h, w, c = shapes[srcs[0]]
+                else:
+                    for sidx in srcs:
+                        use(sidx)
+                    h, w = shapes[srcs[0]][0], shapes[srcs[0]][1]
+                    c = sum(shapes[sidx][2] for sidx in srcs)
+            elif t == 'upsample':
+                use(resolve(i - 1, i))
+                f = int(m.scale_factor)
+                h, w = h * f, w * f
+            elif t == 'yolo':
+                use(resolve(i - 1, i))
+            else:
+                raise NotImplementedError("layer type '%s' is not supported by the HIP engine yet" % t)
+            shapes.append((h, w, c))
+
+        # ---- pass 1: forward ops ---------------------------------------------------------------------
+        T: List[Optional[TensorRef]] = []
+        self.tensors = T
+        heads = []
+        train_graph = self.with_loss
+
+        def conv_bn(m, C_out, rows) -> Optional[BnState]:
+            if not hasattr(m, 'bn'):
+                return None
+            b = BnState(m.bn, C_out)
+            b.count = float(rows)
+            for name in ('mean', 'invstd', 'scale', 'shift', 'p', 'q', 'r'):
+                coef.want(b, name, C_out)
+            return b
+
+        pending_bn_ops = []   # (op list, index) whose coefficient pointers are filled after coef.commit()
+        self._deferred = []
+
+        for i, m in enumerate(mods):
+            t = m._type
+            if t == 'convolutional':
+                conv = m.conv
+                k, s = conv.kernel_size[0], conv.stride[0]
+                Cin, Cout, groups = conv.in_channels, conv.out_channels, conv.groups
+                OH, OW, _ = shapes[i]
+                rows = B * OH * OW
+                ld = _round_up(Cout, 4)
+                bn = conv_bn(m, Cout, rows)
+                act = act_code_of(getattr(m, 'act', None))
+                raw = self._new(rows, ld) if ld == Cout else self._new(rows, ld, fill=0.0)
+                out = TensorRef(raw, B, OH, OW, Cout, ld, bn, act)
+                want_stats = bn is not None and self.bn_train
+                if i == 0:
+                    if not (k == 3 and groups == 1 and Cin == 3):
+                        raise NotImplementedError('first layer must be a dense 3x3 conv on 3 channels')
+                    nblk = l.pq_ew_blocks(rows, Cout)
+                    self._deferred.append(('stem_fwd', i, out, nblk))
+                else:
+                    src = T[resolve(i - 1, i)]
+                    if k == 1 and groups == 1:
+                        nblk = (rows + 127) // 128
+                        self._deferred.append(('c1_fwd', i, out, nblk, src, s))
+                    elif k == 3 and groups == Cin == Cout and conv.padding[0] == 1:
+                        nblk = l.pq_dw3x3_blocks(B, OH, OW, Cout)
+                        self._deferred.append(('dw_fwd', i, out, nblk, src, s))
+                    else:
+                        raise NotImplementedError(
+                            'conv k=%d groups=%d (%d->%d) has no HIP kernel yet (dense/grouped 3x3 is a later row)' %
+                            (k, groups, Cin, Cout))
+                if bn is not None:
+                    bn.fwd_nblk = nblk
+                    if want_stats:
+                        bn.fwd_partial = self._new(nblk * 2 * bn.ldp)
+                    self._deferred.append(('bn_fwd', i, out))
+                T.append(out)
+            elif t == 'shortcut':
+                a, b_ = T[resolve(i - 1, i)], T[resolve(m._from, i)]
+                raw = self._new(a.rows, a.ld) if a.ld == a.C else self._new(a.rows, a.ld, fill=0.0)
+                out = TensorRef(raw, a.B, a.H, a.W, a.C, a.ld, None, act_code_of(m.act))
+                self._deferred.append(('copy', i, out, a, b_, 0, 1))
+                T.append(out)
+            elif t == 'route':
+                srcs = [T[resolve(j, i)] for j in m._layers]
+                if m.single:
+                    T.append(srcs[0])
+                else:
+                    Ctot = sum(s_.C for s_ in srcs)
+                    ld = _round_up(Ctot, 4)
+                    raw = self._new(srcs[0].rows, ld)
+                    out = TensorRef(raw, srcs[0].B, srcs[0].H, srcs[0].W, Ctot, ld, None, 0)
+                    off = 0
+                    for s_ in srcs:
+                        self._deferred.append(('copy', i, out, s_, None, off, 1))
+                        off += s_.C
+                    T.append(out)
+            elif t == 'upsample':
+                a = T[resolve(i - 1, i)]
+                f = int(m.scale_factor)
+                raw = self._new(a.rows * f * f, a.ld)
+                out = TensorRef(raw, a.B, a.H * f, a.W * f, a.C, a.ld, None, 0)
+                self._deferred.append(('copy', i, out, a, None, 0, f))
+                T.append(out)
+            elif t == 'yolo':
+                a = T[resolve(i - 1, i)]
+                if a.bn is not None or a.act != 0:
+                    raise NotImplementedError('yolo layer must follow a linear conv without batch norm')
+                heads.append((i, m, a))
+                T.append(a)
+        for i_, n_ in consumers.items():
+            T[i_].n_consumers = n_
+
+        coef.commit()
+        self.keep.append(coef.buf)
+        self._emit_forward(flat, heads)
+        if train_graph:
+            self._emit_backward(flat, mods, heads, resolve)
+        self.fwd_arr = (abi.Op * len(self.fwd))(*self.fwd)
+        self.bwd_arr = (abi.Op * len(self.bwd))(*self.bwd) if self.bwd else None
+
+    # ------------------------------------------------------------------------------------------ forward emission
+    def _emit_forward(self, flat, heads):
+        model, l = self.model, lib()
+        mods = list(model.module_list)
+        B = self.B
+        for item in self._deferred:
+            kind = item[0]
+            if kind == 'stem_fwd':
+                _, i, out, nblk = item
+                conv = mods[i].conv
+                part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
+                a = abi.StemFwd(None, ptr(conv.weight), ptr(out.raw), ptr(part), B, 3, self.IH, self.IW, out.H, out.W,
+                                out.C, conv.stride[0], out.ld, out.bn.ldp if out.bn else 0)
+                idx = self._op(self.fwd, abi.OP_STEM_FWD, a)
+                self.patch_x.append(('fwd', idx, 'stf'))
+            elif kind == 'c1_fwd':
+                _, i, out, nblk, src, s = item
+                conv = mods[i].conv
+                part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
+                a = abi.Conv1x1Fwd(src.src(), ptr(conv.weight), ptr(conv.bias) if conv.bias is not None else None,
+                                   ptr(out.raw), ptr(part), out.rows, src.C, out.C, out.ld, out.bn.ldp if out.bn else 0,
+                                   s, out.H, out.W, src.H, src.W)
+                self._op(self.fwd, abi.OP_CONV1X1_FWD, a)
+            elif kind == 'dw_fwd':
+                _, i, out, nblk, src, s = item
+                conv = mods[i].conv
+                part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
+                a = abi.DwFwd(src.src(), ptr(conv.weight), ptr(out.raw), ptr(part), B, src.H, src.W, out.H, out.W, out.C, s,
+                              out.ld, out.bn.ldp if out.bn else 0)
+                self._op(self.fwd, abi.OP_DW_FWD, a)
+            elif kind == 'bn_fwd':
+                _, i, out = item
+                b = out.bn
+                bm = b.module
+                train = self.bn_train
+                a = abi.BnFwdFin(ptr(b.fwd_partial) if train else None, ptr(bm.weight), ptr(bm.bias), ptr(bm.running_mean),
+                                 ptr(bm.running_var), ptr(bm.num_batches_tracked) if train else None, ptr(b.mean),
+                                 ptr(b.invstd), ptr(b.scale), ptr(b.shift), b.fwd_nblk, b.ldp, b.C, int(train), b.count,
+                                 float(bm.eps), float(bm.momentum if bm.momentum is not None else 0.1))
+                self._op(self.fwd, abi.OP_BN_FWD_FIN, a)
+            elif kind == 'copy':
+                _, i, out, a_, b_, coff, up = item
+                none = abi.Src(None, None, None, 0, 0)
+                a = abi.Copy(a_.src(), b_.src() if b_ is not None else none, ptr(out.raw), out.B, out.H, out.W, a_.C,
+                             out.ld, coff, up)
+                self._op(self.fwd, abi.OP_COPY_FWD, a)
+        # heads
+        nh = len(heads)
+        self.nheads = nh
+        if self.with_loss:
+            self.loss_buf = self._new(nh, 4, fill=0.0)
+            self.gscale = self._new(nh, 3, fill=0.0)
+            self.nan_dev = torch.zeros(nh, device=self.device, dtype=torch.int32)
+            self.keep.append(self.nan_dev)
+            for slot, (i, m, a) in enumerate(heads):
+                opt = m.opt
+                A = a.C // (5 + opt['classes'])
+                nblk = l.pq_yolo_loss_blocks(a.H, a.W, A)
+                partial = self._new(B * nblk * 3)
+                view = abi.HeadView(ptr(a.raw), a.H * a.W * a.ld, a.W * a.ld, a.ld, 1)
+                if a.grad is None:
+                    a.grad = self._new(a.rows, a.ld, fill=0.0)
+                la = abi.YoloLoss(view, None, None, ptr(partial), self.loss_buf[slot].data_ptr(),
+                                  self.nan_dev[slot:slot + 1].data_ptr(), self.gscale[slot].data_ptr(), ptr(a.grad),
+                                  a.H * a.W * a.ld, a.W * a.ld, a.ld, 1,
+                                  B, a.H, a.W, A, opt['classes'], 1, opt['stride'], abi.BOX_KIND[opt['bbox_loss']], 1,
+                                  float(opt['ignore_thresh']), float(opt['l1_loss_gain']))
+                idx = self._op(self.fwd, abi.OP_LOSS_FWD, la)
+                self.loss_ops_f.append((idx, slot, opt['stride']))
+                self._head_loss_args = getattr(self, '_head_loss_args', []) + [(la, slot, opt['stride'], a)]
+        else:
+            rows_total = sum(a.H * a.W * (a.C // (5 + m.opt['classes'])) for _, m, a in heads)
+            nv = 5 + heads[0][1].opt['classes']
+            self.eval_out = self._new(B, rows_total, nv)
+            row0 = 0
+            for i, m, a in heads:
+                opt = m.opt
+                A = a.C // (5 + opt['classes'])
+                view = abi.HeadView(ptr(a.raw), a.H * a.W * a.ld, a.W * a.ld, a.ld, 1)
+                d = abi.Decode(view, ptr(self.eval_out), B, a.H, a.W, A, opt['classes'], opt['stride'], rows_total, row0)
+                self._op(self.fwd, abi.OP_DECODE, d)
+                row0 += a.H * a.W * A
+
+    # ------------------------------------------------------------------------------------------ backward emission
+    def _emit_backward(self, flat, mods, heads, resolve):
+        l = lib()
+        B = self.B
+        T = self.tensors
+        # heads first (reverse layer order overall, but head losses only touch their own tensors)
+        head_at = {i: (slot, m, a) for slot, (i, m, a) in enumerate(heads)}
+        scratch_need = 0
+        wg_ops = []
+
+        def bn_bwd(out: TensorRef):
+            b = out.bn
+            bm = b.module
+            a = abi.BnBwdFin(ptr(b.bwd_partial), ptr(bm.weight), ptr(b.invstd), flat.grad_ptr(bm.weight), flat.grad_ptr(bm.bias),
+                             ptr(b.p), ptr(b.q), ptr(b.r), b.bwd_nblk, b.ldp, b.C, int(self.bn_train), b.count)
+            self._op(self.bwd, abi.OP_BN_BWD_FIN, a)
+
+        def zero_params(m):
+            for p in m.parameters():
+                o = flat.index[id(p)]
+                self._op(self.bwd, abi.OP_FILL, abi.Fill(flat.grad_views[o].data_ptr(), 0.0, p.numel()))
+
+        for i in range(len(mods) - 1, -1, -1):
+            m = mods[i]
+            t = m._type
+            lo_mark = None
+            if t == 'yolo':
+                slot, hm, a = head_at[i]
+                la, _, stride, _ = self._head_loss_args[slot]
+                a.received += 1
+                idx = self._op(self.bwd, abi.OP_LOSS_BWD, la)
+                self.loss_ops_b.append((idx, slot, stride))
+            elif t == 'convolutional':
+                out = T[i]
+                conv = m.conv
+                if out.n_consumers == 0 or out.grad is None:
+                    zero_params(m)
+                else:
+                    if out.bn is not None:
+                        if self.bn_train and out.bn.bwd_partial is None:
+                            raise RuntimeError('internal: BN layer %d never finalised its gradient' % i)
+                        if not self.bn_train:
+                            # frozen statistics: no sums were collected; p = gamma*invstd, q = r = 0; dgamma/dbeta need sums
+                            raise NotImplementedError('training with BatchNorm in eval mode is not supported yet')
+                        bn_bwd(out)
+                    dy = out.gsrc(self.bn_train)
+                    k, s = conv.kernel_size[0], conv.stride[0]
+                    if i == 0:
+                        need = l.pq_stem3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C, 3)
+                        a = abi.StemWgrad(dy, None, flat.grad_ptr(conv.weight), None, B, 3, self.IH, self.IW, out.H, out.W,
+                                          out.C, s)
+                        idx = self._op(self.bwd, abi.OP_STEM_WGRAD, a)
+                        self.patch_x.append(('bwd', idx, 'stw'))
+                        wg_ops.append((idx, 'stw'))
+                    else:
+                        src = T[resolve(i - 1, i)]
+                        if k == 1:
+                            if s != 1:
+                                raise NotImplementedError('backward of a strided 1x1 conv is not implemented yet')
+                            need = l.pq_conv1x1_wgrad_scratch_bytes(out.rows, src.C, out.C)
+                            a = abi.Conv1x1Wgrad(dy, src.src(), flat.grad_ptr(conv.weight),
+                                                 flat.grad_ptr(conv.bias) if conv.bias is not None else None, None,
+                                                 out.rows, src.C, out.C)
+                            idx = self._op(self.bwd, abi.OP_CONV1X1_WGRAD, a)
+                            wg_ops.append((idx, 'c1w'))
+                            if src.needs_grad:
+                                d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), self._sink(src, (src.rows + 127) // 128), out.rows,
+                                                     src.C, out.C)
+                                self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
+                        else:
+                            need = l.pq_dw3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C)
+                            a = abi.DwWgrad(dy, src.src(), flat.grad_ptr(conv.weight), None, B, src.H, src.W, out.H, out.W,
+                                            out.C, s)
+                            idx = self._op(self.bwd, abi.OP_DW_WGRAD, a)
+                            wg_ops.append((idx, 'dww'))
+                            d = abi.DwDgrad(dy, ptr(conv.weight), self._sink(src, l.pq_ew_blocks(src.rows, src.C)), B, src.H,
+                                            src.W, out.H, out.W, out.C, s)
+                            self._op(self.bwd, abi.OP_DW_DGRAD, d)
+                    scratch_need = max(scratch_need, need)
+                plist = list(m.parameters())
+                if plist:
+                    lo = min(flat.offsets[flat.index[id(p)]] for p in plist)
+                    self.segments.append((len(self.bwd), lo))
+            elif t == 'shortcut':
+                out = T[i]
+                if out.grad is not None:
+                    for srcT in (T[resolve(i - 1, i)], T[resolve(m._from, i)]):
+                        r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B, srcT.H,
+                                         srcT.W, srcT.C, out.ld, 0, 1)
+                        self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+            elif t == 'route':
+                if not m.single:
+                    out = T[i]
+                    off = 0
+                    for j in m._layers:
+                        srcT = T[resolve(j, i)]
+                        if out.grad is not None:
+                            r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B,
+                                             srcT.H, srcT.W, srcT.C, out.ld, off, 1)
+                            self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+                        off += srcT.C
+            elif t == 'upsample':
+                out = T[i]
+                srcT = T[resolve(i - 1, i)]
+                f = int(m.scale_factor)
+                if out.grad is not None:
+                    r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B, srcT.H,
+                                     srcT.W, srcT.C, out.ld, 0, f)
+                    self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+        self.scratch = torch.empty(max(scratch_need, 16) // 4 + 16, device=self.device, dtype=torch.float32)
+        for idx, field in wg_ops:
+            getattr(self.bwd[idx].u, field).scratch = self.scratch.data_ptr()
+
+    # ------------------------------------------------------------------------------------------ run
+    def _patch(self, x, target):
+        xp = x.data_ptr()
+        for which, idx, field in self.patch_x:
+            arr = self.fwd_arr if which == 'fwd' else self.bwd_arr
+            getattr(arr[idx].u, field).image = xp
+        if target is not None:
+            pick = {8: (0, 3), 16: (1, 4), 32: (2, 5)}       # reference model/interpreter.py:16-20
+            for lst, arr in ((self.loss_ops_f, self.fwd_arr), (self.loss_ops_b, self.bwd_arr)):
+                for idx, slot, stride in lst:
+                    li, bi = pick[stride]
+                    la = arr[idx].u.loss
+                    la.label = target[li].data_ptr()
+                    la.boxes = target[bi].data_ptr()
+                    la.M = target[bi].shape[1]
+
+    def run_forward(self, x, target):
+        self._patch(x, target)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib().pq_run_ops(self.fwd_arr, len(self.fwd), st), 'forward step')
+
+    def run_backward(self, reducer=None):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        l = lib()
+        if reducer is None:
+            check(l.pq_run_ops(self.bwd_arr, len(self.bwd), st), 'backward step')
+            return
+        # bucketed replay: launch the ops up to each mark, then hand the finished gradient range to the reducer
+        flat = self.model._flat
+        start, hi = 0, flat.grad.numel()
+        marks = reducer.pick_marks(self.segments, hi)
+        base = C.addressof(self.bwd_arr)
+        for op_end, lo in marks:
+            n = op_end - start
+            if n > 0:
+                sub = C.cast(C.c_void_p(base + start * C.sizeof(abi.Op)), C.POINTER(abi.Op))
+                check(l.pq_run_ops(sub, n, st), 'backward step')
+            reducer.reduce_range(flat.grad, lo, hi)
+            start, hi = op_end, lo
+        if start < len(self.bwd):
+            sub = C.cast(C.c_void_p(base + start * C.sizeof(abi.Op)), C.POINTER(abi.Op))
+            check(l.pq_run_ops(sub, len(self.bwd) - start, st), 'backward step')
+        if hi > 0:
+            reducer.reduce_range(flat.grad, 0, hi)
+        reducer.finish()

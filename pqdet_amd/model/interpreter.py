@@ -1,0 +1,164 @@
+"""``DetectionModel`` -- same constructor, attributes, ``state_dict`` layout and ``forward(x, target=None)`` contract as
+the reference ``model/interpreter.py:22-88``; the layer loop itself is compiled into HIP kernel launches by
+:mod:`pqdet_amd.engine` instead of being interpreted module by module.
+
+* eval  : ``forward(x)`` -> ``Tensor[B, sum(H*W*A), 5+C]`` (heads concatenated in cfg order, reference :74-76)
+* train : ``forward(x, (label_s, label_m, label_l, box_s, box_m, box_l))`` -> dict with ``loss``, ``giou_loss``,
+  ``conf_loss``, ``class_loss`` (each ``(1,)``) and ``loss_per_branch`` (list of ``(1,)`` per head, cfg order),
+  reference :77-85; targets are routed to heads by stride through ``_TARGET_MAP`` (:16-20).
+  ``out['loss'].mean().backward()`` runs the compiled backward and leaves ``param.grad`` as views into one flat buffer.
+"""
+from typing import IO, Union
+
+import torch
+from torch import nn
+
+from .. import abi
+from ..engine import FlatParams, Plan
+from .parser import Parser
+
+
+def item_getter(*items):
+    def getter(x):
+        if x is None:
+            return None
+        return tuple(x[i] for i in items)
+    return getter
+
+
+_TARGET_MAP = {
+    8: item_getter(0, 3),
+    16: item_getter(1, 4),
+    32: item_getter(2, 5),
+}
+
+
+class _StepFn(torch.autograd.Function):
+    """Whole-network forward/backward as one autograd node (the anchor parameter only ties it into the graph)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, plan, x, target):
+        plan.run_forward(x, target)
+        ctx.model, ctx.plan = model, plan
+        ctx.x, ctx.target = x, target           # keep the batch alive until backward has consumed it
+        return plan.loss_buf.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, model = ctx.plan, ctx.model
+        g = g.to(torch.float32)
+        plan.gscale.copy_(g[:, 0:1] + g[:, 1:4])
+        plan._patch(ctx.x, ctx.target)
+        plan.run_backward(model._reducer)
+        model._flat.assign_grads()
+        return None, None, None, None, None
+
+
+class AnyModel(nn.Module):
+
+    def __init__(self, cfg: Union[str, IO], quant: bool = False, onnx: bool = False):
+        super().__init__()
+        if quant:
+            raise NotImplementedError('the QAT model (BASELINE config 5) is not implemented in this build yet')
+        self.quant = quant
+        if isinstance(cfg, str):
+            cfg = open(cfg, 'r')
+        self.module_list = nn.ModuleList(Parser(cfg).torch_layers(quant, onnx))
+        cfg.close()
+        self._flat = None
+        self._plans = {}
+        self._reducer = None          # set by pqdet_amd.parallel.DistributedModel
+        self._nan_event = None
+        self._nan_host = None
+        self.nan_check = 'deferred'   # 'sync' | 'deferred' | 'off'
+
+    # ---- flat parameter storage ------------------------------------------------------------------------
+    def _ensure_flat(self, device):
+        f = self._flat
+        if f is None or f.flat.device != device or not f.still_valid():
+            self._flat = FlatParams(self, device)
+            self._plans.clear()
+        return self._flat
+
+    def flat_buffers(self):
+        """(flat parameter buffer, flat gradient buffer); parameters are views into the first."""
+        dev = next(self.parameters()).device
+        f = self._ensure_flat(dev)
+        return f.flat, f.grad
+
+    def _plan(self, x, with_loss):
+        if not x.is_cuda:
+            raise abi.PQError('pqdet_amd models run on the GPU through libpqdet_hip.so; there is no CPU path '
+                              '(got input on %s)' % x.device)
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError('expected (B, 3, H, W) with H, W multiples of 32, got %s' % (tuple(x.shape),))
+        self._ensure_flat(x.device)
+        for b in self.buffers():
+            if b.device != x.device:
+                raise abi.PQError('model buffers live on %s but the input is on %s' % (b.device, x.device))
+        key = (tuple(x.shape), bool(self.training), bool(with_loss))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = Plan(self, tuple(x.shape), bool(self.training), bool(with_loss))
+            self._plans[key] = plan
+        return plan
+
+    # ---- NaN trap (reference model/loss.py:110-114), polled one step late unless nan_check == 'sync' ----
+    def check_nan(self, wait: bool = True):
+        if self._nan_event is None:
+            return
+        if wait:
+            self._nan_event.synchronize()
+        elif not self._nan_event.query():
+            return
+        bad = bool(self._nan_host.any().item())
+        self._nan_event = None
+        if bad:
+            raise RuntimeError('NaN in loss')
+
+    def _arm_nan(self, plan):
+        if self.nan_check == 'off':
+            return
+        if self._nan_host is None or self._nan_host.numel() != plan.nan_dev.numel():
+            self._nan_host = torch.zeros(plan.nan_dev.numel(), dtype=torch.int32).pin_memory()
+        self._nan_host.copy_(plan.nan_dev, non_blocking=True)
+        self._nan_event = torch.cuda.Event()
+        self._nan_event.record()
+        if self.nan_check == 'sync':
+            self.check_nan(wait=True)
+
+    def forward(self, x, target=None):
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        if target is None:
+            plan = self._plan(x, False)
+            plan.run_forward(x, None)
+            return plan.eval_out.clone()
+        self.check_nan(wait=False)
+        target = tuple(t.to(x.device, torch.float32).contiguous() for t in target)
+        plan = self._plan(x, True)
+        anchor = self._flat.params[0]
+        losses = _StepFn.apply(anchor, self, plan, x, target)      # (heads, 4): total, box, conf, cls per head
+        self._arm_nan(plan)
+        return losses
+
+
+class DetectionModel(AnyModel):
+
+    def forward(self, x, target=None):
+        out = super().forward(x, target)
+        if target is None:
+            return out
+        total = out.sum(0)
+        return {
+            'loss': total[0:1],
+            'giou_loss': total[1:2],
+            'conf_loss': total[2:3],
+            'class_loss': total[3:4],
+            'loss_per_branch': [out[i, 0:1] for i in range(out.shape[0])],
+        }
+
+
+class ClassifierModel(AnyModel):
+    pass

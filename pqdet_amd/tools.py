@@ -1,0 +1,192 @@
+"""Host-side mirror of the hot-path functions of the reference ``tools.py``.
+
+Kept names / signatures (reference ``tools.py`` line numbers in brackets): ``build_model`` [158-243], ``load_weight``
+[120-136], ``load_backbone`` [138-156], ``bare_model`` [251-254], ``get_bn_layers`` [316-333], ``iou_calc3`` [357-376],
+``giou`` [378-404], ``diou`` [406-437], ``ciou`` [439-477], ``iou_calc1`` [335-355], ``iou_xywh_numpy`` [479-505],
+``torch_nms`` [540-566], ``compute_time`` [74-94].
+
+The GPU arithmetic is in libpqdet_hip.so; numpy helpers that the reference runs on the host stay numpy.
+Data-parallel training is one process per GPU (:mod:`pqdet_amd.parallel`), so ``dataparallel=True`` does not wrap the model
+in ``nn.DataParallel``: with an initialised ``torch.distributed`` process group it returns a
+:class:`pqdet_amd.parallel.DistributedModel`, otherwise the bare model.
+"""
+from io import StringIO
+from time import time_ns
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import abi, ops
+
+
+# ----------------------------------------------------------------------------------------------- IoU family
+def _pairs(kind):
+    def fn(boxes1: torch.Tensor, boxes2: torch.Tensor) -> torch.Tensor:
+        return ops.iou_pairs(boxes1, boxes2, kind)
+    return fn
+
+
+iou_calc3 = _pairs(abi.BOX_IOU)
+giou = _pairs(abi.BOX_GIOU)
+diou = _pairs(abi.BOX_DIOU)
+ciou = _pairs(abi.BOX_CIOU)
+
+
+def iou_calc1(boxes1: np.ndarray, boxes2: np.ndarray):
+    """xyxy IoU on the host, union clamped at 1e-14 (reference :335-355)."""
+    a1 = (boxes1[..., 2] - boxes1[..., 0]) * (boxes1[..., 3] - boxes1[..., 1])
+    a2 = (boxes2[..., 2] - boxes2[..., 0]) * (boxes2[..., 3] - boxes2[..., 1])
+    lo = np.maximum(boxes1[..., :2], boxes2[..., :2])
+    hi = np.minimum(boxes1[..., 2:], boxes2[..., 2:])
+    wh = np.maximum(hi - lo, 0.0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / np.maximum(a1 + a2 - inter, 1e-14)
+
+
+def iou_xywh_numpy(boxes1: np.ndarray, boxes2: np.ndarray):
+    """centre-size IoU on the host (reference :479-505); used by label assignment."""
+    a1 = boxes1[..., 2] * boxes1[..., 3]
+    a2 = boxes2[..., 2] * boxes2[..., 3]
+    c1 = np.concatenate([boxes1[..., :2] - boxes1[..., 2:] * 0.5, boxes1[..., :2] + boxes1[..., 2:] * 0.5], axis=-1)
+    c2 = np.concatenate([boxes2[..., :2] - boxes2[..., 2:] * 0.5, boxes2[..., :2] + boxes2[..., 2:] * 0.5], axis=-1)
+    wh = np.maximum(np.minimum(c1[..., 2:], c2[..., 2:]) - np.maximum(c1[..., :2], c2[..., :2]), 0.0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (a1 + a2 - inter)
+
+
+# ----------------------------------------------------------------------------------------------- NMS
+def torch_nms(bboxes: torch.Tensor, score_threshold: float, iou_threshold: float) -> torch.Tensor:
+    """reference :540-566.  bboxes (N, 4+C) recovered predictions -> (K, 6) = x1,y1,x2,y2,score,class on the input
+    device in score-descending order, or a shape-(0,) tensor when nothing survives.
+
+    The whole pipeline (candidate marking, sort, per-class greedy suppression, compaction) runs on the GPU inside
+    ``pq_nms``; the only host synchronisation is reading K to size the returned view (the reference synchronises at the
+    same point through ``nonzero()`` / ``.cpu()``)."""
+    if bboxes.numel() == 0:
+        return torch.tensor([]).to(bboxes)
+    dets, count = ops.nms(bboxes, float(score_threshold), float(iou_threshold))
+    k = int(count.item())
+    if k == 0:
+        return torch.tensor([]).to(bboxes)
+    return dets[:k]
+
+
+# ----------------------------------------------------------------------------------------------- weights / build
+def _state_dict_is_dp(state_dict: Dict) -> bool:
+    for k in state_dict:
+        return k.startswith('module.')
+    return False
+
+
+def _model_has_module_prefix(model: nn.Module) -> bool:
+    return hasattr(model, 'module') and isinstance(getattr(model, 'module'), nn.Module)
+
+
+def bare_model(model: nn.Module) -> nn.Module:
+    return model.module if _model_has_module_prefix(model) else model
+
+
+def _strip(state_dict: Dict) -> Dict:
+    return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+
+
+def load_weight(model: nn.Module, state_dict: Dict):
+    """Keys must match exactly, up to an optional ``module.`` prefix on either side (reference :120-136)."""
+    bare_model(model).load_state_dict(_strip(state_dict))
+
+
+def load_backbone(model: nn.Module, state_dict: Dict):
+    """``state_dict`` holds a prefix of the model's layers (reference :138-156)."""
+    target = bare_model(model)
+    full = target.state_dict()
+    full.update(_strip(state_dict))
+    target.load_state_dict(full)
+
+
+def build_model(cfg_path: Optional[str], weight_path: Optional[str] = None, backbone_path: Optional[str] = None,
+                clear_history: bool = False, device='cuda', dataparallel: bool = True, device_ids=None,
+                qat: bool = False, backend: Optional[str] = None, quantized: bool = False, onnx: bool = False):
+    """reference :158-243 -> (model, info).  ``info`` = checkpoint dict minus ``'model'`` (empty without a weight file)."""
+    from .model.interpreter import DetectionModel
+    model_info = {}
+    state_dict_type = None
+    if weight_path:
+        ckpt = torch.load(weight_path, map_location='cpu')
+        state_dict_type = ckpt.get('type', 'normal')
+        weight = ckpt['model']
+        model_info = {k: v for k, v in ckpt.items() if k != 'model'}
+        if clear_history:
+            model_info['step'] = 0
+    cfg = cfg_path if cfg_path else StringIO(ckpt['cfg'])
+    if state_dict_type in {'qat', 'quant'} or qat or quantized:
+        raise NotImplementedError('QAT / int8 checkpoints (BASELINE config 5) are not implemented in this build yet')
+    model = DetectionModel(cfg, False, onnx)
+    if backbone_path:
+        print('loading backbone weights from {}'.format(backbone_path))
+        load_backbone(model, torch.load(backbone_path, map_location='cpu'))
+    if state_dict_type == 'normal':
+        load_weight(model, weight)
+        print('resumed at %d steps from %s' % (model_info['step'], weight_path))
+    model = model.to(device)
+    if dataparallel:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from .parallel import DistributedModel
+            model = DistributedModel(model)
+    return model, model_info
+
+
+def get_bn_layers(model: nn.Module) -> List[nn.BatchNorm2d]:
+    """BN layers eligible for the sparsity penalty (reference :316-333)."""
+    out, total = [], 0
+    for l in bare_model(model).module_list:
+        if l._type == 'convolutional' and hasattr(l, 'bn'):
+            if not hasattr(l, '_notprune'):
+                out.append(l.bn)
+            total += 1
+    print("sparse mode: {}/{} BN layers will be sparsed.".format(len(out), total))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- timing helpers
+class TicToc:
+    """reference :595-641 (wall-clock records in ns)."""
+
+    def __init__(self, name: Optional[str] = None):
+        self.name = name
+        self.last = 0
+        self.records = []
+
+    def reset(self):
+        self.last = 0
+        self.records.clear()
+
+    def tic(self):
+        self.last = time_ns()
+
+    def toc(self):
+        self.records.append(time_ns() - self.last)
+
+    def mean(self):
+        return float(np.mean(self.records))
+
+    def sum(self):
+        return float(np.sum(self.records))
+
+
+def compute_time(model: nn.Module, times: int = 64, input_size=(3, 512, 512), batch_size: int = 1):
+    """mean eval-forward latency in ms (reference :74-94)."""
+    model.eval()
+    x = torch.zeros(batch_size, *input_size, device='cuda')
+    timer = TicToc()
+    with torch.no_grad():
+        for it in range(times + 10):
+            if it == 10:
+                timer.reset()
+            timer.tic()
+            model(x)
+            torch.cuda.synchronize()
+            timer.toc()
+    return timer.mean() / 1e6

@@ -1,0 +1,586 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch-CPU fp32 statement of the same arithmetic.
+
+Tolerance: conv / BN / loss values within 1e-3 (abs-or-rel, fp32) as BASELINE.json states (in practice ~1e-5);
+index work (NMS selection) bit-exact.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pqdet_amd import abi, ops  # noqa: E402
+
+DEV = 'cuda'
+RT, AT = 1e-3, 1e-4
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def act_ref(u, act):
+    return [lambda v: v, torch.relu, lambda v: v.clamp(0, 6), lambda v: F.leaky_relu(v, 0.1), torch.sigmoid, torch.tanh][act](u)
+
+
+def act_grad_ref(u, act):
+    u = u.detach().clone().requires_grad_(True)
+    act_ref(u, act).sum().backward()
+    return u.grad
+
+
+def close(got, want, rt=RT, at=AT, what=''):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    err = (got - want).abs()
+    tol = at + rt * want.abs()
+    assert bool((err <= tol).all()), '%s max err %g (tol %g at worst), shape %s' % (
+        what, err.max().item(), tol.flatten()[err.argmax()].item(), tuple(got.shape))
+
+
+def rnd(*shape, g, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+def chan_vec(t, pad=16):
+    """per-channel coefficient vector on device, padded so float4 loads past C stay in bounds"""
+    n = t.numel()
+    buf = torch.zeros((n + pad - 1) // pad * pad + pad, dtype=torch.float32)
+    buf[:n] = t
+    return buf.to(DEV)
+
+
+def reduce_partial(partial, nblk, ldp, C_):
+    p = partial.cpu().view(nblk, 2, ldp)
+    return p[:, 0, :C_].double().sum(0), p[:, 1, :C_].double().sum(0)
+
+
+# ----------------------------------------------------------------------------------------------- conv1x1 forward
+@pytest.mark.parametrize('M,I,O,act,affine,bias,stats', [
+    (300, 32, 16, 2, True, False, True),
+    (1000, 24, 144, 0, True, False, True),
+    (257, 160, 960, 2, True, False, True),
+    (512, 1024, 75, 2, True, True, False),
+    (130, 16, 96, 0, False, False, True),
+    (64, 320, 1280, 1, True, False, True),
+])
+def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
+    g = torch.Generator().manual_seed(M + I + O)
+    x = rnd(M, I, g=g)
+    w = rnd(O, I, g=g, scale=1 / math.sqrt(I))
+    sc = torch.rand(I, generator=g) + 0.5 if affine else None
+    sh = rnd(I, g=g, scale=0.3) if affine else None
+    b = rnd(O, g=g) if bias else None
+    xin = act_ref(x * sc + sh if affine else x, act)
+    want = xin @ w.t() + (b if bias else 0)
+    ldo = (O + 3) // 4 * 4 + 4
+    out = torch.full((M, ldo), float('nan'), device=DEV)
+    nblk = (M + 127) // 128
+    ldp = (O + 15) // 16 * 16
+    partial = torch.zeros(nblk * 2 * ldp, device=DEV) if stats else None
+    xd, wd = x.to(DEV), w.to(DEV)
+    a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, act), wd.data_ptr(),
+                       None, out.data_ptr(), abi.ptr(partial), M, I, O, ldo, ldp, 1, 0, 0, 0, 0)
+    keep = []
+    if affine:
+        scd, shd = chan_vec(sc), chan_vec(sh)
+        keep += [scd, shd]
+        a.inp.scale, a.inp.shift = scd.data_ptr(), shd.data_ptr()
+    if bias:
+        bd = b.to(DEV)
+        keep.append(bd)
+        a.bias = bd.data_ptr()
+    abi.check(abi.lib().pq_conv1x1_fwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(out[:, :O], want, what='conv1x1 out')
+    assert torch.isnan(out[:, O:]).all(), 'wrote outside the logical channels'
+    if stats:
+        s1, s2 = reduce_partial(partial, nblk, ldp, O)
+        close(s1.float(), want.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum')
+        close(s2.float(), (want.double() ** 2).sum(0).float(), rt=1e-3, at=1e-2, what='sumsq')
+
+
+def test_conv1x1_fwd_strided_rows():
+    g = torch.Generator().manual_seed(5)
+    B, IH, IW, I, O = 2, 6, 10, 16, 24
+    x = rnd(B, IH, IW, I, g=g)
+    w = rnd(O, I, g=g)
+    want = F.conv2d(x.permute(0, 3, 1, 2), w.view(O, I, 1, 1), stride=2).permute(0, 2, 3, 1)
+    OH, OW = want.shape[1:3]
+    out = torch.empty(B * OH * OW, O, device=DEV)
+    xd, wd = x.to(DEV), w.to(DEV)
+    a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, 0), wd.data_ptr(), None, out.data_ptr(), None,
+                       B * OH * OW, I, O, O, 0, 2, OH, OW, IH, IW)
+    abi.check(abi.lib().pq_conv1x1_fwd(C.byref(a), stream()))
+    close(out.view(B, OH, OW, O), want, what='strided 1x1')
+
+
+# ----------------------------------------------------------------------------------------------- conv1x1 backward
+def _bn_bwd_coeffs(g_, y, gamma, eps=1e-5):
+    """closed-form BN backward as p,q,mu,r coefficient vectors (double)"""
+    n = y.shape[0]
+    mu = y.double().mean(0)
+    var = y.double().var(0, unbiased=False)
+    inv = 1 / torch.sqrt(var + eps)
+    xh = (y.double() - mu) * inv
+    dbeta = g_.double().sum(0)
+    dgamma = (g_.double() * xh).sum(0)
+    p = gamma.double() * inv
+    q = -p * inv * dgamma / n
+    r = -p * dbeta / n
+    return p.float(), q.float(), mu.float(), r.float(), inv.float()
+
+
+@pytest.mark.parametrize('M,I,O,two,act,accum,stats', [
+    (300, 16, 32, True, 2, False, True),
+    (1000, 144, 24, True, 0, True, True),
+    (257, 960, 160, True, 2, False, True),
+    (512, 1024, 75, False, 2, False, True),
+    (130, 96, 576, True, 0, True, False),
+])
+def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
+    g = torch.Generator().manual_seed(M + I + O + 1)
+    gy = rnd(M, O, g=g)
+    yout = rnd(M, O, g=g) + 0.3
+    gamma = torch.rand(O, generator=g) + 0.5
+    w = rnd(O, I, g=g, scale=1 / math.sqrt(O))
+    ldg = (O + 3) // 4 * 4
+    if two:
+        p, q, mu, r, _ = _bn_bwd_coeffs(gy, yout, gamma)
+        dy = p * gy + q * (yout - mu) + r
+    else:
+        dy = gy
+    dz = dy @ w
+    yin = rnd(M, I, g=g) * 2 + 1
+    a_in = torch.rand(I, generator=g) + 0.5
+    b_in = rnd(I, g=g, scale=0.5)
+    mean_in = yin.mean(0)
+    inv_in = 1 / torch.sqrt(yin.var(0, unbiased=False) + 1e-5)
+    old = rnd(M, I, g=g)
+    tot = dz + (old if accum else 0)
+    gout = tot * act_grad_ref(yin * a_in + b_in, act)
+    gyd = torch.zeros(M, ldg, device=DEV)
+    gyd[:, :O] = gy.to(DEV)
+    youtd = torch.zeros(M, ldg, device=DEV)
+    youtd[:, :O] = yout.to(DEV)
+    wd, yind = w.to(DEV), yin.to(DEV)
+    gdst = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
+    nblk = (M + 127) // 128
+    ldp = (I + 15) // 16 * 16
+    partial = torch.zeros(nblk * 2 * ldp, device=DEV)
+    vecs = [chan_vec(v) for v in ((p, q, mu, r) if two else ())]
+    sv = [chan_vec(v) for v in (a_in, b_in, mean_in, inv_in)]
+    a = abi.Conv1x1Dgrad()
+    a.dy = abi.GSrc(gyd.data_ptr(), youtd.data_ptr() if two else None, *([v.data_ptr() for v in vecs] if two else [None] * 4), ldg, ldg)
+    a.w = wd.data_ptr()
+    a.dx = abi.GSink(gdst.data_ptr(), yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
+                     sv[2].data_ptr() if stats else None, sv[3].data_ptr() if stats else None,
+                     partial.data_ptr() if stats else None, I, I, act, int(accum), 1, ldp)
+    a.M, a.I, a.O = M, I, O
+    abi.check(abi.lib().pq_conv1x1_dgrad(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(gdst, gout, what='dgrad sink')
+    if stats:
+        s1, s2 = reduce_partial(partial, nblk, ldp, I)
+        xh = (yin.double() - mean_in.double()) * inv_in.double()
+        close(s1.float(), gout.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum g')
+        close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat')
+
+
+@pytest.mark.parametrize('M,I,O,two,bias', [(3000, 32, 16, True, False), (1000, 24, 144, True, False),
+                                            (4096, 160, 960, True, False), (700, 1024, 75, False, True),
+                                            (5000, 96, 24, True, False)])
+def test_conv1x1_wgrad(M, I, O, two, bias):
+    g = torch.Generator().manual_seed(M + I + O + 2)
+    gy = rnd(M, O, g=g)
+    yout = rnd(M, O, g=g) + 0.3
+    gamma = torch.rand(O, generator=g) + 0.5
+    x = rnd(M, I, g=g)
+    sc, sh = torch.rand(I, generator=g) + 0.5, rnd(I, g=g, scale=0.3)
+    xin = (x * sc + sh).clamp(0, 6)
+    ldg = (O + 3) // 4 * 4
+    if two:
+        p, q, mu, r, _ = _bn_bwd_coeffs(gy, yout, gamma)
+        dy = p * gy + q * (yout - mu) + r
+    else:
+        dy = gy
+    want = dy.double().t() @ xin.double()
+    gyd = torch.zeros(M, ldg, device=DEV)
+    gyd[:, :O] = gy.to(DEV)
+    youtd = torch.zeros(M, ldg, device=DEV)
+    youtd[:, :O] = yout.to(DEV)
+    xd = x.to(DEV)
+    vecs = [chan_vec(v) for v in ((p, q, mu, r) if two else ())]
+    scd, shd = chan_vec(sc), chan_vec(sh)
+    l = abi.lib()
+    scratch = torch.empty(l.pq_conv1x1_wgrad_scratch_bytes(M, I, O) // 4, device=DEV)
+    dw = torch.full((O, I), float('nan'), device=DEV)
+    db = torch.full((O,), float('nan'), device=DEV) if bias else None
+    a = abi.Conv1x1Wgrad()
+    a.dy = abi.GSrc(gyd.data_ptr(), youtd.data_ptr() if two else None, *([v.data_ptr() for v in vecs] if two else [None] * 4), ldg, ldg)
+    a.inp = abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), I, 2)
+    a.dw, a.dbias, a.scratch = dw.data_ptr(), abi.ptr(db), scratch.data_ptr()
+    a.M, a.I, a.O = M, I, O
+    abi.check(l.pq_conv1x1_wgrad(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(dw, want.float(), rt=1e-3, at=1e-3, what='wgrad')
+    if bias:
+        close(db, dy.double().sum(0).float(), rt=1e-3, at=1e-3, what='bias grad')
+
+
+# ----------------------------------------------------------------------------------------------- depthwise 3x3
+@pytest.mark.parametrize('B,H,W,Cc,stride', [(2, 9, 13, 32, 1), (2, 10, 14, 96, 2), (1, 7, 7, 144, 1), (2, 8, 8, 960, 1),
+                                             (1, 5, 9, 576, 2)])
+def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
+    g = torch.Generator().manual_seed(B * H * W + Cc)
+    l = abi.lib()
+    x = rnd(B, H, W, Cc, g=g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, rnd(Cc, g=g, scale=0.3)
+    w = rnd(Cc, 1, 3, 3, g=g, scale=0.4)
+    xin = (x * sc + sh).clamp(0, 6).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(xin, wr, stride=stride, padding=1, groups=Cc)
+    OH, OW = y.shape[2:]
+    yn = y.permute(0, 2, 3, 1).contiguous()
+    xd, wd = x.to(DEV), w.to(DEV)
+    scd, shd = chan_vec(sc), chan_vec(sh)
+    out = torch.full((B, OH, OW, Cc), float('nan'), device=DEV)
+    nblk = l.pq_dw3x3_blocks(B, OH, OW, Cc)
+    ldp = Cc
+    partial = torch.zeros(nblk * 2 * ldp, device=DEV)
+    a = abi.DwFwd(abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), Cc, 2), wd.data_ptr(), out.data_ptr(), partial.data_ptr(),
+                  B, H, W, OH, OW, Cc, stride, Cc, ldp)
+    abi.check(l.pq_dw3x3_fwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(out, yn, what='dw fwd')
+    s1, s2 = reduce_partial(partial, nblk, ldp, Cc)
+    close(s1.float(), yn.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='dw sum')
+    close(s2.float(), (yn.double() ** 2).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='dw sumsq')
+
+    # backward: upstream gradient through a BN on y (two-tensor operand), sink with relu6' and stats
+    gy = rnd(B, OH, OW, Cc, g=g)
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    p, q, mu, r, _ = _bn_bwd_coeffs(gy.view(-1, Cc), yn.detach().view(-1, Cc), gamma)
+    dy = p * gy + q * (yn.detach() - mu) + r
+    y.backward(dy.permute(0, 3, 1, 2))
+    dxin = xin.grad.permute(0, 2, 3, 1)            # gradient w.r.t. the activated input
+    u = x * sc + sh
+    gwant = dxin * ((u > 0) & (u < 6)).float()
+    mean_in = x.view(-1, Cc).mean(0)
+    inv_in = 1 / torch.sqrt(x.view(-1, Cc).var(0, unbiased=False) + 1e-5)
+    gyd, ynd = gy.to(DEV), yn.detach().to(DEV)
+    vecs = [chan_vec(v) for v in (p, q, mu, r)]
+    sv = [chan_vec(v) for v in (mean_in, inv_in)]
+    gdst = torch.full((B, H, W, Cc), float('nan'), device=DEV)
+    nb2 = l.pq_dw3x3_blocks(B, H, W, Cc)
+    part2 = torch.zeros(nb2 * 2 * ldp, device=DEV)
+    d = abi.DwDgrad()
+    d.dy = abi.GSrc(gyd.data_ptr(), ynd.data_ptr(), *[v.data_ptr() for v in vecs], Cc, Cc)
+    d.w = wd.data_ptr()
+    d.dx = abi.GSink(gdst.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
+                     part2.data_ptr(), Cc, Cc, 2, 0, 1, ldp)
+    d.B, d.IH, d.IW, d.OH, d.OW, d.C, d.stride = B, H, W, OH, OW, Cc, stride
+    abi.check(l.pq_dw3x3_dgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    close(gdst, gwant, what='dw dgrad')
+    s1, s2 = reduce_partial(part2, nb2, ldp, Cc)
+    xh = (x.double() - mean_in.double()) * inv_in.double()
+    close(s1.float(), gwant.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='dw dgrad sum')
+    close(s2.float(), (gwant.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='dw dgrad sum xhat')
+
+    scratch = torch.empty(l.pq_dw3x3_wgrad_scratch_bytes(B, OH, OW, Cc) // 4, device=DEV)
+    dw = torch.full((Cc, 9), float('nan'), device=DEV)
+    wg = abi.DwWgrad()
+    wg.dy = d.dy
+    wg.inp = a.inp
+    wg.dw, wg.scratch = dw.data_ptr(), scratch.data_ptr()
+    wg.B, wg.IH, wg.IW, wg.OH, wg.OW, wg.C, wg.stride = B, H, W, OH, OW, Cc, stride
+    abi.check(l.pq_dw3x3_wgrad(C.byref(wg), stream()))
+    torch.cuda.synchronize()
+    close(dw.view(Cc, 1, 3, 3), wr.grad, rt=1e-3, at=1e-3, what='dw wgrad')
+
+
+# ----------------------------------------------------------------------------------------------- stem
+@pytest.mark.parametrize('B,H,W,O,stride', [(2, 16, 20, 32, 2), (1, 9, 9, 16, 1)])
+def test_stem(B, H, W, O, stride):
+    g = torch.Generator().manual_seed(77 + H)
+    l = abi.lib()
+    img = rnd(B, 3, H, W, g=g)
+    w = rnd(O, 3, 3, 3, g=g, scale=0.3).requires_grad_(True)
+    y = F.conv2d(img, w, stride=stride, padding=1)
+    OH, OW = y.shape[2:]
+    yn = y.permute(0, 2, 3, 1).contiguous()
+    imgd, wd = img.to(DEV), w.detach().to(DEV)
+    out = torch.empty(B, OH, OW, O, device=DEV)
+    nblk = l.pq_ew_blocks(B * OH * OW, O)
+    partial = torch.zeros(nblk * 2 * O, device=DEV)
+    a = abi.StemFwd(imgd.data_ptr(), wd.data_ptr(), out.data_ptr(), partial.data_ptr(), B, 3, H, W, OH, OW, O, stride, O, O)
+    abi.check(l.pq_stem3x3_fwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(out, yn, what='stem fwd')
+    s1, s2 = reduce_partial(partial, nblk, O, O)
+    close(s1.float(), yn.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2)
+    gy = rnd(B, OH, OW, O, g=g)
+    y.backward(gy.permute(0, 3, 1, 2))
+    gyd = gy.to(DEV)
+    scratch = torch.empty(l.pq_stem3x3_wgrad_scratch_bytes(B, OH, OW, O, 3) // 4, device=DEV)
+    dw = torch.full((O, 3, 3, 3), float('nan'), device=DEV)
+    wg = abi.StemWgrad(abi.GSrc(gyd.data_ptr(), None, None, None, None, None, O, 0), imgd.data_ptr(), dw.data_ptr(),
+                       scratch.data_ptr(), B, 3, H, W, OH, OW, O, stride)
+    abi.check(l.pq_stem3x3_wgrad(C.byref(wg), stream()))
+    torch.cuda.synchronize()
+    close(dw, w.grad, rt=1e-3, at=1e-3, what='stem wgrad')
+
+
+# ----------------------------------------------------------------------------------------------- BN finalize
+def test_bn_finalize_matches_batchnorm2d():
+    g = torch.Generator().manual_seed(11)
+    l = abi.lib()
+    Cc, N = 40, 500
+    y = rnd(N, Cc, g=g) * 3 + 2
+    bn = torch.nn.BatchNorm2d(Cc)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cc, generator=g) + 0.5)
+        bn.bias.copy_(rnd(Cc, g=g))
+        bn.running_mean.copy_(rnd(Cc, g=g))
+        bn.running_var.copy_(torch.rand(Cc, generator=g) + 0.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    yin = y.t().reshape(1, Cc, N, 1).clone().requires_grad_(True)
+    out = bn(yin)
+    gup = rnd(1, Cc, N, 1, g=g)
+    out.backward(gup)
+    nblk, ldp = 3, 48
+    partial = torch.zeros(nblk, 2, ldp)
+    chunks = [slice(0, 200), slice(200, 350), slice(350, 500)]
+    for k, s in enumerate(chunks):
+        partial[k, 0, :Cc] = y[s].sum(0)
+        partial[k, 1, :Cc] = (y[s] ** 2).sum(0)
+    dv = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    gam, bet, rm, rv = dv(bn.weight.detach()), dv(bn.bias.detach()), dv(rm0), dv(rv0)
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    mean, inv, sc, sh = (torch.empty(Cc, device=DEV) for _ in range(4))
+    pd = dv(partial)
+    a = abi.BnFwdFin(pd.data_ptr(), gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(),
+                     mean.data_ptr(), inv.data_ptr(), sc.data_ptr(), sh.data_ptr(), nblk, ldp, Cc, 1, float(N), 1e-5, 0.1)
+    abi.check(l.pq_bn_fwd_finalize(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(rm, bn.running_mean, what='running_mean')
+    close(rv, bn.running_var, what='running_var')
+    assert nbt.item() == 1
+    close(y.to(DEV) * sc + sh, out.detach().view(Cc, N).t(), what='normalised')
+    # backward coefficients reproduce autograd's dx
+    gflat = gup.view(Cc, N).t().contiguous()
+    xh = (y.double() - y.double().mean(0)) / torch.sqrt(y.double().var(0, unbiased=False) + 1e-5)
+    part2 = torch.zeros(nblk, 2, ldp)
+    for k, s in enumerate(chunks):
+        part2[k, 0, :Cc] = gflat[s].sum(0)
+        part2[k, 1, :Cc] = (gflat[s].double() * xh[s]).sum(0).float()
+    p2 = dv(part2)
+    dgam, dbet, pp, qq, rr = (torch.empty(Cc, device=DEV) for _ in range(5))
+    b = abi.BnBwdFin(p2.data_ptr(), gam.data_ptr(), inv.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), pp.data_ptr(),
+                     qq.data_ptr(), rr.data_ptr(), nblk, ldp, Cc, 1, float(N))
+    abi.check(l.pq_bn_bwd_finalize(C.byref(b), stream()))
+    torch.cuda.synchronize()
+    close(dgam, bn.weight.grad, what='dgamma')
+    close(dbet, bn.bias.grad, what='dbeta')
+    dx = pp * gflat.to(DEV) + qq * (y.to(DEV) - mean) + rr
+    close(dx, yin.grad.view(Cc, N).t(), what='bn dx')
+    # eval mode
+    a.train = 0
+    abi.check(l.pq_bn_fwd_finalize(C.byref(a), stream()))
+    bn.eval()
+    close(y.to(DEV) * sc + sh, bn(yin).detach().view(Cc, N).t(), what='eval normalised')
+
+
+# ----------------------------------------------------------------------------------------------- copy / route
+def test_copy_and_route():
+    g = torch.Generator().manual_seed(3)
+    l = abi.lib()
+    B, H, W, C1, C2 = 2, 4, 6, 16, 8
+    a1 = rnd(B, H // 2, W // 2, C1, g=g)
+    s1, h1 = torch.rand(C1, generator=g) + 0.5, rnd(C1, g=g)
+    a2 = rnd(B, H, W, C2, g=g)
+    want = torch.cat([F.interpolate((a1 * s1 + h1).clamp(0, 6).permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1), a2], -1)
+    out = torch.full((B, H, W, C1 + C2), float('nan'), device=DEV)
+    a1d, a2d, s1d, h1d = a1.to(DEV), a2.to(DEV), chan_vec(s1), chan_vec(h1)
+    c = abi.Copy(abi.Src(a1d.data_ptr(), s1d.data_ptr(), h1d.data_ptr(), C1, 2), abi.Src(None, None, None, 0, 0), out.data_ptr(),
+                 B, H, W, C1, C1 + C2, 0, 2)
+    abi.check(l.pq_copy_fwd(C.byref(c), stream()))
+    c = abi.Copy(abi.Src(a2d.data_ptr(), None, None, C2, 0), abi.Src(None, None, None, 0, 0), out.data_ptr(), B, H, W, C2, C1 + C2, C1, 1)
+    abi.check(l.pq_copy_fwd(C.byref(c), stream()))
+    torch.cuda.synchronize()
+    close(out, want, what='route cat + upsample')
+    # shortcut: out = a2' + b2
+    b2 = rnd(B, H, W, C2, g=g)
+    out2 = torch.empty(B, H, W, C2, device=DEV)
+    b2d = b2.to(DEV)
+    c = abi.Copy(abi.Src(a2d.data_ptr(), None, None, C2, 1), abi.Src(b2d.data_ptr(), None, None, C2, 0), out2.data_ptr(), B, H, W, C2, C2, 0, 1)
+    abi.check(l.pq_copy_fwd(C.byref(c), stream()))
+    close(out2, a2.relu() + b2, what='shortcut')
+    # route backward of the upsampled slice, finalising relu6' with stats
+    gout = rnd(B, H, W, C1 + C2, g=g)
+    goutd = gout.to(DEV)
+    dz = gout[..., :C1].view(B, H // 2, 2, W // 2, 2, C1).sum((2, 4))
+    u = a1 * s1 + h1
+    gw = dz * ((u > 0) & (u < 6)).float()
+    mean = a1.view(-1, C1).mean(0)
+    inv = 1 / torch.sqrt(a1.view(-1, C1).var(0, unbiased=False) + 1e-5)
+    md, idv = chan_vec(mean), chan_vec(inv)
+    gdst = torch.empty(B, H // 2, W // 2, C1, device=DEV)
+    nblk = l.pq_ew_blocks(B * (H // 2) * (W // 2), C1)
+    part = torch.zeros(nblk * 2 * C1, device=DEV)
+    r = abi.RouteBwd(goutd.data_ptr(), abi.GSink(gdst.data_ptr(), a1d.data_ptr(), s1d.data_ptr(), h1d.data_ptr(), md.data_ptr(),
+                                                 idv.data_ptr(), part.data_ptr(), C1, C1, 2, 0, 1, C1), B, H // 2, W // 2, C1, C1 + C2, 0, 2)
+    abi.check(l.pq_route_bwd(C.byref(r), stream()))
+    torch.cuda.synchronize()
+    close(gdst, gw, what='route bwd')
+    t1, t2 = reduce_partial(part, nblk, C1, C1)
+    close(t1.float(), gw.double().sum((0, 1, 2)).float(), at=1e-3)
+    xh = (a1.double() - mean.double()) * inv.double()
+    close(t2.float(), (gw.double() * xh).sum((0, 1, 2)).float(), at=1e-3)
+
+
+# ----------------------------------------------------------------------------------------------- head
+def test_decode_golden(golden):
+    for tag in 'ab':
+        ncls, stride = (int(v) for v in golden['g2_%s_meta' % tag])
+        raw = torch.from_numpy(golden['g2_%s_in' % tag]).to(DEV).requires_grad_(True)
+        out = ops.decode_nchw(raw, ncls, stride)
+        close(out, torch.from_numpy(golden['g2_%s_out' % tag]), rt=1e-5, at=1e-5, what='decode')
+
+
+@pytest.mark.parametrize('kind', ['l1', 'giou', 'diou', 'iou'])
+def test_loss_golden_forward_and_grad(golden, kind):
+    from pqdet_amd.model.loss import loss_per_scale
+    raw = torch.from_numpy(golden['g3_raw']).to(DEV).requires_grad_(True)
+    label = torch.from_numpy(golden['g3_label']).to(DEV)
+    boxes = torch.from_numpy(golden['g3_boxes']).to(DEV)
+    opt = {'stride': 16, 'bbox_loss': kind, 'ignore_thresh': 0.5, 'l1_loss_gain': 0.05, 'classes': 3}
+    pred = ops.decode_nchw(raw, 3, 16)
+    pred.retain_grad()
+    out = loss_per_scale(pred, label, boxes, opt)
+    out[0].sum().backward()
+    close(torch.cat([o.detach() for o in out]), torch.from_numpy(golden['g3_%s_losses' % kind]), rt=1e-4, at=1e-5, what='losses')
+    close(pred.grad, torch.from_numpy(golden['g3_%s_dpred' % kind]), rt=1e-3, at=1e-5, what='dpred')
+    close(raw.grad, torch.from_numpy(golden['g3_%s_draw' % kind]), rt=1e-3, at=1e-5, what='draw')
+
+
+def test_loss_ciou_raises_like_reference(golden):
+    from pqdet_amd.model.loss import loss_per_scale
+    raw = torch.from_numpy(golden['g3_raw']).to(DEV)
+    opt = {'stride': 16, 'bbox_loss': 'ciou', 'ignore_thresh': 0.5, 'l1_loss_gain': 0.05, 'classes': 3}
+    with pytest.raises(RuntimeError, match='NaN in loss'):
+        loss_per_scale(ops.decode_nchw(raw, 3, 16), torch.from_numpy(golden['g3_label']).to(DEV),
+                       torch.from_numpy(golden['g3_boxes']).to(DEV), opt)
+
+
+def test_loss_random_vs_oracle_bigger():
+    from oracle import loss as oloss
+    from oracle.net import OracleNet
+    from pqdet_amd.model.loss import loss_per_scale
+    g = torch.Generator().manual_seed(21)
+    B, H, W, A, Cc, M = 3, 8, 8, 3, 20, 150          # M > 128 exercises the global-memory box path
+    raw = rnd(B, A * (5 + Cc), H, W, g=g, scale=0.8)
+    label = torch.zeros(B, H, W, A, 6 + Cc)
+    label[..., -1] = 1
+    boxes = torch.zeros(B, M, 4)
+    for b in range(B):
+        for j in range(40):
+            x1, y1 = torch.rand(2, generator=g) * 200
+            w_, h_ = torch.rand(2, generator=g) * 50 + 4
+            cy, cx = int((y1 + h_ / 2) // 32) % H, int((x1 + w_ / 2) // 32) % W
+            oh = torch.full((Cc,), 0.01 / Cc)
+            oh[j % Cc] += 0.99
+            label[b, cy, cx, j % A] = torch.tensor([x1, y1, x1 + w_, y1 + h_, 1.0, *oh.tolist(), 0.6 + 0.4 * (j % 2)])
+            boxes[b, j] = torch.tensor([x1, y1, x1 + w_, y1 + h_])
+    for kind in ('l1', 'giou'):
+        opt = {'stride': 32, 'bbox_loss': kind, 'ignore_thresh': 0.5, 'l1_loss_gain': 0.05, 'classes': Cc}
+        rc = raw.clone().requires_grad_(True)
+        want = oloss.loss_per_scale(OracleNet.decode(rc, Cc, 32), label, boxes, opt)
+        want[0].sum().backward()
+        rg = raw.to(DEV).requires_grad_(True)
+        got = loss_per_scale(ops.decode_nchw(rg, Cc, 32), label.to(DEV), boxes.to(DEV), opt)
+        got[0].sum().backward()
+        close(torch.cat([o.detach() for o in got]), torch.cat([o.detach() for o in want]), rt=1e-4, at=1e-4, what='loss ' + kind)
+        close(rg.grad, rc.grad, rt=1e-3, at=1e-5, what='draw ' + kind)
+
+
+def test_iou_family_golden(golden):
+    from pqdet_amd import tools
+    b1, b2 = torch.from_numpy(golden['g4_b1']).to(DEV), torch.from_numpy(golden['g4_b2']).to(DEV)
+    for name in ('iou_calc3', 'giou', 'diou'):
+        got = getattr(tools, name)(b1[:, None, :], b2[None, :, :])
+        want = torch.from_numpy(golden['g4_bc_' + name])
+        ok = ~torch.isnan(want)
+        close(got.cpu()[ok], want[ok], rt=1e-5, at=1e-6, what=name)
+        assert torch.isnan(got.cpu()[~ok]).all()
+
+
+# ----------------------------------------------------------------------------------------------- adam
+def test_adam_matches_torch():
+    g = torch.Generator().manual_seed(9)
+    n = 10007
+    p0 = rnd(n, g=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=4e-4, weight_decay=1e-2)
+    p = p0.to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gr = rnd(n, g=g)
+        ref.grad = gr.clone()
+        opt.step()
+        ops.adam_step(p, gr.to(DEV), m, v, 4e-4, 0.9, 0.999, 1e-8, 1e-2, step)
+    close(p, ref.detach(), rt=1e-5, at=1e-6, what='adam')
+
+
+# ----------------------------------------------------------------------------------------------- post-process
+def test_recover_golden(golden):
+    from pqdet_amd.dataset import base_sample
+    pred = torch.from_numpy(golden['g6_pred'])
+    insz = torch.FloatTensor([512, 512])
+    orig = torch.from_numpy(golden['g6_orig'])
+    for name, key, o in (('voc', 'g6_voc', orig), ('voc', 'g6_voc_single', orig[0]), ('visdrone', 'g6_visdrone', orig)):
+        p = pred.clone().to(DEV)
+        got = base_sample.RECOVER_BBOXES_REGISTER[name](p, insz.to(DEV), o.to(DEV))
+        close(got, torch.from_numpy(golden[key]), rt=1e-6, at=1e-5, what=key)
+        # in-place contract of the reference: input now holds the recovered boxes and conf-scaled probs
+        close(p[..., :4], got[..., :4], rt=0, at=0)
+        close(p[..., 5:], got[..., 4:], rt=0, at=0)
+
+
+def _random_dets(n, ncls, seed, hot=0.3):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(n, 2, generator=g) * 300
+    wh = torch.rand(n, 2, generator=g) * 80 + 4
+    sc = torch.rand(n, ncls, generator=g)
+    sc = sc * (torch.rand(n, ncls, generator=g) < hot).float()
+    return torch.cat([xy, xy + wh, sc], 1).float()
+
+
+@pytest.mark.parametrize('n,ncls,seed', [(40, 3, 1), (700, 20, 2), (3000, 20, 3), (16128, 20, 4), (50, 5, 5)])
+def test_nms_selection_bit_exact(n, ncls, seed):
+    from oracle import postprocess as opost
+    from pqdet_amd import tools
+    bb = _random_dets(n, ncls, seed, hot=0.3 if n < 10000 else 0.05)
+    want = opost.torch_nms(bb.numpy(), 0.1, 0.45)
+    got = tools.torch_nms(bb.to(DEV), 0.1, 0.45).cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+
+
+def test_nms_empty_and_ties():
+    from oracle import postprocess as opost
+    from pqdet_amd import tools
+    bb = _random_dets(30, 4, 8)
+    none = tools.torch_nms(bb.to(DEV), 2.0, 0.45)
+    assert tuple(none.shape) == (0,)
+    # identical boxes / identical scores: ties resolve by ascending candidate index on both sides
+    bb[5] = bb[4]
+    bb[7, :4] = bb[6, :4]
+    want = opost.torch_nms(bb.numpy(), 0.1, 0.45)
+    got = tools.torch_nms(bb.to(DEV), 0.1, 0.45).cpu().numpy()
+    np.testing.assert_array_equal(got, want)

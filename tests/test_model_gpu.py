@@ -1,0 +1,145 @@
+"""End-to-end parity of the HIP engine (DetectionModel on cuda) against the golden vectors and the CPU oracle."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import postprocess as opost  # noqa: E402
+from oracle.net import OracleNet  # noqa: E402
+from pqdet_amd import optim  # noqa: E402
+from pqdet_amd.model import zoo  # noqa: E402
+from pqdet_amd.model.interpreter import DetectionModel  # noqa: E402
+from seedfill import seeded_boxes, seeded_fill, seeded_images  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _targets(batch, h, w, ncls, seed=1):
+    bl = seeded_boxes(batch, min(h, w), ncls, seed)
+    hw = np.array([[h // s, w // s] for s in (8, 16, 32)])
+    per = [opost.create_label(bb, hw, ncls) for bb in bl]
+    labels = [torch.from_numpy(np.stack([p[i] for p in per])) for i in range(3)]
+    boxes = [torch.from_numpy(opost.pad_boxes([p[3 + i] for p in per])) for i in range(3)]
+    return tuple(labels + boxes)
+
+
+def _pair(seed=0):
+    text = zoo.cfg_text('mobilenetv2-fpn')
+    net = DetectionModel(io.StringIO(text))
+    seeded_fill(net, seed)
+    ref = OracleNet(io.StringIO(text))
+    ref.load_state_dict(net.state_dict())
+    return net.to(DEV), ref
+
+
+def _relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_golden_g5_mobilenetv2_64(golden, g5_names):
+    net, _ = _pair()
+    x = seeded_images(2, 64, 64, 0).to(DEV)
+    tgt = tuple(t.to(DEV) for t in _targets(2, 64, 64, 20))
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+    np.testing.assert_allclose(ev.cpu().numpy(), golden['g5_mbv2_64_eval'], rtol=1e-3, atol=1e-3)
+    net.train()
+    out = net(x, tgt)
+    out['loss'].mean().backward()
+    got = np.array([out[k].item() for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss')]
+                   + [v.item() for v in out['loss_per_branch']])
+    np.testing.assert_allclose(got, golden['g5_mbv2_64_loss'], rtol=1e-3)
+    names = [k for k, _ in net.named_parameters()]
+    assert names == g5_names['mbv2_64']
+    gn = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
+    np.testing.assert_allclose(gn, golden['g5_mbv2_64_gradnorm'], rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(net.module_list[0].conv.weight.grad.cpu().numpy(), golden['g5_mbv2_64_grad_first_w'],
+                               rtol=1e-2, atol=1e-3 * np.abs(golden['g5_mbv2_64_grad_first_w']).max())
+    sd = net.state_dict()
+    rm = [k for k in sd if k.endswith('running_mean')]
+    np.testing.assert_allclose(sd[rm[0]].cpu().numpy(), golden['g5_mbv2_64_rmean_first'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sd[rm[-1].replace('running_mean', 'running_var')].cpu().numpy(),
+                               golden['g5_mbv2_64_rvar_last'], rtol=1e-4, atol=1e-5)
+    assert sd[rm[0].replace('running_mean', 'num_batches_tracked')].item() == 1
+
+
+@pytest.mark.parametrize('B,H,W', [(3, 96, 160), (2, 128, 128)])
+def test_train_step_matches_oracle_every_gradient(B, H, W):
+    net, ref = _pair(seed=3)
+    x = seeded_images(B, H, W, 5)
+    tgt = _targets(B, H, W, 20, seed=7)
+    net.train(), ref.train()
+    out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    out['loss'].mean().backward()
+    want = ref(x, tgt)
+    want['loss'].mean().backward()
+    for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss'):
+        assert abs(out[k].item() - want[k].item()) <= 1e-3 * abs(want[k].item()) + 1e-5, k
+    worst = 0.0
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        assert n1 == n2
+        e = _relerr(p1.grad, p2.grad)
+        worst = max(worst, e)
+        assert e < 5e-3 or p2.grad.norm().item() < 1e-7, (n1, e)
+    print('worst relative gradient error', worst)
+    for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
+        if b1.is_floating_point():
+            assert _relerr(b1, b2) < 1e-4, n1
+
+
+def test_two_adam_steps_and_multiscale():
+    net, ref = _pair(seed=4)
+    net.train(), ref.train()
+    opt = optim.Adam(net.parameters(), lr=4e-4)
+    ropt = torch.optim.Adam(ref.parameters(), lr=4e-4)
+    for step, (H, W) in enumerate([(64, 64), (96, 96), (64, 64)]):
+        x = seeded_images(2, H, W, 10 + step)
+        tgt = _targets(2, H, W, 20, seed=20 + step)
+        opt.zero_grad()
+        net(x.to(DEV), tuple(t.to(DEV) for t in tgt))['loss'].mean().backward()
+        opt.step()
+        ropt.zero_grad()
+        ref(x, tgt)['loss'].mean().backward()
+        ropt.step()
+    # Adam normalises the step, so parameters stay close even where tiny gradients differ in the last bits
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        assert (p1.detach().cpu() - p2.detach()).abs().max().item() < 2e-3, n1
+    net.eval(), ref.eval()
+    x = seeded_images(2, 64, 64, 99)
+    with torch.no_grad():
+        a, b = net(x.to(DEV)).cpu(), ref(x)
+    assert _relerr(a, b) < 2e-2
+
+
+def test_eval_then_recover_then_nms_pipeline():
+    from pqdet_amd import tools
+    from pqdet_amd.dataset import RECOVER_BBOXES_REGISTER
+    net, ref = _pair(seed=6)
+    net.eval(), ref.eval()
+    x = seeded_images(2, 128, 128, 1)
+    with torch.no_grad():
+        pred = net(x.to(DEV))
+        pred_ref = ref(x)
+    insz = torch.FloatTensor([128, 128])
+    orig = torch.FloatTensor([[100, 120], [128, 90]])
+    got = RECOVER_BBOXES_REGISTER['voc'](pred, insz.to(DEV), orig.to(DEV))
+    want = opost.recover_boxes(pred_ref, insz, orig, 'voc')
+    assert _relerr(got, want) < 1e-3
+    # NMS selection on identical inputs (the oracle's recovered boxes) is bit-exact
+    for i in range(2):
+        a = tools.torch_nms(want[i].contiguous().to(DEV), 0.1, 0.45).cpu().numpy()
+        b = opost.torch_nms(want[i].numpy(), 0.1, 0.45)
+        assert a.shape == b.shape
+        np.testing.assert_array_equal(a, b)
+
+
+def test_no_cpu_fallback():
+    from pqdet_amd import abi
+    net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
+    with pytest.raises(abi.PQError):
+        net(torch.zeros(1, 3, 64, 64))
