@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one TRAIN STEP of mobilenetv2-fpn, 512x512, batch 16 per GPU (BASELINE.json,
+configs[1]), synthetic data, fp32, on N MI355X of one node (one process per GPU, RCCL gradient all-reduce).
+
+    python bench.py                                   # N=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward (conv backbone + FPN neck + 3 YOLO heads + fused decode/loss) + zero_grad + backward
+(+ gradient all-reduce) + fused Adam update, i.e. the body of the reference's ``trainer.py:225-242``; the batch is
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
+``roofline`` (dominant kernel class, measured live with HIP events on the launch stream in a separate profiling pass)
+and ``cpu_baseline`` (the CPU oracle's train step on the host cores, N=1 only).
+"""
+import argparse
+import ctypes as C
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pqdet_amd import abi, optim  # noqa: E402
+from pqdet_amd.dataset import labels  # noqa: E402
+from pqdet_amd.model import zoo  # noqa: E402
+from pqdet_amd.model.interpreter import DetectionModel  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec
+
+KERNEL_CLASS = {
+    abi.OP_CONV1X1_FWD: ('conv1x1_fwd (gemm_nt, fp32 MFMA)', 'mfma'),
+    abi.OP_CONV1X1_DGRAD: ('conv1x1_dgrad (gemm_nt, fp32 MFMA)', 'mfma'),
+    abi.OP_CONV1X1_WGRAD: ('conv1x1_wgrad (gemm_tn, fp32 MFMA)', 'mfma'),
+    abi.OP_DW_FWD: ('dw3x3_fwd', 'hbm'), abi.OP_DW_DGRAD: ('dw3x3_dgrad', 'hbm'), abi.OP_DW_WGRAD: ('dw3x3_wgrad', 'hbm'),
+    abi.OP_STEM_FWD: ('stem3x3_fwd', 'hbm'), abi.OP_STEM_WGRAD: ('stem3x3_wgrad', 'hbm'),
+    abi.OP_BN_FWD_FIN: ('bn_fwd_finalize', 'hbm'), abi.OP_BN_BWD_FIN: ('bn_bwd_finalize', 'hbm'),
+    abi.OP_COPY_FWD: ('copy_fwd (shortcut/route/upsample)', 'hbm'), abi.OP_ROUTE_BWD: ('route_bwd', 'hbm'),
+    abi.OP_LOSS_FWD: ('yolo_loss_fwd', 'hbm'), abi.OP_LOSS_BWD: ('yolo_loss_bwd', 'hbm'), abi.OP_FILL: ('fill', 'hbm'),
+}
+
+
+def op_work(op):
+    """Algorithmic (flops, bytes) of one op: SURVEY 8(d) counting rule -- 2*MACs; 4*(in + out elements) + weights."""
+    c = op.code
+    if c in (abi.OP_CONV1X1_FWD,):
+        a = op.u.c1f
+        return 2.0 * a.M * a.I * a.O, 4.0 * (a.M * a.I + a.M * a.O + a.I * a.O)
+    if c in (abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_WGRAD):
+        a = op.u.c1d if c == abi.OP_CONV1X1_DGRAD else op.u.c1w
+        return 2.0 * a.M * a.I * a.O, 4.0 * (a.M * a.I + a.M * a.O + a.I * a.O)
+    if c in (abi.OP_DW_FWD, abi.OP_DW_DGRAD, abi.OP_DW_WGRAD):
+        a = {abi.OP_DW_FWD: op.u.dwf, abi.OP_DW_DGRAD: op.u.dwd, abi.OP_DW_WGRAD: op.u.dww}[c]
+        n_in, n_out = a.B * a.IH * a.IW * a.C, a.B * a.OH * a.OW * a.C
+        return 2.0 * 9 * n_out, 4.0 * (n_in + n_out + 9 * a.C)
+    if c in (abi.OP_STEM_FWD, abi.OP_STEM_WGRAD):
+        a = op.u.stf if c == abi.OP_STEM_FWD else op.u.stw
+        n_in, n_out = a.B * a.CI * a.IH * a.IW, a.B * a.OH * a.OW * a.O
+        return 2.0 * 27 * n_out, 4.0 * (n_in + n_out)
+    if c == abi.OP_COPY_FWD:
+        a = op.u.cp
+        n = a.B * a.H * a.W * a.C
+        return float(n), 4.0 * n * (3 if a.b.x else 2)
+    if c == abi.OP_ROUTE_BWD:
+        a = op.u.rb
+        n = a.B * a.H * a.W * a.C
+        return float(n), 4.0 * n * 2
+    if c in (abi.OP_LOSS_FWD, abi.OP_LOSS_BWD):
+        a = op.u.loss
+        n = a.B * a.H * a.W * a.A * (5 + a.C)
+        return 30.0 * n, 4.0 * n * 3
+    return 0.0, 0.0
+
+
+def profile_kernels(plan, x, tgt, passes=3):
+    """Per-kernel-class device time of one step, HIP events on the launch stream (profiling pass, not the timed run)."""
+    l = abi.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    plan._patch(x, tgt)
+    acc = {}
+    for arr, n in ((plan.fwd_arr, len(plan.fwd)), (plan.bwd_arr, len(plan.bwd))):
+        ms = (C.c_float * n)()
+        tot = [0.0] * n
+        for _ in range(passes):
+            abi.check(l.pq_run_ops_timed(arr, n, st, ms), 'profiling pass')
+            for k in range(n):
+                tot[k] += ms[k] / passes
+        for k in range(n):
+            name, bound = KERNEL_CLASS.get(arr[k].code, ('other', 'hbm'))
+            fl, by = op_work(arr[k])
+            e = acc.setdefault(name, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0, 'bound': bound})
+            e['ms'] += tot[k]; e['flops'] += fl; e['bytes'] += by; e['launches'] += 1
+    return acc
+
+
+def cpu_baseline(batch, size, steps=2):
+    """The CPU oracle (oracle/, PyTorch-CPU restatement pinned against the reference's golden vectors) timed on the
+    host cores on the same workload shape.  Reported baseline only -- never part of the measured path."""
+    from oracle.net import OracleNet
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    net = OracleNet(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=4e-4)
+    x = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(0))
+    tgt = labels.synthetic_targets(batch, size, 20, seed=1)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        net(x, tgt)['loss'].mean().backward()
+        opt.step()
+        if i:
+            times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    return {'value': batch / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d timed train steps (after 1 warm-up) of mobilenetv2-fpn %dx%d batch %d on the CPU oracle, '
+                      '%.2f s/step' % (steps, size, size, batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(0)
+    model = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn'))).to(dev)
+    model.train()
+    model.nan_check = 'deferred'
+    runner = model
+    if world > 1:
+        from pqdet_amd.parallel import DistributedModel
+        runner = DistributedModel(model)
+    opt = optim.Adam(model.parameters(), lr=4e-4, weight_decay=0.0)
+
+    B, S = args.batch, args.size
+    x = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(rank)).to(dev)
+    tgt = tuple(t.to(dev) for t in labels.synthetic_targets(B, S, 20, seed=1 + rank))
+
+    def step():
+        opt.zero_grad()
+        out = runner(x, tgt)
+        out['loss'].mean().backward()
+        opt.step()
+        return out
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    model.check_nan(wait=True)
+    loss_value = out['loss'].item()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        plan = list(model._plans.values())[0]
+        prof = profile_kernels(plan, x, tgt)
+        dom_name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
+        if dom['bound'] == 'mfma':
+            achieved, peak, unit = dom['flops'] / (dom['ms'] * 1e-3) / 1e12, PEAK_FP32_TFLOPS, 'TFLOP/s'
+        else:
+            achieved, peak, unit = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9, PEAK_HBM_GBS, 'GB/s'
+        total_ms = sum(v['ms'] for v in prof.values())
+        roofline = {'bound': dom['bound'], 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
+                    'frac': round(achieved / peak, 4), 'traffic': None, 'kernel': dom_name,
+                    'kernel_ms_per_step': round(dom['ms'], 3), 'launches_per_step': dom['launches'],
+                    'device_ms_per_step_all_kernels': round(total_ms, 3),
+                    'breakdown_ms': {k: round(v['ms'], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}}
+        line = {
+            'metric': 'images/sec train step, mobilenetv2-fpn 512x512 bs16/GPU', 'value': round(value, 2),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'mobilenetv2-fpn.cfg train step (fwd + YOLO loss + bwd + Adam), %dx%d, batch %d per GPU, '
+                                   'C=20, random-init weights' % (S, S, B),
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(B, S)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -327,6 +327,9 @@ typedef struct pq_op {
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);
+/* profiling variant: brackets every op with HIP events on `stream`, synchronises at the end and writes the elapsed
+ * milliseconds of op k to ms[k] (used by bench.py for the live roofline figure; never on the timed path) */
+int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms);
 /* index of the first failing op of the last pq_run_ops (or -1) and its message */
 int pq_last_failed_op(void);
 const char* pq_last_error(void);

@@ -195,6 +195,7 @@ SIGNATURES = {
     'pq_nms': (C.c_int, [C.POINTER(Nms), C.c_void_p]),
     'pq_nms_scratch_bytes': (i64, [i32, i32]),
     'pq_run_ops': (C.c_int, [C.POINTER(Op), i32, C.c_void_p]),
+    'pq_run_ops_timed': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.POINTER(C.c_float)]),
     'pq_last_failed_op': (C.c_int, []),
     'pq_last_error': (C.c_char_p, []),
     'pq_version': (C.c_char_p, []),

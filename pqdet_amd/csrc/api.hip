@@ -52,6 +52,31 @@ extern "C" int pq_run_ops(const pq_op* ops, int32_t n, void* stream) {
     return PQ_OK;
 }
 
+extern "C" int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms) {
+    g_failed_op = -1;
+    if (!ops || n < 0 || !ms) { pq_set_error("pq_run_ops_timed: bad arguments"); return PQ_EINVAL; }
+    static thread_local hipEvent_t* ev = nullptr;
+    static thread_local int nev = 0;
+    if (nev < n + 1) {
+        for (int i = 0; i < nev; ++i) hipEventDestroy(ev[i]);
+        delete[] ev;
+        ev = new hipEvent_t[n + 1];
+        nev = n + 1;
+        for (int i = 0; i < nev; ++i)
+            if (hipEventCreate(&ev[i]) != hipSuccess) { pq_set_error("pq_run_ops_timed: hipEventCreate failed"); return PQ_ELAUNCH; }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipEventRecord(ev[0], st);
+    for (int i = 0; i < n; ++i) {
+        const int rc = run_one(ops[i], stream);
+        if (rc != PQ_OK) { g_failed_op = i; return rc; }
+        hipEventRecord(ev[i + 1], st);
+    }
+    if (hipEventSynchronize(ev[n]) != hipSuccess) { pq_set_error("pq_run_ops_timed: sync failed"); return PQ_ELAUNCH; }
+    for (int i = 0; i < n; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    return PQ_OK;
+}
+
 extern "C" int32_t pq_abi_sizeof(int32_t code) {
     switch (code) {
         case 0: return (int32_t)sizeof(pq_op);

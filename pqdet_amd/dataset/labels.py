@@ -1,0 +1,77 @@
+"""Label assignment on the host (numpy) -- mirrors the reference ``TrainDataset.create_label`` and the box padding of
+``collate_batch`` (``dataset/train_dataset.py:16-43,109-150``; anchors / strides / IoU threshold defaults from
+``config.py:56-61``).  This is the producer of the 6-tuple ``DetectionModel.forward(x, target)`` consumes; it runs in
+DataLoader workers in the reference and stays a host function here (a device version is the next scope row).
+"""
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ..tools import iou_xywh_numpy
+
+ANCHORS = np.array([(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119), (116, 90), (156, 198), (373, 326)],
+                   dtype=np.float32)
+STRIDES = np.array([8, 16, 32])
+
+
+def create_label(bboxes: Sequence[np.ndarray], output_sizes: np.ndarray, num_classes: int, strides=STRIDES,
+                 anchors=ANCHORS, gt_per_grid: int = 3, anchors_iou_threshold: float = 0.3):
+    """bboxes rows = [x1, y1, x2, y2, class, mixup weight]; output_sizes (3, 2) = (h, w) of the three heads.
+    -> (label_s, label_m, label_l, boxes_s, boxes_m, boxes_l); labels are (h, w, gt_per_grid, 6 + C) float32."""
+    grids = [np.zeros((output_sizes[i][0], output_sizes[i][1], gt_per_grid, 6 + num_classes), dtype=np.float32)
+             for i in range(3)]
+    for gmap in grids:
+        gmap[..., -1] = 1.0                                       # mix-up weight defaults to 1
+    lists: List[List[np.ndarray]] = [[], [], []]
+    uniform = np.full(num_classes, 1.0 / num_classes)
+    for box in bboxes:
+        corners = box[:4]
+        cls_id, mix = int(box[4]), box[5]
+        centre_size = np.concatenate([(corners[2:] + corners[:2]) * 0.5, corners[2:] - corners[:2]], axis=-1)
+        target_prob = np.zeros(num_classes, dtype=np.float64)
+        target_prob[cls_id] = 1.0
+        target_prob = target_prob * (1 - 0.01) + 0.01 * uniform    # label smoothing, delta = 0.01
+        cells = (centre_size[:2][:, None] // strides).astype(np.int32).T          # (3, 2): (x, y) per scale
+        cell_centres = (cells.astype(np.float32) + 0.5) * strides[:, None]
+        anchor_boxes = np.concatenate([np.repeat(cell_centres, 3, axis=0), anchors], axis=-1)
+        overlap = iou_xywh_numpy(centre_size, anchor_boxes)
+        chosen = overlap > anchors_iou_threshold
+        if not chosen.any():
+            chosen[overlap.argmax()] = 1
+        row = np.concatenate([corners, [1.0], target_prob, [mix]], axis=-1)
+        for k in chosen.nonzero()[0]:
+            scale, slot = k // 3, k % 3
+            cx, cy = cells[scale]
+            grids[scale][cy, cx, slot, :] = row
+            lists[scale].append(corners)
+    return (*grids, *lists)
+
+
+def pad_box_lists(per_image: Sequence[Sequence[np.ndarray]]) -> np.ndarray:
+    """zero-pad every image's list to the batch maximum (at least one row) -> (B, M, 4) float32."""
+    m = max(max(len(a) for a in per_image), 1)
+    out = np.zeros((len(per_image), m, 4), dtype=np.float32)
+    for i, a in enumerate(per_image):
+        if len(a):
+            out[i, :len(a)] = np.asarray(a, dtype=np.float32)
+    return out
+
+
+def synthetic_targets(batch: int, size: int, num_classes: int, seed: int = 1, max_boxes: int = 8) -> Tuple[torch.Tensor, ...]:
+    """SURVEY 8(d) synthetic targets: per image n ~ U{1..max_boxes} boxes with w, h in [16, size/2], uniform classes."""
+    rng = np.random.RandomState(seed)
+    hw = np.array([[size // s, size // s] for s in STRIDES])
+    grids, lists = [[], [], []], [[], [], []]
+    for _ in range(batch):
+        n = rng.randint(1, max_boxes + 1)
+        boxes = []
+        for _ in range(n):
+            w, h = rng.uniform(16, size * 0.5, 2)
+            x1, y1 = rng.uniform(0, size - w), rng.uniform(0, size - h)
+            boxes.append(np.array([x1, y1, x1 + w, y1 + h, rng.randint(0, num_classes), 1.0], dtype=np.float32))
+        out = create_label(boxes, hw, num_classes)
+        for i in range(3):
+            grids[i].append(out[i])
+            lists[i].append(out[3 + i])
+    return tuple(torch.from_numpy(np.stack(g, 0)) for g in grids) + tuple(torch.from_numpy(pad_box_lists(l)) for l in lists)

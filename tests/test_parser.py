@@ -81,3 +81,13 @@ def test_state_dict_key_layout():
     assert keys[0] == '0.conv.weight' and '0.bn.running_var' in keys and '0.bn.num_batches_tracked' in keys
     assert len(keys) == 492
     assert '71.conv.bias' in keys
+
+
+def test_product_label_assignment_matches_golden(golden):
+    import numpy as np
+    from pqdet_amd.dataset import labels
+    out = labels.create_label(golden['g8_boxes'], np.array([[16, 16], [8, 8], [4, 4]]), 5)
+    for i in range(3):
+        np.testing.assert_array_equal(out[i], golden['g8_label%d' % i])
+        np.testing.assert_array_equal(np.asarray(out[3 + i], np.float32).reshape(-1, 4), golden['g8_list%d' % i])
+    np.testing.assert_array_equal(labels.pad_box_lists([[], out[3], out[4]]), golden['g8_padded'])
