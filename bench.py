@@ -98,12 +98,29 @@ def profile_kernels(plan, x, tgt, passes=3):
     return acc
 
 
+def log(*a):
+    print('[bench]', *a, file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(batch, size, steps=2):
     """The CPU oracle (oracle/, PyTorch-CPU restatement pinned against the reference's golden vectors) timed on the
     host cores on the same workload shape.  Reported baseline only -- never part of the measured path."""
     from oracle.net import OracleNet
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
+    log('cpu baseline on %d threads (os.cpu_count=%s)' % (threads, os.cpu_count()))
     net = OracleNet(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=4e-4)
@@ -115,6 +132,7 @@ def cpu_baseline(batch, size, steps=2):
         opt.zero_grad()
         net(x, tgt)['loss'].mean().backward()
         opt.step()
+        log('cpu step %d: %.2f s' % (i, time.perf_counter() - t0))
         if i:
             times.append(time.perf_counter() - t0)
     dt = sum(times) / len(times)
@@ -171,9 +189,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log('rank %d/%d: model + batch on %s, warming up' % (rank, world, dev))
     for _ in range(args.warmup):
         step()
     fence()
+    log('timing %d steps' % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -186,6 +206,7 @@ def main():
     model.check_nan(wait=True)
     loss_value = out['loss'].item()
 
+    log('timed region done: %.3f s' % dt)
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
