@@ -87,11 +87,13 @@ typedef struct pq_conv1x1_fwd_args {
     const float* w;      /* [O][I] */
     const float* bias;   /* [O] or NULL */
     float* out;          /* [M][ldo] raw */
-    float* partial;      /* [ceil(M/128)][2][ldp] or NULL */
+    float* partial;      /* [pq_conv1x1_blocks(M, O)][2][ldp] or NULL */
     int32_t M, I, O, ldo, ldp;
     int32_t sub, OH, OW, IH, IW;   /* sub==1: plain; else strided gather of input rows */
 } pq_conv1x1_fwd_args;
 int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream);
+/* row-blocks (partial-sum rows) a GEMM with M rows and N output columns uses: fwd N=O, dgrad sink N=I */
+int32_t pq_conv1x1_blocks(int32_t M, int32_t N);
 
 typedef struct pq_conv1x1_dgrad_args {
     pq_gsrc dy;

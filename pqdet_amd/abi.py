@@ -166,6 +166,7 @@ OP_FIELD = {
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
 SIGNATURES = {
     'pq_conv1x1_fwd': (C.c_int, [C.POINTER(Conv1x1Fwd), C.c_void_p]),
+    'pq_conv1x1_blocks': (i32, [i32, i32]),
     'pq_conv1x1_dgrad': (C.c_int, [C.POINTER(Conv1x1Dgrad), C.c_void_p]),
     'pq_conv1x1_wgrad': (C.c_int, [C.POINTER(Conv1x1Wgrad), C.c_void_p]),
     'pq_conv1x1_wgrad_scratch_bytes': (i64, [i32, i32, i32]),

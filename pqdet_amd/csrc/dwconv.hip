@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
     const int c0 = c4 * 4;
     const bool cok = c4 < p.C4;
     const int OWG = (p.OW + TW - 1) / TW;
-    const long items = (long)p.B * p.OH * OWG;
+    const int items = p.B * p.OH * OWG;
     constexpr int NCOL = (TW - 1) * S + 3;
 
     float4 wk[9];
@@ -49,33 +49,40 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
     const SinkCoef4 sk = sink_coef4(p.sink, c0, p.C);
     float4 s1 = f4zero(), s2 = f4zero();
 
-    for (long it = (long)blockIdx.x * blockDim.y + ty; it < items && cok; it += (long)gridDim.x * blockDim.y) {
+    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int oxg = (int)(it % OWG);
-        const long t2 = it / OWG;
+        const int t2 = it / OWG;
         const int oy = (int)(t2 % p.OH);
         const int b = (int)(t2 / p.OH);
         const int ox0 = oxg * TW;
         float4 acc[TW];
 #pragma unroll
         for (int t = 0; t < TW; ++t) acc[t] = f4zero();
+        // Loads are issued unconditionally at clamped coordinates (a whole window row in flight at once) and masked
+        // afterwards: branching around each load would serialise them behind their own waits.
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * S - 1 + ky;
-            if (iy < 0 || iy >= p.IH) continue;
-            const size_t rowbase = ((size_t)b * p.IH + iy) * p.IW;
+            const bool yok = iy >= 0 && iy < p.IH;
+            const int iyc = min(max(iy, 0), p.IH - 1);
+            const size_t rowbase = ((size_t)b * p.IH + iyc) * p.IW;
+            float4 ra[NCOL], rb[NCOL];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int ixc = min(max(ox0 * S - 1 + j, 0), p.IW - 1);
+                if (GRAD) {
+                    ra[j] = ldg4(p.dy.g + (rowbase + ixc) * p.dy.ldg + c0);
+                    rb[j] = gk.two ? ldg4(p.dy.y + (rowbase + ixc) * p.dy.ldy + c0) : f4zero();
+                } else {
+                    ra[j] = ldg4(p.in.x + (rowbase + ixc) * p.in.ld + c0);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) {
                 const int ix = ox0 * S - 1 + j;
-                float4 v = f4zero();
-                if (ix >= 0 && ix < p.IW) {
-                    if (GRAD) {
-                        float4 g = ldg4(p.dy.g + (rowbase + ix) * p.dy.ldg + c0);
-                        float4 y = gk.two ? ldg4(p.dy.y + (rowbase + ix) * p.dy.ldy + c0) : f4zero();
-                        v = gsrc_apply4(g, y, gk);
-                    } else {
-                        v = src_apply4(ldg4(p.in.x + (rowbase + ix) * p.in.ld + c0), xk);
-                    }
-                }
+                const bool ok = yok && ix >= 0 && ix < p.IW;
+                float4 v = GRAD ? gsrc_apply4(ra[j], rb[j], gk) : src_apply4(ra[j], xk);
+                v = ok ? v : f4zero();
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
                     const int kx = j - t * S;
@@ -108,35 +115,48 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwP p) {
     const int c4 = blockIdx.y * blockDim.x + tx;
     const int c0 = c4 * 4;
     const bool cok = c4 < p.C4;
-    const long items = (long)p.B * p.IH * p.IW;
+    const int items = p.B * p.IH * p.IW;
     float4 wk[9];
     load_w9(p.w, c0, p.C, wk, false);
     const GsrcCoef4 gk = gsrc_coef4(p.dy, c0, p.C);
     const SinkCoef4 sk = sink_coef4(p.sink, c0, p.C);
     float4 s1 = f4zero(), s2 = f4zero();
-    for (long it = (long)blockIdx.x * blockDim.y + ty; it < items && cok; it += (long)gridDim.x * blockDim.y) {
+    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int ix = (int)(it % p.IW);
-        const long t2 = it / p.IW;
+        const int t2 = it / p.IW;
         const int iy = (int)(t2 % p.IH);
         const int b = (int)(t2 / p.IH);
+        // stride 2: input pixel (iy, ix) receives at most 2 x 2 taps.  Tap "a" is output floor((i+1)/2) with kernel
+        // index k = (i+1) & 1, tap "b" (only when k == 0) is the output before it with kernel index 2.
+        static_assert(S == 2, "generic-tap dgrad is written for stride 2");
+        const int oya = (iy + 1) >> 1, kya = (iy + 1) & 1, oxa = (ix + 1) >> 1, kxa = (ix + 1) & 1;
+        const bool ya_ok = oya < p.OH, yb_ok = kya == 0 && oya >= 1;
+        const bool xa_ok = oxa < p.OW, xb_ok = kxa == 0 && oxa >= 1;
+        const int oy_[2] = {min(oya, p.OH - 1), max(oya - 1, 0)};
+        const int ox_[2] = {min(oxa, p.OW - 1), max(oxa - 1, 0)};
+        const bool yv[2] = {ya_ok, yb_ok}, xv[2] = {xa_ok, xb_ok};
+        float4 rg[4], ry[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t r = ((size_t)b * p.OH + oy_[q >> 1]) * p.OW + ox_[q & 1];
+            rg[q] = ldg4(p.dy.g + r * p.dy.ldg + c0);
+            ry[q] = gk.two ? ldg4(p.dy.y + r * p.dy.ldy + c0) : f4zero();
+        }
         float4 acc = f4zero();
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int ty2 = iy + 1 - ky;
-            if (ty2 < 0 || (ty2 % S) != 0) continue;
-            const int oy = ty2 / S;
-            if (oy >= p.OH) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int tx2 = ix + 1 - kx;
-                if (tx2 < 0 || (tx2 % S) != 0) continue;
-                const int ox = tx2 / S;
-                if (ox >= p.OW) continue;
-                const size_t r = ((size_t)b * p.OH + oy) * p.OW + ox;
-                float4 g = ldg4(p.dy.g + r * p.dy.ldg + c0);
-                float4 y = gk.two ? ldg4(p.dy.y + r * p.dy.ldy + c0) : f4zero();
-                acc = f4fma(gsrc_apply4(g, y, gk), wk[ky * 3 + kx], acc);
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = yv[q >> 1] && xv[q & 1];
+            // kernel row: tap a -> kya (0|1), tap b -> 2; same for columns
+            float4 w0, w1, w2;   // the three columns of the selected kernel row
+            if ((q >> 1) == 0) {
+                w0 = kya ? wk[3] : wk[0]; w1 = kya ? wk[4] : wk[1]; w2 = kya ? wk[5] : wk[2];
+            } else {
+                w0 = wk[6]; w1 = wk[7]; w2 = wk[8];
             }
+            const float4 wsel = ((q & 1) == 0) ? (kxa ? w1 : w0) : w2;
+            float4 v = gsrc_apply4(rg[q], ry[q], gk);
+            v = ok ? v : f4zero();
+            acc = f4fma(v, wsel, acc);
         }
         sink_emit4(p.sink, sk, (size_t)it, c0, acc, s1, s2);
     }
@@ -153,40 +173,53 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwP p) {
     const int c0 = c4 * 4;
     const bool cok = c4 < p.C4;
     const int OWG = (p.OW + TW - 1) / TW;
-    const long items = (long)p.B * p.OH * OWG;
+    const int items = p.B * p.OH * OWG;
     constexpr int NCOL = (TW - 1) * S + 3;
     const SrcCoef4 xk = src_coef4(p.in, c0, p.C);
     const GsrcCoef4 gk = gsrc_coef4(p.dy, c0, p.C);
     float4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f4zero();
-    for (long it = (long)blockIdx.x * blockDim.y + ty; it < items && cok; it += (long)gridDim.x * blockDim.y) {
+    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int oxg = (int)(it % OWG);
-        const long t2 = it / OWG;
+        const int t2 = it / OWG;
         const int oy = (int)(t2 % p.OH);
         const int b = (int)(t2 / p.OH);
         const int ox0 = oxg * TW;
         float4 dy[TW];
-        const size_t orow = ((size_t)b * p.OH + oy) * p.OW + ox0;
+        const size_t orow = ((size_t)b * p.OH + oy) * p.OW;
+        {
+            float4 rg[TW], ry[TW];
 #pragma unroll
-        for (int t = 0; t < TW; ++t) {
-            dy[t] = f4zero();
-            if (ox0 + t < p.OW) {
-                float4 g = ldg4(p.dy.g + (orow + t) * p.dy.ldg + c0);
-                float4 y = gk.two ? ldg4(p.dy.y + (orow + t) * p.dy.ldy + c0) : f4zero();
-                dy[t] = gsrc_apply4(g, y, gk);
+            for (int t = 0; t < TW; ++t) {
+                const int oxc = min(ox0 + t, p.OW - 1);
+                rg[t] = ldg4(p.dy.g + (orow + oxc) * p.dy.ldg + c0);
+                ry[t] = gk.two ? ldg4(p.dy.y + (orow + oxc) * p.dy.ldy + c0) : f4zero();
+            }
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const float4 v = gsrc_apply4(rg[t], ry[t], gk);
+                dy[t] = (ox0 + t < p.OW) ? v : f4zero();
             }
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * S - 1 + ky;
-            if (iy < 0 || iy >= p.IH) continue;
-            const size_t rowbase = ((size_t)b * p.IH + iy) * p.IW;
+            const bool yok = iy >= 0 && iy < p.IH;
+            const int iyc = min(max(iy, 0), p.IH - 1);
+            const size_t rowbase = ((size_t)b * p.IH + iyc) * p.IW;
+            float4 rx[NCOL];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int ixc = min(max(ox0 * S - 1 + j, 0), p.IW - 1);
+                rx[j] = ldg4(p.in.x + (rowbase + ixc) * p.in.ld + c0);
+            }
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) {
                 const int ix = ox0 * S - 1 + j;
-                if (ix < 0 || ix >= p.IW) continue;
-                const float4 v = src_apply4(ldg4(p.in.x + (rowbase + ix) * p.in.ld + c0), xk);
+                const bool ok = yok && ix >= 0 && ix < p.IW;
+                float4 v = src_apply4(rx[j], xk);
+                v = ok ? v : f4zero();
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
                     const int kx = j - t * S;
@@ -214,11 +247,20 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwP p) {
     }
 }
 
-__global__ void partial_reduce_kernel(const float* part, int nblk, int n, float* out) {
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += part[(size_t)k * n + j];
-        out[j] = s;
+// out[j] = sum_k part[k*n + j]; block = 64 columns x 16 row lanes (deterministic tree)
+__global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* part, int nblk, int n, float* out) {
+    __shared__ float red[16][65];
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    if (j < n)
+        for (int k = threadIdx.y; k < nblk; k += 16) s += part[(size_t)k * n + j];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && j < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        out[j] = t;
     }
 }
 
@@ -244,31 +286,42 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemP p) {
         for (int j = 0; j < 4; ++j) e[j] = (c0 + j < p.O) ? p.w[(size_t)(c0 + j) * CI * 9 + t] : 0.f;
         wk[t] = make_float4(e[0], e[1], e[2], e[3]);
     }
-    const long items = (long)p.B * p.OH * p.OW;
+    const int items = p.B * p.OH * p.OW;
     const size_t plane = (size_t)p.IH * p.IW;
     float4 s1 = f4zero(), s2 = f4zero();
-    for (long it = (long)blockIdx.x * blockDim.y + ty; it < items && cok; it += (long)gridDim.x * blockDim.y) {
+    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int ox = (int)(it % p.OW);
-        const long t2 = it / p.OW;
+        const int t2 = it / p.OW;
         const int oy = (int)(t2 % p.OH);
         const int b = (int)(t2 / p.OH);
         float4 acc = f4zero();
+        float px[CI * 9];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) {
             const float* pl = p.img + ((size_t)b * CI + ci) * plane;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy * p.S - 1 + ky;
-                if (iy < 0 || iy >= p.IH) continue;
+                const int iyc = min(max(oy * p.S - 1 + ky, 0), p.IH - 1);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox * p.S - 1 + kx;
-                    if (ix < 0 || ix >= p.IW) continue;
-                    const float v = pl[(size_t)iy * p.IW + ix];
-                    acc = f4fma(make_float4(v, v, v, v), wk[ci * 9 + ky * 3 + kx], acc);
+                    const int ixc = min(max(ox * p.S - 1 + kx, 0), p.IW - 1);
+                    px[ci * 9 + ky * 3 + kx] = pl[(size_t)iyc * p.IW + ixc];      // unconditional, masked below
                 }
             }
         }
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * p.S - 1 + ky;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * p.S - 1 + kx;
+                    const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                    const float v = ok ? px[ci * 9 + ky * 3 + kx] : 0.f;
+                    acc = f4fma(make_float4(v, v, v, v), wk[ci * 9 + ky * 3 + kx], acc);
+                }
+            }
         stg4(p.out + (size_t)it * p.ldo + c0, acc);
         s1 = f4add(s1, acc);
         s2 = f4fma(acc, acc, s2);
@@ -286,32 +339,43 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemP p) {
     float4 acc[CI * 9];
 #pragma unroll
     for (int t = 0; t < CI * 9; ++t) acc[t] = f4zero();
-    const long items = (long)p.B * p.OH * p.OW;
+    const int items = p.B * p.OH * p.OW;
     const size_t plane = (size_t)p.IH * p.IW;
-    for (long it = (long)blockIdx.x * blockDim.y + ty; it < items && cok; it += (long)gridDim.x * blockDim.y) {
+    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int ox = (int)(it % p.OW);
-        const long t2 = it / p.OW;
+        const int t2 = it / p.OW;
         const int oy = (int)(t2 % p.OH);
         const int b = (int)(t2 / p.OH);
         float4 g = ldg4(p.dy.g + (size_t)it * p.dy.ldg + c0);
         float4 y = gk.two ? ldg4(p.dy.y + (size_t)it * p.dy.ldy + c0) : f4zero();
         const float4 dy = gsrc_apply4(g, y, gk);
+        float px[CI * 9];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) {
             const float* pl = p.img + ((size_t)b * CI + ci) * plane;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy * p.S - 1 + ky;
-                if (iy < 0 || iy >= p.IH) continue;
+                const int iyc = min(max(oy * p.S - 1 + ky, 0), p.IH - 1);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox * p.S - 1 + kx;
-                    if (ix < 0 || ix >= p.IW) continue;
-                    const float v = pl[(size_t)iy * p.IW + ix];
-                    acc[ci * 9 + ky * 3 + kx] = f4fma(dy, make_float4(v, v, v, v), acc[ci * 9 + ky * 3 + kx]);
+                    const int ixc = min(max(ox * p.S - 1 + kx, 0), p.IW - 1);
+                    px[ci * 9 + ky * 3 + kx] = pl[(size_t)iyc * p.IW + ixc];
                 }
             }
         }
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * p.S - 1 + ky;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * p.S - 1 + kx;
+                    const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                    const float v = ok ? px[ci * 9 + ky * 3 + kx] : 0.f;
+                    acc[ci * 9 + ky * 3 + kx] = f4fma(dy, make_float4(v, v, v, v), acc[ci * 9 + ky * 3 + kx]);
+                }
+            }
     }
     float4* l4 = reinterpret_cast<float4*>(lds);
 #pragma unroll
@@ -416,7 +480,7 @@ extern "C" int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream) {
     else hipLaunchKernelGGL((dw_wgrad_kernel<2, 2>), grid, blk, sh, st, p);
     PQ_CHECK_LAUNCH();
     const int n = a->C * 9;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 63) / 64), dim3(64, 16), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -465,7 +529,7 @@ extern "C" int pq_stem3x3_wgrad(const pq_stem3x3_wgrad_args* a, void* stream) {
     hipLaunchKernelGGL((stem_wgrad_kernel<3>), grid, blk, (size_t)g.cx * g.py * 4 * sizeof(float), st, p);
     PQ_CHECK_LAUNCH();
     const int n = a->O * a->CI * 9;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 63) / 64), dim3(64, 16), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

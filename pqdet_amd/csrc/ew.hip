@@ -6,14 +6,15 @@ namespace pq {
 
 // ------------------------------------------------------------------------------------------------ BN finalize
 // One block of 256 threads = 16 channels x 16 row-lanes; partial is [nblk][2][ldp].
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize_args a) {
-    __shared__ double sh[2][16][17];
+constexpr int BN_RL = 64;    // row lanes per block (block = 16 channels x BN_RL)
+__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize_args a) {
+    __shared__ double sh[2][16][BN_RL + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     if (a.train) {
         double s1 = 0.0, s2 = 0.0;
         if (c < a.C)
-            for (int k = rl; k < a.nblk; k += 16) {
+            for (int k = rl; k < a.nblk; k += BN_RL) {
                 const float* row = a.partial + (size_t)k * 2 * a.ldp;
                 s1 += (double)row[c];
                 s2 += (double)row[a.ldp + c];
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize
         __syncthreads();
         if (rl == 0 && c < a.C) {
             double t1 = 0.0, t2 = 0.0;
-            for (int k = 0; k < 16; ++k) { t1 += sh[0][cl][k]; t2 += sh[1][cl][k]; }
+            for (int k = 0; k < BN_RL; ++k) { t1 += sh[0][cl][k]; t2 += sh[1][cl][k]; }
             const double n = (double)a.count;
             const double mean = t1 / n;
             double var = t2 / n - mean * mean;
@@ -52,13 +53,13 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize_args a) {
-    __shared__ double sh[2][16][17];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize_args a) {
+    __shared__ double sh[2][16][BN_RL + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < a.C)
-        for (int k = rl; k < a.nblk; k += 16) {
+        for (int k = rl; k < a.nblk; k += BN_RL) {
             const float* row = a.partial + (size_t)k * 2 * a.ldp;
             s1 += (double)row[c];
             s2 += (double)row[a.ldp + c];
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize
     __syncthreads();
     if (rl == 0 && c < a.C) {
         double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < 16; ++k) { t1 += sh[0][cl][k]; t2 += sh[1][cl][k]; }
+        for (int k = 0; k < BN_RL; ++k) { t1 += sh[0][cl][k]; t2 += sh[1][cl][k]; }
         const float inv = a.invstd[c];
         const float pc = a.gamma[c] * inv;
         a.dbeta[c] = (float)t1;
@@ -94,15 +95,15 @@ __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
     const SrcCoef4 ka = src_coef4(a.a, c0, a.C);
     const SrcCoef4 kb = src_coef4(a.b, c0, a.C);
     const bool two = a.b.x != nullptr;
-    const long rows = (long)a.B * a.H * a.W;
+    const int rows = a.B * a.H * a.W;
     const int SH = a.H / a.up, SW = a.W / a.up;
-    for (long r = (long)blockIdx.x * blockDim.y + threadIdx.y; r < rows; r += (long)gridDim.x * blockDim.y) {
+    for (int r = blockIdx.x * blockDim.y + threadIdx.y; r < rows; r += gridDim.x * blockDim.y) {
         size_t sr = (size_t)r;
         if (a.up > 1) {
             const int x = (int)(r % a.W);
-            const long t2 = r / a.W;
+            const int t2 = r / a.W;
             const int y = (int)(t2 % a.H);
-            const long b = t2 / a.H;
+            const int b = t2 / a.H;
             sr = ((size_t)b * SH + y / a.up) * SW + x / a.up;
         }
         float4 v = src_apply4(ldg4(a.a.x + sr * a.a.ld + c0), ka);
@@ -119,18 +120,18 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     const int c4 = blockIdx.y * blockDim.x + threadIdx.x, c0 = c4 * 4;
     const bool cok = c4 < p.C4;
     const SinkCoef4 sk = sink_coef4(a.dx, c0, a.C);
-    const long rows = (long)a.B * a.H * a.W;
+    const int rows = a.B * a.H * a.W;
     const int OH = a.H * a.up, OW = a.W * a.up;
     float4 s1 = f4zero(), s2 = f4zero();
-    for (long r = (long)blockIdx.x * blockDim.y + threadIdx.y; r < rows && cok; r += (long)gridDim.x * blockDim.y) {
+    for (int r = blockIdx.x * blockDim.y + threadIdx.y; r < rows && cok; r += gridDim.x * blockDim.y) {
         float4 dz = f4zero();
         if (a.up == 1) {
             dz = ldg4(a.gout + (size_t)r * a.ldgo + a.coff + c0);
         } else {
             const int x = (int)(r % a.W);
-            const long t2 = r / a.W;
+            const int t2 = r / a.W;
             const int y = (int)(t2 % a.H);
-            const long b = t2 / a.H;
+            const int b = t2 / a.H;
             for (int dy = 0; dy < a.up; ++dy)
                 for (int dx = 0; dx < a.up; ++dx) {
                     const size_t orow = ((size_t)b * OH + (size_t)y * a.up + dy) * OW + (size_t)x * a.up + dx;
@@ -197,7 +198,7 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
     PQ_CHECK_ARG(a->C > 0, "empty");
     PQ_CHECK_ARG(!a->train || (a->partial && a->nblk > 0 && a->count > 0.f), "train mode needs partial sums");
     PQ_CHECK_ARG(a->train || (a->running_mean && a->running_var), "eval mode needs running statistics");
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + 15) / 16), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + 15) / 16), dim3(16 * BN_RL), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -205,7 +206,7 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
 extern "C" int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->partial && a->gamma && a->invstd && a->dgamma && a->dbeta && a->p && a->q && a->r, "null pointer");
     PQ_CHECK_ARG(a->C > 0 && a->nblk > 0 && a->count > 0.f, "empty");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->C + 15) / 16), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->C + 15) / 16), dim3(16 * BN_RL), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

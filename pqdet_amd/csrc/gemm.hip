@@ -76,79 +76,90 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     const int br0 = BKN ? (t / BNQ) : (t >> 3);
     const bool bvec = BKN ? ((N & 3) == 0 && (p.ldb & 3) == 0) : ((p.ldb & 3) == 0);
 
-    float4 ra[AI], ra1[AI], rb[BI];
-    float4 rc0, rc1, rc2, rc3;
+    // Register staging sets (PF of them): the global loads of k-tile t+PF are in flight while tile t is multiplied.
+    struct RegSet { float4 a[AI], a1[AI], b[BI], c0, c1, c2, c3; };
     const int Kpad = (K + 3) & ~3;
 
-    auto load_tiles = [&](int k0) {
+    // All loads are unconditional at clamped (always valid) addresses -- masking happens when the tile is written to
+    // LDS -- so the compiler can issue a whole tile's loads back to back.
+    auto load_tiles = [&](int k0, RegSet& r) {
         const int ka = k0 + 4 * ac4;
-        const bool kin = ka < Kpad;
+        if (ka < Kpad) {       // one branch around the whole batch (columns past K contribute nothing and are skipped)
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            ra[i] = (avalid[i] && kin) ? ldg4(arow0[i] + ka) : f4zero();
-            if (AMODE == 2) ra1[i] = (avalid[i] && kin) ? ldg4(arow1[i] + ka) : f4zero();
-        }
-        if (AMODE == 1) {
-            rc0 = (kin && p.c0) ? ldg4(p.c0 + ka) : f4zero();
-            rc1 = (kin && p.c0) ? ldg4(p.c1 + ka) : f4zero();
-        } else if (AMODE == 2) {
-            rc0 = kin ? ldg4(p.c0 + ka) : f4zero();
-            rc1 = kin ? ldg4(p.c1 + ka) : f4zero();
-            rc2 = kin ? ldg4(p.c2 + ka) : f4zero();
-            rc3 = kin ? ldg4(p.c3 + ka) : f4zero();
+            for (int i = 0; i < AI; ++i) {
+                r.a[i] = ldg4(arow0[i] + ka);
+                if (AMODE == 2) r.a1[i] = ldg4(arow1[i] + ka);
+            }
+            if (AMODE == 1) {
+                if (p.c0) { r.c0 = ldg4(p.c0 + ka); r.c1 = ldg4(p.c1 + ka); }
+            } else if (AMODE == 2) {
+                r.c0 = ldg4(p.c0 + ka); r.c1 = ldg4(p.c1 + ka); r.c2 = ldg4(p.c2 + ka); r.c3 = ldg4(p.c3 + ka);
+            }
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             if (!BKN) {
-                int n = n0 + br0 + 32 * i, kb = k0 + 4 * bc4;
-                const float* src = p.b + (size_t)n * p.ldb + kb;
-                if (n < N && kb < K) {
-                    if (bvec && kb + 3 < K) rb[i] = ldg4(src);
-                    else rb[i] = make_float4(src[0], kb + 1 < K ? src[1] : 0.f, kb + 2 < K ? src[2] : 0.f, kb + 3 < K ? src[3] : 0.f);
-                } else rb[i] = f4zero();
+                const int n = min(n0 + br0 + 32 * i, N - 1), kb = k0 + 4 * bc4;
+                if (bvec) {     // rows >= N / k >= K read real (finite) weights: they only meet zeroed A or unstored C
+                    r.b[i] = ldg4(p.b + (size_t)n * p.ldb + min(kb, Kpad - 4));
+                } else {
+                    const float* src = p.b + (size_t)n * p.ldb;
+                    r.b[i] = make_float4(kb < K ? src[kb] : 0.f, kb + 1 < K ? src[kb + 1] : 0.f, kb + 2 < K ? src[kb + 2] : 0.f,
+                                         kb + 3 < K ? src[kb + 3] : 0.f);
+                }
             } else {
-                int k = k0 + br0 + BKROWS * i, n = n0 + 4 * bc4;
-                const float* src = p.b + (size_t)k * p.ldb + n;
-                if (k < K && n < N) {
-                    if (bvec) rb[i] = ldg4(src);
-                    else rb[i] = make_float4(src[0], n + 1 < N ? src[1] : 0.f, n + 2 < N ? src[2] : 0.f, n + 3 < N ? src[3] : 0.f);
-                } else rb[i] = f4zero();
+                const int k = min(k0 + br0 + BKROWS * i, K - 1), n = n0 + 4 * bc4;
+                if (bvec) {
+                    r.b[i] = ldg4(p.b + (size_t)k * p.ldb + min(n, N - 4));
+                } else {
+                    const float* src = p.b + (size_t)k * p.ldb;
+                    r.b[i] = make_float4(n < N ? src[n] : 0.f, n + 1 < N ? src[n + 1] : 0.f, n + 2 < N ? src[n + 2] : 0.f,
+                                         n + 3 < N ? src[n + 3] : 0.f);
+                }
             }
         }
     };
 
-    auto store_tiles = [&](int k0) {
+    auto store_tiles = [&](int k0, const RegSet& r) {
         const int ka = k0 + 4 * ac4;
-        float c0[4] = {rc0.x, rc0.y, rc0.z, rc0.w}, c1[4] = {rc1.x, rc1.y, rc1.z, rc1.w};
-        float c2[4] = {rc2.x, rc2.y, rc2.z, rc2.w}, c3[4] = {rc3.x, rc3.y, rc3.z, rc3.w};
+        float c0[4] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w}, c1[4] = {r.c1.x, r.c1.y, r.c1.z, r.c1.w};
+        float c2[4] = {r.c2.x, r.c2.y, r.c2.z, r.c2.w}, c3[4] = {r.c3.x, r.c3.y, r.c3.z, r.c3.w};
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            float v[4] = {r.a[i].x, r.a[i].y, r.a[i].z, r.a[i].w};
             float y[4] = {0.f, 0.f, 0.f, 0.f};
-            if (AMODE == 2) { y[0] = ra1[i].x; y[1] = ra1[i].y; y[2] = ra1[i].z; y[3] = ra1[i].w; }
+            if (AMODE == 2) { y[0] = r.a1[i].x; y[1] = r.a1[i].y; y[2] = r.a1[i].z; y[3] = r.a1[i].w; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float r = v[j];
+                float q = v[j];
                 if (AMODE == 1) {
-                    if (p.c0 != nullptr) r = fmaf(c0[j], r, c1[j]);
-                    r = act_fwd(r, p.act);
+                    if (p.c0 != nullptr) q = fmaf(c0[j], q, c1[j]);
+                    q = act_fwd(q, p.act);
                 } else if (AMODE == 2) {
-                    r = fmaf(c0[j], r, fmaf(c1[j], y[j] - c2[j], c3[j]));
+                    q = fmaf(c0[j], q, fmaf(c1[j], y[j] - c2[j], c3[j]));
                 }
-                v[j] = (avalid[i] && ka + j < K) ? r : 0.f;
+                v[j] = (avalid[i] && ka + j < K) ? q : 0.f;
             }
             *reinterpret_cast<float4*>(&As[(ar0 + 32 * i) * LDT + 4 * ac4]) = make_float4(v[0], v[1], v[2], v[3]);
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             if (!BKN) {
-                *reinterpret_cast<float4*>(&Bs[(br0 + 32 * i) * LDT + 4 * bc4]) = rb[i];
+                // a clamped k (tile beyond K) holds duplicates of real weights; the matching A columns are zero
+                *reinterpret_cast<float4*>(&Bs[(br0 + 32 * i) * LDT + 4 * bc4]) = r.b[i];
             } else {
-                int kr = br0 + BKROWS * i;
-                Bs[(4 * bc4 + 0) * LDT + kr] = rb[i].x;
-                Bs[(4 * bc4 + 1) * LDT + kr] = rb[i].y;
-                Bs[(4 * bc4 + 2) * LDT + kr] = rb[i].z;
-                Bs[(4 * bc4 + 3) * LDT + kr] = rb[i].w;
+                const int kr = br0 + BKROWS * i;
+                const bool kok = k0 + kr < K;
+                const int n = n0 + 4 * bc4;
+                // B[k][n] tiles: a clamped n (n > N-4) would alias other columns -> mask explicitly
+                float e[4] = {r.b[i].x, r.b[i].y, r.b[i].z, r.b[i].w};
+                if (bvec && n > N - 4) {
+                    const int sh = n - (N - 4);      // loaded from column N-4: shift the valid ones down
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = (j + sh < 4) ? e[(j + sh) & 3] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(4 * bc4 + j) * LDT + kr] = (kok && n + j < N) ? e[j] : 0.f;
             }
         }
     };
@@ -161,16 +172,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    rc0 = rc1 = rc2 = rc3 = f4zero();
-    // AMODE 2 with y == NULL never reaches this kernel (host dispatches AMODE 0 instead).
-    const int nk = (K + BK - 1) / BK;
-    load_tiles(0);
     const int lrow = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
-        store_tiles(kt * BK);
-        __syncthreads();
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             float4 af[TI], bf[TJ];
@@ -189,6 +192,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                     acc[i][j] = mfma32(af[i].z, bf[j].z, acc[i][j]);
                     acc[i][j] = mfma32(af[i].w, bf[j].w, acc[i][j]);
                 }
+        }
+    };
+
+    // AMODE 2 with y == NULL never reaches this kernel (host dispatches AMODE 0 instead).
+    const int nk = (K + BK - 1) / BK;
+    constexpr int PF = (TI * TJ <= 2 && AMODE != 2) ? 2 : 1;   // short MFMA phases: prefetch two tiles ahead (when registers allow)
+    RegSet r0, r1;
+    r0.c0 = r0.c1 = r0.c2 = r0.c3 = f4zero();
+    r1.c0 = r1.c1 = r1.c2 = r1.c3 = f4zero();
+    load_tiles(0, r0);
+    if (PF == 2 && nk > 1) load_tiles(BK, r1);
+    for (int kt = 0; kt < nk; kt += PF) {
+        __syncthreads();
+        store_tiles(kt * BK, r0);
+        __syncthreads();
+        if (kt + PF < nk) load_tiles((kt + PF) * BK, r0);
+        compute();
+        if (PF == 2 && kt + 1 < nk) {
+            __syncthreads();
+            store_tiles((kt + 1) * BK, r1);
+            __syncthreads();
+            if (kt + 3 < nk) load_tiles((kt + 3) * BK, r1);
+            compute();
         }
     }
 
@@ -418,13 +444,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTP p) {
     }
 }
 
-// out[j] = sum_s slab[s*stride + j]
-__global__ void slab_reduce_kernel(const float* slab, size_t stride, int splits, float* out0, int n0, float* out1, int n1) {
+// out[j] = sum_s slab[s*stride + j]; block = 64 columns x 16 split lanes
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* slab, size_t stride, int splits, float* out0, int n0, float* out1, int n1) {
+    __shared__ float red[16][65];
     const int n = n0 + n1;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(size_t)k * stride + j];
-        if (j < n0) out0[j] = s; else out1[j - n0] = s;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    if (j < n)
+        for (int k = threadIdx.y; k < splits; k += 16) s += slab[(size_t)k * stride + j];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && j < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        if (j < n0) out0[j] = t; else out1[j - n0] = t;
     }
 }
 
@@ -433,21 +467,37 @@ __global__ void slab_reduce_kernel(const float* slab, size_t stride, int splits,
 using namespace pq;
 
 // ------------------------------------------------------------------------------------------------ host dispatch
+// pick the block tile: prefer big tiles (operand reuse) but keep >= ~2 blocks per CU and little padding waste
+struct TileCand { int bm, bn; float bonus; };
+static const TileCand kTiles[4] = {{128, 128, 1.00f}, {128, 64, 0.94f}, {64, 64, 0.86f}, {128, 32, 0.84f}};
+static int pick_tile(int M, int N) {
+    int best = 0;
+    float best_score = -1.f;
+    for (int c = 0; c < 4; ++c) {
+        const long gm = (M + kTiles[c].bm - 1) / kTiles[c].bm, gn = (N + kTiles[c].bn - 1) / kTiles[c].bn;
+        const float eff = (float)((double)M * N / ((double)gm * gn * kTiles[c].bm * kTiles[c].bn));
+        const float fill = gm * gn >= 512 ? 1.f : (float)(gm * gn) / 512.f;
+        const float score = eff * fill * kTiles[c].bonus;
+        if (score > best_score) { best_score = score; best = c; }
+    }
+    return best;
+}
+extern "C" int32_t pq_conv1x1_blocks(int32_t M, int32_t N) {
+    const int c = pick_tile(M, N);
+    return (M + kTiles[c].bm - 1) / kTiles[c].bm;
+}
+
 template <int AMODE, bool BKN, int EMODE>
 static void launch_nt(const GemmP& p, hipStream_t st) {
-    const int N = p.N;
-    auto cost = [&](int bn, float pen) { return (float)(((N + bn - 1) / bn) * bn) * pen; };
-    const float c128 = cost(128, 1.0f), c64 = cost(64, 1.04f), c32 = cost(32, 1.10f);
+    const int best = pick_tile(p.M, p.N);
     dim3 blk(256);
-    if (c128 <= c64 && c128 <= c32) {
-        dim3 grid((N + 127) / 128, (p.M + 127) / 128);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, AMODE, BKN, EMODE>), grid, blk, 0, st, p);
-    } else if (c64 <= c32) {
-        dim3 grid((N + 63) / 64, (p.M + 127) / 128);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 64, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p);
-    } else {
-        dim3 grid((N + 31) / 32, (p.M + 127) / 128);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p);
+    const int bm = kTiles[best].bm, bn = kTiles[best].bn;
+    dim3 grid((p.N + bn - 1) / bn, (p.M + bm - 1) / bm);
+    switch (best) {
+        case 0: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, AMODE, BKN, EMODE>), grid, blk, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 64, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p); break;
     }
 }
 
@@ -495,7 +545,7 @@ static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, 
     big = (O >= 96 && I >= 96);
     const int b = big ? 128 : 64;
     tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
-    int want = (1024 + tiles - 1) / tiles;
+    int want = (512 + tiles - 1) / tiles;
     int maxs = (M + 255) / 256;
     splits = want < 1 ? 1 : (want > maxs ? maxs : want);
     if (splits < 1) splits = 1;
@@ -525,8 +575,8 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
     else hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
     const int n0 = a->O * a->I, n1 = a->dbias ? a->O : 0;
-    int rb = (n0 + n1 + 255) / 256; if (rb > 2048) rb = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)a->scratch, p.slab_stride, splits,
+    const int rb = (n0 + n1 + 63) / 64;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(64, 16), 0, st, (const float*)a->scratch, p.slab_stride, splits,
                        a->dw, n0, a->dbias, n1);
     PQ_CHECK_LAUNCH();
     return PQ_OK;

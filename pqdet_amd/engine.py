@@ -272,7 +272,7 @@ class Plan:
                 else:
                     src = T[resolve(i - 1, i)]
                     if k == 1 and groups == 1:
-                        nblk = (rows + 127) // 128
+                        nblk = l.pq_conv1x1_blocks(rows, Cout)
                         self._deferred.append(('c1_fwd', i, out, nblk, src, s))
                     elif k == 3 and groups == Cin == Cout and conv.padding[0] == 1:
                         nblk = l.pq_dw3x3_blocks(B, OH, OW, Cout)
@@ -480,7 +480,7 @@ class Plan:
                             idx = self._op(self.bwd, abi.OP_CONV1X1_WGRAD, a)
                             wg_ops.append((idx, 'c1w'))
                             if src.needs_grad:
-                                d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), self._sink(src, (src.rows + 127) // 128), out.rows,
+                                d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), self._sink(src, l.pq_conv1x1_blocks(src.rows, src.C)), out.rows,
                                                      src.C, out.C)
                                 self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
                         else:

@@ -44,7 +44,7 @@ for tag, arr, n in (('fwd', plan.fwd_arr, len(plan.fwd)), ('bwd', plan.bwd_arr, 
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print('total device ms (fwd+bwd): %.3f' % tot)
-for r in rows[:40]:
+for r in rows[:int(os.environ.get('TOPN', '40'))]:
     ms_, tag, k, name, desc, fl, by = r
     print('%8.3f ms  %s#%-3d %-38s %-34s %7.1f TF/s %8.1f GB/s' % (ms_, tag, k, name, desc, fl / ms_ / 1e9 if ms_ > 0 else 0, by / ms_ / 1e6 if ms_ > 0 else 0))
 agg = {}

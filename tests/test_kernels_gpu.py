@@ -86,7 +86,7 @@ def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
     want = xin @ w.t() + (b if bias else 0)
     ldo = (O + 3) // 4 * 4 + 4
     out = torch.full((M, ldo), float('nan'), device=DEV)
-    nblk = (M + 127) // 128
+    nblk = abi.lib().pq_conv1x1_blocks(M, O)
     ldp = (O + 15) // 16 * 16
     partial = torch.zeros(nblk * 2 * ldp, device=DEV) if stats else None
     xd, wd = x.to(DEV), w.to(DEV)
@@ -176,7 +176,7 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
     youtd[:, :O] = yout.to(DEV)
     wd, yind = w.to(DEV), yin.to(DEV)
     gdst = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
-    nblk = (M + 127) // 128
+    nblk = abi.lib().pq_conv1x1_blocks(M, I)
     ldp = (I + 15) // 16 * 16
     partial = torch.zeros(nblk * 2 * ldp, device=DEV)
     vecs = [chan_vec(v) for v in ((p, q, mu, r) if two else ())]
