@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpqdet_hip.so')
+LIB_PATH = os.environ.get('PQDET_HIP_LIB') or os.path.join(_HERE, 'lib', 'libpqdet_hip.so')   # env: perf experiments only
 
 c_fp = C.c_void_p          # device float* (raw address)
 i32 = C.c_int32

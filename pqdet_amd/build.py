@@ -39,18 +39,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, defines=(), tag: str = '') -> str:
+    """defines/tag: build an ablation variant next to the real library (perf experiments only)."""
+    global LIB
     os.makedirs(OUT_DIR, exist_ok=True)
+    lib = LIB if not tag else LIB.replace('.so', '_%s.so' % tag)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'pqdet_hip.h')]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
-        o = os.path.join(OUT_DIR, src.replace('.hip', '.o'))
+        o = os.path.join(OUT_DIR, src.replace('.hip', (tag and '_' + tag) + '.o'))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, '-c', s, '-o', o] + COMMON + extra)
+            jobs.append([hipcc, '-c', s, '-o', o] + COMMON + extra + ['-D' + d for d in defines])
 
     def run(cmd):
         if verbose:
@@ -60,10 +63,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs)
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', lib] + objs)
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith('-D')]
+    tags = [a[6:] for a in sys.argv[1:] if a.startswith('--tag=')]
+    print(build(force='--force' in sys.argv, defines=defs, tag=tags[0] if tags else ''))

@@ -12,38 +12,45 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- activations (reference model/parser.py:106-112) -------------------------------------------------------
-__device__ __forceinline__ float act_fwd(float u, int act) {
-    switch (act) {
-        case PQ_ACT_RELU: return fmaxf(u, 0.f);
-        case PQ_ACT_RELU6: return fminf(fmaxf(u, 0.f), 6.f);
-        case PQ_ACT_LEAKY: return u > 0.f ? u : 0.1f * u;
-        case PQ_ACT_LOGISTIC: return 1.f / (1.f + __expf(-u));
-        case PQ_ACT_TANH: return tanhf(u);
-        default: return u;
-    }
+// linear / relu / relu6 / leaky(0.1) are one branch-free family  act(u) = min(max(u,0) + slope*min(u,0), hi);
+// logistic / tanh (never used between layers by the shipped cfgs) take a uniform slow branch.
+struct ActParam { float slope, hi; int special; int code; };
+__host__ __device__ __forceinline__ ActParam act_param(int act) {
+    ActParam a;
+    a.code = act;
+    a.special = (act == PQ_ACT_LOGISTIC || act == PQ_ACT_TANH) ? 1 : 0;
+    a.slope = (act == PQ_ACT_LINEAR) ? 1.f : (act == PQ_ACT_LEAKY ? 0.1f : 0.f);
+    a.hi = (act == PQ_ACT_RELU6) ? 6.f : __builtin_huge_valf();
+    return a;
+}
+__device__ __forceinline__ float act_fwd_slow(float u, int act) {
+    return act == PQ_ACT_LOGISTIC ? 1.f / (1.f + __expf(-u)) : tanhf(u);
+}
+__device__ __forceinline__ float act_bwd_slow(float u, int act) {
+    if (act == PQ_ACT_LOGISTIC) { float s = 1.f / (1.f + __expf(-u)); return s * (1.f - s); }
+    float t = tanhf(u);
+    return 1.f - t * t;
+}
+// piecewise-linear family only (callers reject logistic/tanh on virtual operands at the host)
+__device__ __forceinline__ float act_fwd(float u, const ActParam& a) {
+    return fminf(fmaf(a.slope, fminf(u, 0.f), fmaxf(u, 0.f)), a.hi);
 }
 // derivative w.r.t. the pre-activation u (ATen: threshold_backward / hardtanh_backward use strict bounds)
-__device__ __forceinline__ float act_bwd(float u, int act) {
-    switch (act) {
-        case PQ_ACT_RELU: return u > 0.f ? 1.f : 0.f;
-        case PQ_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
-        case PQ_ACT_LEAKY: return u > 0.f ? 1.f : 0.1f;
-        case PQ_ACT_LOGISTIC: { float s = 1.f / (1.f + __expf(-u)); return s * (1.f - s); }
-        case PQ_ACT_TANH: { float t = tanhf(u); return 1.f - t * t; }
-        default: return 1.f;
-    }
+__device__ __forceinline__ float act_bwd(float u, const ActParam& a) {
+    return (u > 0.f ? 1.f : a.slope) * (u < a.hi ? 1.f : 0.f);
 }
+inline bool act_is_special(int act) { return act == PQ_ACT_LOGISTIC || act == PQ_ACT_TANH; }
 
 // ---- operand loaders -----------------------------------------------------------------------------------------
 // Per-thread cached coefficient pack for 4 consecutive channels of a pq_src.
 struct SrcCoef4 {
     float a[4], b[4];
-    int act;
+    ActParam act;
     bool affine;
 };
 __device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C) {
     SrcCoef4 k;
-    k.act = s.act;
+    k.act = act_param(s.act);
     k.affine = s.scale != nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -57,10 +64,7 @@ __device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C) {
 __device__ __forceinline__ float4 src_apply4(float4 v, const SrcCoef4& k) {
     float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float u = k.affine ? fmaf(k.a[j], r[j], k.b[j]) : r[j];
-        r[j] = act_fwd(u, k.act);
-    }
+    for (int j = 0; j < 4; ++j) r[j] = act_fwd(fmaf(k.a[j], r[j], k.b[j]), k.act);     // (a, b) default to (1, 0)
     return make_float4(r[0], r[1], r[2], r[3]);
 }
 
@@ -102,13 +106,13 @@ __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
 struct SinkCoef4 {
     float a[4], b[4], mean[4], inv[4];
     bool affine, stats;
-    int act;
+    ActParam act;
 };
 __device__ __forceinline__ SinkCoef4 sink_coef4(const pq_gsink& s, int c0, int C) {
     SinkCoef4 k;
     k.affine = s.scale != nullptr;
     k.stats = s.mean != nullptr && s.partial != nullptr;
-    k.act = s.act;
+    k.act = act_param(s.act);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int c = c0 + j;
@@ -125,7 +129,7 @@ __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k
                                            float4& s1, float4& s2) {
     float* gp = s.g + row * (size_t)s.ldg + c0;
     if (s.accumulate) dz = f4add(dz, ldg4(gp));
-    if (s.finalize && (k.act != PQ_ACT_LINEAR || k.stats)) {
+    if (s.finalize && (k.act.code != PQ_ACT_LINEAR || k.stats)) {
         float4 y4 = ldg4(s.y + row * (size_t)s.ldy + c0);
         float d[4] = {dz.x, dz.y, dz.z, dz.w}, y[4] = {y4.x, y4.y, y4.z, y4.w};
         float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t2[4] = {s2.x, s2.y, s2.z, s2.w};

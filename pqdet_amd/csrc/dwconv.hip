@@ -419,6 +419,7 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->in.x && a->w && a->out, "null pointer");
     PQ_CHECK_ARG(check_dw_common(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need C%4==0, stride 1|2, pad 1)");
     PQ_CHECK_ARG((a->in.ld & 3) == 0 && (a->ldo & 3) == 0, "pitches must be multiples of 4");
+    if (act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     DwP p{};
     p.in = a->in; p.w = a->w; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;
@@ -436,6 +437,7 @@ extern "C" int pq_dw3x3_dgrad(const pq_dw3x3_dgrad_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->dy.g && a->w && a->dx.g, "null pointer");
     PQ_CHECK_ARG(check_dw_common(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need C%4==0, stride 1|2, pad 1)");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    if (act_is_special(a->dx.act)) { pq_set_error("pq_dw3x3_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }
     DwP p{};
     p.dy = a->dy; p.w = a->w; p.sink = a->dx;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;

@@ -217,6 +217,7 @@ extern "C" int pq_copy_fwd(const pq_copy_args* a, void* stream) {
     PQ_CHECK_ARG(a->C % 4 == 0 && a->coff % 4 == 0 && a->ldo % 4 == 0 && a->a.ld % 4 == 0, "channels / offsets / pitches must be multiples of 4");
     PQ_CHECK_ARG(a->H % a->up == 0 && a->W % a->up == 0, "output size must be a multiple of the upsample factor");
     PQ_CHECK_ARG(!(a->b.x && a->up != 1), "second addend needs up==1");
+    if (act_is_special(a->a.act) || (a->b.x && act_is_special(a->b.act))) { pq_set_error("pq_copy_fwd: logistic/tanh operands are not supported yet"); return PQ_EUNSUPPORTED; }
     CopyP p{*a, a->C / 4};
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
     hipLaunchKernelGGL(copy_fwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), 0, (hipStream_t)stream, p);
@@ -229,6 +230,7 @@ extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->up >= 1, "bad shape");
     PQ_CHECK_ARG(a->C % 4 == 0 && a->coff % 4 == 0 && a->ldgo % 4 == 0 && a->dx.ldg % 4 == 0, "channels / offsets / pitches must be multiples of 4");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    if (act_is_special(a->dx.act)) { pq_set_error("pq_route_bwd: logistic/tanh sinks are not supported yet"); return PQ_EUNSUPPORTED; }
     RouteP p{*a, a->C / 4};
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
     hipLaunchKernelGGL(route_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float),

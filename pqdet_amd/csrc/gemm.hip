@@ -36,21 +36,25 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // AMODE: 0 plain, 1 forward affine+act, 2 gradient pair.  BKN: B stored [k][n].  EMODE: 0 store(+bias), 1 store+stats, 2 sink
-template <int BM, int BN, int WM, int WN, int AMODE, bool BKN, int EMODE>
+// DB: double-buffered LDS + loads two k-tiles ahead (compute-bound shapes); !DB: one buffer (full-N streaming tiles).
+template <int BM, int BN, int WM, int WN, int AMODE, bool BKN, int EMODE, bool DB, int PF = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     constexpr int NWN = BN / WN;
     constexpr int TI = WM / 32, TJ = WN / 32;
     constexpr int AI = BM / 32;            // float4 A loads per thread per k-tile
     constexpr int BI = BN / 32;            // float4 B loads per thread per k-tile
+    constexpr int NB = DB ? 2 : 1;
+    constexpr int LDBK = BN + 4;           // row pitch of the [k][n] B image (BKN)
     static_assert((BM / WM) * NWN == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
-    __shared__ float red[2 * 4 * 128];
+    __shared__ __attribute__((aligned(16))) float As2[NB * BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs2[NB * BN * LDT];
+    __shared__ float red[2 * 4 * 192];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w / NWN, wn = w % NWN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int M = p.M, N = p.N, K = p.K;
+    const ActParam aact = act_param(p.act);
 
     // ---- A load plan
     const int ac4 = t & 7, ar0 = t >> 3;
@@ -70,10 +74,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         arow1[i] = (AMODE == 2) ? p.a1 + src * (size_t)p.lda1 : nullptr;
     }
     // ---- B load plan
-    constexpr int BNQ = BN / 4;                 // float4 per k-row (BKN)
-    constexpr int BKROWS = 256 / BNQ;           // k rows per pass (BKN)
-    const int bc4 = BKN ? (t % BNQ) : (t & 7);
-    const int br0 = BKN ? (t / BNQ) : (t >> 3);
+    constexpr int BNQ = BN / 4;                 // float4 per k-row (BKN): element e = t + 256*i -> (row e / BNQ, quad e % BNQ)
+    const int bc4 = t & 7;                      // NK layout: quad within the 32-wide k-tile
+    const int br0 = t >> 3;                     // NK layout: row (n) within a 32-row pass
     const bool bvec = BKN ? ((N & 3) == 0 && (p.ldb & 3) == 0) : ((p.ldb & 3) == 0);
 
     // Register staging sets (PF of them): the global loads of k-tile t+PF are in flight while tile t is multiplied.
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             }
             if (AMODE == 1) {
                 if (p.c0) { r.c0 = ldg4(p.c0 + ka); r.c1 = ldg4(p.c1 + ka); }
+                else { r.c0 = make_float4(1.f, 1.f, 1.f, 1.f); r.c1 = f4zero(); }
             } else if (AMODE == 2) {
                 r.c0 = ldg4(p.c0 + ka); r.c1 = ldg4(p.c1 + ka); r.c2 = ldg4(p.c2 + ka); r.c3 = ldg4(p.c3 + ka);
             }
@@ -108,7 +112,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                                          kb + 3 < K ? src[kb + 3] : 0.f);
                 }
             } else {
-                const int k = min(k0 + br0 + BKROWS * i, K - 1), n = n0 + 4 * bc4;
+                const int e = t + 256 * i;
+                const int k = min(k0 + e / BNQ, K - 1), n = n0 + 4 * (e % BNQ);
                 if (bvec) {
                     r.b[i] = ldg4(p.b + (size_t)k * p.ldb + min(n, N - 4));
                 } else {
@@ -120,26 +125,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         }
     };
 
-    auto store_tiles = [&](int k0, const RegSet& r) {
+    auto store_tiles = [&](int k0, const RegSet& r, int buf) {
+        float* As = As2 + buf * (BM * LDT);
+        float* Bs = Bs2 + buf * (BN * LDT);
         const int ka = k0 + 4 * ac4;
-        float c0[4] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w}, c1[4] = {r.c1.x, r.c1.y, r.c1.z, r.c1.w};
-        float c2[4] = {r.c2.x, r.c2.y, r.c2.z, r.c2.w}, c3[4] = {r.c3.x, r.c3.y, r.c3.z, r.c3.w};
+        const float c0[4] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w}, c1[4] = {r.c1.x, r.c1.y, r.c1.z, r.c1.w};
+        const float c2[4] = {r.c2.x, r.c2.y, r.c2.z, r.c2.w}, c3[4] = {r.c3.x, r.c3.y, r.c3.z, r.c3.w};
+        bool kok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kok[j] = ka + j < K;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             float v[4] = {r.a[i].x, r.a[i].y, r.a[i].z, r.a[i].w};
-            float y[4] = {0.f, 0.f, 0.f, 0.f};
-            if (AMODE == 2) { y[0] = r.a1[i].x; y[1] = r.a1[i].y; y[2] = r.a1[i].z; y[3] = r.a1[i].w; }
+            if (AMODE == 1) {
+                // branch-free: (c0, c1) are (1, 0) when the operand has no affine; piecewise-linear activation family
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float q = v[j];
-                if (AMODE == 1) {
-                    if (p.c0 != nullptr) q = fmaf(c0[j], q, c1[j]);
-                    q = act_fwd(q, p.act);
-                } else if (AMODE == 2) {
-                    q = fmaf(c0[j], q, fmaf(c1[j], y[j] - c2[j], c3[j]));
+                for (int j = 0; j < 4; ++j) {
+                    const float u = fmaf(c0[j], v[j], c1[j]);
+                    v[j] = fminf(fmaf(aact.slope, fminf(u, 0.f), fmaxf(u, 0.f)), aact.hi);
                 }
-                v[j] = (avalid[i] && ka + j < K) ? q : 0.f;
+            } else if (AMODE == 2) {
+                const float y[4] = {r.a1[i].x, r.a1[i].y, r.a1[i].z, r.a1[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], y[j] - c2[j], c3[j]));
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (avalid[i] && kok[j]) ? v[j] : 0.f;
             *reinterpret_cast<float4*>(&As[(ar0 + 32 * i) * LDT + 4 * ac4]) = make_float4(v[0], v[1], v[2], v[3]);
         }
 #pragma unroll
@@ -148,18 +159,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                 // a clamped k (tile beyond K) holds duplicates of real weights; the matching A columns are zero
                 *reinterpret_cast<float4*>(&Bs[(br0 + 32 * i) * LDT + 4 * bc4]) = r.b[i];
             } else {
-                const int kr = br0 + BKROWS * i;
+                // B arrives as [k][n] rows: keep that layout in LDS (float4 row writes are conflict free) and let the
+                // MFMA phase read its fragment with four ds_read_b32 (lanes walk n, so those are conflict free too)
+                const int e = t + 256 * i;
+                const int kr = e / BNQ, bq = e % BNQ;
                 const bool kok = k0 + kr < K;
-                const int n = n0 + 4 * bc4;
-                // B[k][n] tiles: a clamped n (n > N-4) would alias other columns -> mask explicitly
-                float e[4] = {r.b[i].x, r.b[i].y, r.b[i].z, r.b[i].w};
-                if (bvec && n > N - 4) {
-                    const int sh = n - (N - 4);      // loaded from column N-4: shift the valid ones down
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) e[j] = (j + sh < 4) ? e[(j + sh) & 3] : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[(4 * bc4 + j) * LDT + kr] = (kok && n + j < N) ? e[j] : 0.f;
+                const int n = n0 + 4 * bq;
+                const float ev[4] = {r.b[i].x, r.b[i].y, r.b[i].z, r.b[i].w};
+                float4 o;
+                o.x = (kok && n + 0 < N) ? ev[0] : 0.f;
+                o.y = (kok && n + 1 < N) ? ev[1] : 0.f;
+                o.z = (kok && n + 2 < N) ? ev[2] : 0.f;
+                o.w = (kok && n + 3 < N) ? ev[3] : 0.f;
+                *reinterpret_cast<float4*>(&Bs[kr * LDBK + 4 * bq]) = o;
             }
         }
     };
@@ -173,7 +185,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int lrow = lane & 31, lh = lane >> 5;
-    auto compute = [&]() {
+    auto compute = [&](int buf) {
+        const float* As = As2 + buf * (BM * LDT);
+        const float* Bs = Bs2 + buf * (BN * LDT);
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             float4 af[TI], bf[TJ];
@@ -181,8 +195,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             for (int i = 0; i < TI; ++i)
                 af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + 32 * i + lrow) * LDT + ks * 8 + lh * 4]);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + 32 * j + lrow) * LDT + ks * 8 + lh * 4]);
+            for (int j = 0; j < TJ; ++j) {
+                if (!BKN) {
+                    bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + 32 * j + lrow) * LDT + ks * 8 + lh * 4]);
+                } else {
+                    const float* bp = &Bs[(ks * 8 + lh * 4) * LDBK + wn * WN + 32 * j + lrow];
+                    bf[j] = make_float4(bp[0], bp[LDBK], bp[2 * LDBK], bp[3 * LDBK]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -197,28 +217,66 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 
     // AMODE 2 with y == NULL never reaches this kernel (host dispatches AMODE 0 instead).
     const int nk = (K + BK - 1) / BK;
-    constexpr int PF = (TI * TJ <= 2 && AMODE != 2) ? 2 : 1;   // short MFMA phases: prefetch two tiles ahead (when registers allow)
     RegSet r0, r1;
     r0.c0 = r0.c1 = r0.c2 = r0.c3 = f4zero();
     r1.c0 = r1.c1 = r1.c2 = r1.c3 = f4zero();
-    load_tiles(0, r0);
-    if (PF == 2 && nk > 1) load_tiles(BK, r1);
-    for (int kt = 0; kt < nk; kt += PF) {
+    if (DB && PF == 2) {
+        // One barrier per k-tile: tile t+1 goes into the other LDS buffer right after this wave's MFMAs of tile t (other
+        // waves may still be multiplying); its global loads were issued two MFMA phases earlier (register sets alternate).
+        load_tiles(0, r0);
+        if (nk > 1) load_tiles(BK, r1);
+        store_tiles(0, r0, 0);
         __syncthreads();
-        store_tiles(kt * BK, r0);
+        for (int kt = 0; kt < nk; kt += 2) {
+#ifndef PQ_ABLATE_LOADS
+            if (kt + 2 < nk) load_tiles((kt + 2) * BK, r0);
+#endif
+            compute(0);
+            if (kt + 1 < nk) store_tiles((kt + 1) * BK, r1, 1);
+            __syncthreads();
+            if (kt + 1 < nk) {
+#ifndef PQ_ABLATE_LOADS
+                if (kt + 3 < nk) load_tiles((kt + 3) * BK, r1);
+#endif
+                compute(1);
+                if (kt + 2 < nk) store_tiles((kt + 2) * BK, r0, 0);
+                __syncthreads();
+            }
+        }
+    } else if (DB) {
+        // same, loads one k-tile ahead (big tiles: the MFMA phase alone covers the memory latency, registers are scarce)
+        load_tiles(0, r0);
+        store_tiles(0, r0, 0);
         __syncthreads();
-        if (kt + PF < nk) load_tiles((kt + PF) * BK, r0);
-        compute();
-        if (PF == 2 && kt + 1 < nk) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+#ifndef PQ_ABLATE_LOADS
+            if (more) load_tiles((kt + 1) * BK, r0);
+#endif
+            compute(kt & 1);
+            if (more) store_tiles((kt + 1) * BK, r0, (kt + 1) & 1);
             __syncthreads();
-            store_tiles((kt + 1) * BK, r1);
+        }
+    } else {
+        load_tiles(0, r0);
+        for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();
-            if (kt + 3 < nk) load_tiles((kt + 3) * BK, r1);
-            compute();
+            store_tiles(kt * BK, r0, 0);
+            __syncthreads();
+#ifndef PQ_ABLATE_LOADS
+            if (kt + 1 < nk) load_tiles((kt + 1) * BK, r0);
+#endif
+            compute(0);
         }
     }
 
     // ---------------------------------------------------------------- epilogue
+#ifdef PQ_ABLATE_EPILOGUE
+    { float keep = 0.f;
+      for (int i = 0; i < TI; ++i) for (int j = 0; j < TJ; ++j) for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+      if (keep == 123.456f) p.out[0] = keep;
+      return; }
+#endif
     float s1[TJ], s2[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) s1[j] = s2[j] = 0.f;
@@ -228,32 +286,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         const pq_gsink& sk = p.sink;
         const bool affine = sk.scale != nullptr;
         const bool stats = sk.mean != nullptr && sk.partial != nullptr;
+        const ActParam sact = act_param(sk.act);
         const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
         want_stats = sk.finalize && stats;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int n = n0 + wn * WN + 32 * j + lrow;
             const bool nok = n < N;
-            const float ca = (affine && nok) ? sk.scale[n] : 1.f, cb = (affine && nok) ? sk.shift[n] : 0.f;
-            const float cm = (stats && nok) ? sk.mean[n] : 0.f, ci = (stats && nok) ? sk.invstd[n] : 0.f;
+            const int nc = min(n, N - 1);
+            const float ca = affine ? sk.scale[nc] : 1.f, cb = affine ? sk.shift[nc] : 0.f;
+            const float cm = stats ? sk.mean[nc] : 0.f, ci = stats ? sk.invstd[nc] : 0.f;
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+            for (int i = 0; i < TI; ++i) {
+                // batch the 16 (y, old g) loads of this 32x32 tile at clamped addresses, then compute and store
+                float yv[16], gv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mc = min(m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
+                    yv[r] = need_y ? sk.y[(size_t)mc * sk.ldy + nc] : 0.f;
+                    gv[r] = sk.accumulate ? sk.g[(size_t)mc * sk.ldg + nc] : 0.f;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float dz = acc[i][j][r] + gv[r];
+                    if (need_y) {
+                        const float u = fmaf(ca, yv[r], cb);
+                        dz *= act_bwd(u, sact);
+                    }
                     if (m < M && nok) {
-                        float* gp = sk.g + (size_t)m * sk.ldg + n;
-                        float dz = acc[i][j][r];
-                        if (sk.accumulate) dz += *gp;
-                        if (need_y) {
-                            const float y = sk.y[(size_t)m * sk.ldy + n];
-                            const float u = affine ? fmaf(ca, y, cb) : y;
-                            dz *= act_bwd(u, sk.act);
-                            if (stats) { s1[j] += dz; s2[j] = fmaf(dz, (y - cm) * ci, s2[j]); }
-                        }
-                        *gp = dz;
+                        sk.g[(size_t)m * sk.ldg + n] = dz;
+                        if (stats) { s1[j] += dz; s2[j] = fmaf(dz, (yv[r] - cm) * ci, s2[j]); }
                     }
                 }
+            }
         }
     } else {
         want_stats = (EMODE == 1) && p.partial != nullptr;
@@ -284,15 +350,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             s1[j] += __shfl_xor(s1[j], 32);
             s2[j] += __shfl_xor(s2[j], 32);
             if (lh == 0) {
-                red[(0 * 4 + wm) * 128 + wn * WN + 32 * j + lrow] = s1[j];
-                red[(1 * 4 + wm) * 128 + wn * WN + 32 * j + lrow] = s2[j];
+                red[(0 * 4 + wm) * 192 + wn * WN + 32 * j + lrow] = s1[j];
+                red[(1 * 4 + wm) * 192 + wn * WN + 32 * j + lrow] = s2[j];
             }
         }
         __syncthreads();
         if (t < BN) {
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int q = 0; q < BM / WM; ++q) { a += red[(0 * 4 + q) * 128 + t]; b += red[(1 * 4 + q) * 128 + t]; }
+            for (int q = 0; q < BM / WM; ++q) { a += red[(0 * 4 + q) * 192 + t]; b += red[(1 * 4 + q) * 192 + t]; }
             const int n = n0 + t;
             if (n < N) {
                 float* dst = part + (size_t)blockIdx.y * 2 * ldp;
@@ -333,33 +399,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTP p) {
     const int oc = o0 + 4 * yc4, ic = i0 + 4 * xc4;
     const GsrcCoef4 gk = gsrc_coef4(p.dy, oc, p.O);
     const SrcCoef4 xk = src_coef4(p.x, ic, p.I);
-    const bool ovec = oc + 3 < p.O, ivec = ic + 3 < p.I;
     const bool do_bias = p.want_bias && ti == 0;
+    // unconditional loads at clamped coordinates (pitches are multiples of 4, so a whole quad is always readable);
+    // rows / columns outside the problem are zeroed when the tile is written to LDS
+    const int Opad = (p.O + 3) & ~3, Ipad = (p.I + 3) & ~3;
+    const int ocl = min(oc, Opad - 4), icl = min(ic, Ipad - 4);
 
     float4 ry[OL], ry1[OL], rx[IL];
     float4 bsum = f4zero();
 
-    auto ld4 = [](const float* base, bool vec, int c, int C) -> float4 {
-        if (vec) return ldg4(base);
-        float4 v = f4zero();
-        if (c < C) v.x = base[0];
-        if (c + 1 < C) v.y = base[1];
-        if (c + 2 < C) v.z = base[2];
-        return v;
-    };
     auto load_tiles = [&](int mb) {
+        if (oc < Opad) {       // one branch per batch: lanes whose quad lies past O skip their loads
 #pragma unroll
-        for (int l = 0; l < OL; ++l) {
-            int m = mb + yr0 + ORP * l;
-            bool ok = m < mend && oc < p.O;
-            ry[l] = ok ? ld4(p.dy.g + (size_t)m * p.dy.ldg + oc, ovec, oc, p.O) : f4zero();
-            ry1[l] = (ok && gk.two) ? ld4(p.dy.y + (size_t)m * p.dy.ldy + oc, ovec, oc, p.O) : f4zero();
+            for (int l = 0; l < OL; ++l) {
+                const int m = min(mb + yr0 + ORP * l, mend - 1);
+                ry[l] = ldg4(p.dy.g + (size_t)m * p.dy.ldg + ocl);
+                if (gk.two) ry1[l] = ldg4(p.dy.y + (size_t)m * p.dy.ldy + ocl);
+            }
         }
+        if (ic < Ipad) {
 #pragma unroll
-        for (int l = 0; l < IL; ++l) {
-            int m = mb + xr0 + IRP * l;
-            bool ok = m < mend && ic < p.I;
-            rx[l] = ok ? ld4(p.x.x + (size_t)m * p.x.ld + ic, ivec, ic, p.I) : f4zero();
+            for (int l = 0; l < IL; ++l) {
+                const int m = min(mb + xr0 + IRP * l, mend - 1);
+                rx[l] = ldg4(p.x.x + (size_t)m * p.x.ld + icl);
+            }
         }
     };
     auto store_tiles = [&](int mb) {
@@ -467,37 +530,54 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* slab, si
 using namespace pq;
 
 // ------------------------------------------------------------------------------------------------ host dispatch
-// pick the block tile: prefer big tiles (operand reuse) but keep >= ~2 blocks per CU and little padding waste
+// Block-tile choice.
+//  * streaming tiles 128 x (32*TJ), TJ = ceil(N/32) <= 6, one block per 128 rows covering ALL N columns: the A tile is
+//    read once and the block writes one contiguous slab of the output -- used whenever that still fills the chip;
+//  * otherwise the best of 128x128 / 128x64 / 64x64 / 128x32 by padding waste and block count (double-buffered LDS).
 struct TileCand { int bm, bn; float bonus; };
-static const TileCand kTiles[4] = {{128, 128, 1.00f}, {128, 64, 0.94f}, {64, 64, 0.86f}, {128, 32, 0.84f}};
-static int pick_tile(int M, int N) {
+static const TileCand kTiles[4] = {{128, 128, 141.f}, {128, 64, 132.f}, {64, 64, 114.f}, {128, 32, 105.f}};
+struct TilePick { int kind; int idx; int bm, bn; };     // kind 0: kTiles[idx]; kind 1: streaming with TJ = idx
+static TilePick pick_tile(int M, int N) {
+    const int tj = (N + 31) / 32;
+    if (tj <= 6 && (long)(M + 127) / 128 >= 384) return {1, tj, 128, 32 * tj};
+    // cost model: the busiest CU runs ceil(blocks / 256) tiles back to back (MFMA bound), each tile at the on-chip
+    // rate measured for its shape (scripts/probes/mfma_probe.hip: 141 / 132 / 114 / 105 TF/s)
     int best = 0;
-    float best_score = -1.f;
+    float best_cost = 3.4e38f;
     for (int c = 0; c < 4; ++c) {
         const long gm = (M + kTiles[c].bm - 1) / kTiles[c].bm, gn = (N + kTiles[c].bn - 1) / kTiles[c].bn;
-        const float eff = (float)((double)M * N / ((double)gm * gn * kTiles[c].bm * kTiles[c].bn));
-        const float fill = gm * gn >= 512 ? 1.f : (float)(gm * gn) / 512.f;
-        const float score = eff * fill * kTiles[c].bonus;
-        if (score > best_score) { best_score = score; best = c; }
+        const long rounds = (gm * gn + 255) / 256;
+        const float cost = (float)rounds * kTiles[c].bm * kTiles[c].bn / kTiles[c].bonus;
+        if (cost < best_cost) { best_cost = cost; best = c; }
     }
-    return best;
+    return {0, best, kTiles[best].bm, kTiles[best].bn};
 }
 extern "C" int32_t pq_conv1x1_blocks(int32_t M, int32_t N) {
-    const int c = pick_tile(M, N);
-    return (M + kTiles[c].bm - 1) / kTiles[c].bm;
+    const TilePick t = pick_tile(M, N);
+    return (M + t.bm - 1) / t.bm;
 }
 
 template <int AMODE, bool BKN, int EMODE>
 static void launch_nt(const GemmP& p, hipStream_t st) {
-    const int best = pick_tile(p.M, p.N);
+    const TilePick t = pick_tile(p.M, p.N);
     dim3 blk(256);
-    const int bm = kTiles[best].bm, bn = kTiles[best].bn;
-    dim3 grid((p.N + bn - 1) / bn, (p.M + bm - 1) / bm);
-    switch (best) {
-        case 0: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, AMODE, BKN, EMODE>), grid, blk, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 64, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE>), grid, blk, 0, st, p); break;
+    dim3 grid((p.N + t.bn - 1) / t.bn, (p.M + t.bm - 1) / t.bm);
+    if (t.kind == 0) {
+        switch (t.idx) {
+            case 0: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, AMODE, BKN, EMODE, true, 1>), grid, blk, 0, st, p); break;
+            case 1: hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 64, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
+            case 2: hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
+            default: hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
+        }
+    } else {
+        switch (t.idx) {
+            case 1: hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 2: hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 32, 64, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 3: hipLaunchKernelGGL((gemm_nt_kernel<128, 96, 32, 96, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 4: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, 128, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 5: hipLaunchKernelGGL((gemm_nt_kernel<128, 160, 32, 160, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            default: hipLaunchKernelGGL((gemm_nt_kernel<128, 192, 32, 192, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+        }
     }
 }
 
@@ -508,6 +588,7 @@ extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a->ldo >= a->O && a->in.ld >= a->I, "pitch smaller than channel count");
     PQ_CHECK_ARG(a->partial == nullptr || a->ldp >= a->O, "stats pitch too small");
     PQ_CHECK_ARG(a->sub >= 1, "sub must be >= 1");
+    if (act_is_special(a->in.act)) { pq_set_error("pq_conv1x1_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     GemmP p{};
     p.a0 = a->in.x; p.lda0 = a->in.ld; p.c0 = a->in.scale; p.c1 = a->in.shift; p.act = a->in.act;
     p.sub = a->sub; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
@@ -529,6 +610,7 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "gradient pitch must be a multiple of 4");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    if (act_is_special(a->dx.act)) { pq_set_error("pq_conv1x1_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }
     GemmP p{};
     p.a0 = a->dy.g; p.a1 = a->dy.y; p.lda0 = a->dy.ldg; p.lda1 = a->dy.ldy;
     p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
@@ -563,6 +645,7 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->dw && a->scratch, "null pointer");
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->in.ld & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "pitches must be multiples of 4");
+    if (act_is_special(a->in.act)) { pq_set_error("pq_conv1x1_wgrad: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     bool big; int tiles, splits, rows;
     wgrad_plan(a->M, a->I, a->O, big, tiles, splits, rows);
     GemmTP p{};

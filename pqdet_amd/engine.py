@@ -261,6 +261,9 @@ class Plan:
                 ld = _round_up(Cout, 4)
                 bn = conv_bn(m, Cout, rows)
                 act = act_code_of(getattr(m, 'act', None))
+                if act in (abi.ACT_LOGISTIC, abi.ACT_TANH):
+                    raise NotImplementedError('logistic / tanh between layers are not supported by the HIP engine yet '
+                                              '(no shipped detector cfg uses them)')
                 raw = self._new(rows, ld) if ld == Cout else self._new(rows, ld, fill=0.0)
                 out = TensorRef(raw, B, OH, OW, Cout, ld, bn, act)
                 want_stats = bn is not None and self.bn_train
