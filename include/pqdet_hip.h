@@ -316,9 +316,10 @@ enum {
     PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
+#define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
 typedef struct pq_op {
     int32_t code;
-    int32_t pad;
+    int32_t flags;
     union {
         pq_conv1x1_fwd_args c1f; pq_conv1x1_dgrad_args c1d; pq_conv1x1_wgrad_args c1w;
         pq_dw3x3_fwd_args dwf; pq_dw3x3_dgrad_args dwd; pq_dw3x3_wgrad_args dww;
@@ -329,6 +330,10 @@ typedef struct pq_op {
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);
+/* two-stream replay: ops flagged PQ_OPF_SIDE are launched on `side_stream` after an event recorded on `stream` at their
+ * position (they see everything launched before them); `stream` waits for the side stream at the end of the call.
+ * Lets the weight-gradient GEMMs overlap the latency-bound data-gradient chain of the backward pass. */
+int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side_stream);
 /* profiling variant: brackets every op with HIP events on `stream`, synchronises at the end and writes the elapsed
  * milliseconds of op k to ms[k] (used by bench.py for the live roofline figure; never on the timed path) */
 int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms);

@@ -149,8 +149,11 @@ class _OpU(C.Union):
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill)]
 
 
+OPF_SIDE = 1
+
+
 class Op(C.Structure):
-    _fields_ = [('code', i32), ('pad', i32), ('u', _OpU)]
+    _fields_ = [('code', i32), ('flags', i32), ('u', _OpU)]
 
 
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
@@ -196,6 +199,7 @@ SIGNATURES = {
     'pq_nms': (C.c_int, [C.POINTER(Nms), C.c_void_p]),
     'pq_nms_scratch_bytes': (i64, [i32, i32]),
     'pq_run_ops': (C.c_int, [C.POINTER(Op), i32, C.c_void_p]),
+    'pq_run_ops2': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p]),
     'pq_run_ops_timed': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.POINTER(C.c_float)]),
     'pq_last_failed_op': (C.c_int, []),
     'pq_last_error': (C.c_char_p, []),

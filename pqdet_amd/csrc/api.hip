@@ -52,6 +52,45 @@ extern "C" int pq_run_ops(const pq_op* ops, int32_t n, void* stream) {
     return PQ_OK;
 }
 
+extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side_stream) {
+    g_failed_op = -1;
+    if (!ops || n < 0) { pq_set_error("pq_run_ops2: bad arguments"); return PQ_EINVAL; }
+    if (!side_stream || side_stream == stream) return pq_run_ops(ops, n, stream);
+    static thread_local hipEvent_t ev[64];
+    static thread_local int nev = 0, next = 0;
+    if (nev == 0) {
+        for (int i = 0; i < 64; ++i)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { pq_set_error("pq_run_ops2: event create failed"); return PQ_ELAUNCH; }
+        nev = 64;
+    }
+    hipStream_t main_s = (hipStream_t)stream, side_s = (hipStream_t)side_stream;
+    bool used_side = false, main_dirty = true;     // main_dirty: something was launched on main since the last fork event
+    for (int i = 0; i < n; ++i) {
+        const bool side = (ops[i].flags & PQ_OPF_SIDE) != 0;
+        if (side) {
+            if (main_dirty) {
+                hipEvent_t e = ev[next]; next = (next + 1) & 63;
+                if (hipEventRecord(e, main_s) != hipSuccess || hipStreamWaitEvent(side_s, e, 0) != hipSuccess) {
+                    pq_set_error("pq_run_ops2: fork failed"); g_failed_op = i; return PQ_ELAUNCH;
+                }
+                main_dirty = false;
+            }
+            used_side = true;
+        } else {
+            main_dirty = true;
+        }
+        const int rc = run_one(ops[i], side ? side_stream : stream);
+        if (rc != PQ_OK) { g_failed_op = i; return rc; }
+    }
+    if (used_side) {
+        hipEvent_t e = ev[next]; next = (next + 1) & 63;
+        if (hipEventRecord(e, side_s) != hipSuccess || hipStreamWaitEvent(main_s, e, 0) != hipSuccess) {
+            pq_set_error("pq_run_ops2: join failed"); return PQ_ELAUNCH;
+        }
+    }
+    return PQ_OK;
+}
+
 extern "C" int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms) {
     g_failed_op = -1;
     if (!ops || n < 0 || !ms) { pq_set_error("pq_run_ops_timed: bad arguments"); return PQ_EINVAL; }

@@ -6,8 +6,9 @@ namespace pq {
 
 // ------------------------------------------------------------------------------------------------ BN finalize
 // One block of 256 threads = 16 channels x 16 row-lanes; partial is [nblk][2][ldp].
-constexpr int BN_RL = 64;    // row lanes per block (block = 16 channels x BN_RL)
-__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize_args a) {
+// block = 16 channels x BN_RL row lanes; BN_RL = 8 for short partial lists (most layers), 64 for the 256x256 layers
+template <int BN_RL>
+__global__ __launch_bounds__(16 * BN_RL) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize_args a) {
     __shared__ double sh[2][16][BN_RL + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(pq_bn_fwd_finaliz
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize_args a) {
+template <int BN_RL>
+__global__ __launch_bounds__(16 * BN_RL) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize_args a) {
     __shared__ double sh[2][16][BN_RL + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -198,7 +200,8 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
     PQ_CHECK_ARG(a->C > 0, "empty");
     PQ_CHECK_ARG(!a->train || (a->partial && a->nblk > 0 && a->count > 0.f), "train mode needs partial sums");
     PQ_CHECK_ARG(a->train || (a->running_mean && a->running_var), "eval mode needs running statistics");
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + 15) / 16), dim3(16 * BN_RL), 0, (hipStream_t)stream, *a);
+    if (a->nblk > 256) hipLaunchKernelGGL((bn_fwd_finalize_kernel<64>), dim3((a->C + 15) / 16), dim3(16 * 64), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((bn_fwd_finalize_kernel<8>), dim3((a->C + 15) / 16), dim3(16 * 8), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -206,7 +209,8 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
 extern "C" int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->partial && a->gamma && a->invstd && a->dgamma && a->dbeta && a->p && a->q && a->r, "null pointer");
     PQ_CHECK_ARG(a->C > 0 && a->nblk > 0 && a->count > 0.f, "empty");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->C + 15) / 16), dim3(16 * BN_RL), 0, (hipStream_t)stream, *a);
+    if (a->nblk > 256) hipLaunchKernelGGL((bn_bwd_finalize_kernel<64>), dim3((a->C + 15) / 16), dim3(16 * 64), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((bn_bwd_finalize_kernel<8>), dim3((a->C + 15) / 16), dim3(16 * 8), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -470,7 +470,7 @@ class Plan:
                                           out.C, s)
                         idx = self._op(self.bwd, abi.OP_STEM_WGRAD, a)
                         self.patch_x.append(('bwd', idx, 'stw'))
-                        wg_ops.append((idx, 'stw'))
+                        wg_ops.append((idx, 'stw', need))
                     else:
                         src = T[resolve(i - 1, i)]
                         if k == 1:
@@ -481,7 +481,7 @@ class Plan:
                                                  flat.grad_ptr(conv.bias) if conv.bias is not None else None, None,
                                                  out.rows, src.C, out.C)
                             idx = self._op(self.bwd, abi.OP_CONV1X1_WGRAD, a)
-                            wg_ops.append((idx, 'c1w'))
+                            wg_ops.append((idx, 'c1w', need))
                             if src.needs_grad:
                                 d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), self._sink(src, l.pq_conv1x1_blocks(src.rows, src.C)), out.rows,
                                                      src.C, out.C)
@@ -491,11 +491,10 @@ class Plan:
                             a = abi.DwWgrad(dy, src.src(), flat.grad_ptr(conv.weight), None, B, src.H, src.W, out.H, out.W,
                                             out.C, s)
                             idx = self._op(self.bwd, abi.OP_DW_WGRAD, a)
-                            wg_ops.append((idx, 'dww'))
+                            wg_ops.append((idx, 'dww', need))
                             d = abi.DwDgrad(dy, ptr(conv.weight), self._sink(src, l.pq_ew_blocks(src.rows, src.C)), B, src.H,
                                             src.W, out.H, out.W, out.C, s)
                             self._op(self.bwd, abi.OP_DW_DGRAD, d)
-                    scratch_need = max(scratch_need, need)
                 plist = list(m.parameters())
                 if plist:
                     lo = min(flat.offsets[flat.index[id(p)]] for p in plist)
@@ -526,9 +525,11 @@ class Plan:
                     r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B, srcT.H,
                                      srcT.W, srcT.C, out.ld, 0, f)
                     self._op(self.bwd, abi.OP_ROUTE_BWD, r)
-        self.scratch = torch.empty(max(scratch_need, 16) // 4 + 16, device=self.device, dtype=torch.float32)
-        for idx, field in wg_ops:
-            getattr(self.bwd[idx].u, field).scratch = self.scratch.data_ptr()
+        # weight-gradient ops only feed the optimiser: they get private scratch and may run on the side stream
+        for idx, field, need in wg_ops:
+            buf = self._new(max(need, 64) // 4 + 16)
+            getattr(self.bwd[idx].u, field).scratch = buf.data_ptr()
+            self.bwd[idx].flags = abi.OPF_SIDE
 
     # ------------------------------------------------------------------------------------------ run
     def _patch(self, x, target):
@@ -554,10 +555,13 @@ class Plan:
     def run_backward(self, reducer=None):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         l = lib()
+        side = self.model._side_stream()
+        sd = C.c_void_p(side.cuda_stream) if side is not None else None
         if reducer is None:
-            check(l.pq_run_ops(self.bwd_arr, len(self.bwd), st), 'backward step')
+            check(l.pq_run_ops2(self.bwd_arr, len(self.bwd), st, sd), 'backward step')
             return
-        # bucketed replay: launch the ops up to each mark, then hand the finished gradient range to the reducer
+        # bucketed replay: launch the ops up to each mark (pq_run_ops2 joins the side stream at the end of every call, so
+        # the gradient range is final on the main stream), then hand the finished range to the reducer
         flat = self.model._flat
         start, hi = 0, flat.grad.numel()
         marks = reducer.pick_marks(self.segments, hi)
@@ -566,12 +570,12 @@ class Plan:
             n = op_end - start
             if n > 0:
                 sub = C.cast(C.c_void_p(base + start * C.sizeof(abi.Op)), C.POINTER(abi.Op))
-                check(l.pq_run_ops(sub, n, st), 'backward step')
+                check(l.pq_run_ops2(sub, n, st, sd), 'backward step')
             reducer.reduce_range(flat.grad, lo, hi)
             start, hi = op_end, lo
         if start < len(self.bwd):
             sub = C.cast(C.c_void_p(base + start * C.sizeof(abi.Op)), C.POINTER(abi.Op))
-            check(l.pq_run_ops(sub, len(self.bwd) - start, st), 'backward step')
+            check(l.pq_run_ops2(sub, len(self.bwd) - start, st, sd), 'backward step')
         if hi > 0:
             reducer.reduce_range(flat.grad, 0, hi)
         reducer.finish()

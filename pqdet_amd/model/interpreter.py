@@ -71,6 +71,15 @@ class AnyModel(nn.Module):
         self._nan_event = None
         self._nan_host = None
         self.nan_check = 'deferred'   # 'sync' | 'deferred' | 'off'
+        self.overlap_wgrad = True     # run weight-gradient kernels on a side HIP stream during backward
+        self._side = None
+
+    def _side_stream(self):
+        if not self.overlap_wgrad:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     # ---- flat parameter storage ------------------------------------------------------------------------
     def _ensure_flat(self, device):
