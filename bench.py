@@ -38,6 +38,7 @@ KERNEL_CLASS = {
     abi.OP_CONV1X1_DGRAD: ('conv1x1_dgrad (gemm_nt, fp32 MFMA)', 'mfma'),
     abi.OP_CONV1X1_WGRAD: ('conv1x1_wgrad (gemm_tn, fp32 MFMA)', 'mfma'),
     abi.OP_DW_FWD: ('dw3x3_fwd', 'hbm'), abi.OP_DW_DGRAD: ('dw3x3_dgrad', 'hbm'), abi.OP_DW_WGRAD: ('dw3x3_wgrad', 'hbm'),
+    abi.OP_DW_BWD: ('dw3x3_bwd (fused dgrad+wgrad, LDS tiles)', 'hbm'),
     abi.OP_STEM_FWD: ('stem3x3_fwd', 'hbm'), abi.OP_STEM_WGRAD: ('stem3x3_wgrad', 'hbm'),
     abi.OP_BN_FWD_FIN: ('bn_fwd_finalize', 'hbm'), abi.OP_BN_BWD_FIN: ('bn_bwd_finalize', 'hbm'),
     abi.OP_COPY_FWD: ('copy_fwd (shortcut/route/upsample)', 'hbm'), abi.OP_ROUTE_BWD: ('route_bwd', 'hbm'),
@@ -58,6 +59,10 @@ def op_work(op):
         a = {abi.OP_DW_FWD: op.u.dwf, abi.OP_DW_DGRAD: op.u.dwd, abi.OP_DW_WGRAD: op.u.dww}[c]
         n_in, n_out = a.B * a.IH * a.IW * a.C, a.B * a.OH * a.OW * a.C
         return 2.0 * 9 * n_out, 4.0 * (n_in + n_out + 9 * a.C)
+    if c == abi.OP_DW_BWD:
+        a = op.u.dwb
+        n_in, n_out = a.B * a.IH * a.IW * a.C, a.B * a.OH * a.OW * a.C
+        return 2.0 * 2.0 * 9 * n_out, 2.0 * 4.0 * (n_in + n_out + 9 * a.C)
     if c in (abi.OP_STEM_FWD, abi.OP_STEM_WGRAD):
         a = op.u.stf if c == abi.OP_STEM_FWD else op.u.stw
         n_in, n_out = a.B * a.CI * a.IH * a.IW, a.B * a.OH * a.OW * a.O

@@ -120,11 +120,12 @@ typedef struct pq_dw3x3_fwd_args {
     pq_src in;
     const float* w;
     float* out;          /* raw, pitch ldo */
-    float* partial;      /* [nblk][2][ldp] or NULL; nblk = pq_dw3x3_blocks(...) */
+    float* partial;      /* [nblk][2][ldp] or NULL; nblk = pq_dw3x3_fwd_blocks(B, OH, OW, C, stride) */
     int32_t B, IH, IW, OH, OW, C, stride, ldo, ldp;
 } pq_dw3x3_fwd_args;
 int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream);
-int32_t pq_dw3x3_blocks(int32_t B, int32_t H, int32_t W, int32_t C);   /* row-blocks used for (B,H,W,C) outputs */
+int32_t pq_dw3x3_fwd_blocks(int32_t B, int32_t OH, int32_t OW, int32_t C, int32_t stride);   /* statistics rows written by pq_dw3x3_fwd */
+int32_t pq_dw3x3_blocks(int32_t B, int32_t H, int32_t W, int32_t C);   /* row-blocks of the streaming pq_dw3x3_dgrad sink */
 
 typedef struct pq_dw3x3_dgrad_args {
     pq_gsrc dy;          /* at output resolution */
@@ -143,6 +144,24 @@ typedef struct pq_dw3x3_wgrad_args {
 } pq_dw3x3_wgrad_args;
 int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream);
 int64_t pq_dw3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_t OW, int32_t C);
+
+/* fused, LDS-tiled backward: ONE kernel stages (g_out, y_out) and y_in once and produces both the input gradient (through
+ * the sink, statistics rows = pq_dw3x3_bwd_blocks) and dw -- 3 tensor reads + 1 write instead of the 7 passes of
+ * pq_dw3x3_dgrad + pq_dw3x3_wgrad (which remain available as the streaming variants). */
+typedef struct pq_dw3x3_bwd_args {
+    pq_gsrc dy;
+    pq_src in;
+    const float* w;
+    pq_gsink dx;
+    float* dw;
+    float* scratch;      /* >= pq_dw3x3_bwd_scratch_bytes */
+    int32_t B, IH, IW, OH, OW, C, stride;
+} pq_dw3x3_bwd_args;
+int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream);
+int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t C, int32_t stride);
+int32_t pq_dw3x3_bwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t stride);
+/* 1 when the fused tiled backward beats pq_dw3x3_dgrad + pq_dw3x3_wgrad for this plane size (measured heuristic) */
+int32_t pq_dw3x3_bwd_fused_pays(int32_t IH, int32_t IW, int32_t stride);
 
 /* ------------------------------------------------------------------ network stem: dense 3x3 conv on the NCHW image
  * (3 input channels, pad 1, stride 1|2), the first section of every shipped detector cfg. */
@@ -313,7 +332,7 @@ int64_t pq_nms_scratch_bytes(int32_t N, int32_t C);
 enum {
     PQ_OP_CONV1X1_FWD = 1, PQ_OP_CONV1X1_DGRAD, PQ_OP_CONV1X1_WGRAD, PQ_OP_DW_FWD, PQ_OP_DW_DGRAD, PQ_OP_DW_WGRAD,
     PQ_OP_STEM_FWD, PQ_OP_STEM_WGRAD, PQ_OP_BN_FWD_FIN, PQ_OP_BN_BWD_FIN, PQ_OP_COPY_FWD, PQ_OP_ROUTE_BWD,
-    PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL
+    PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -322,7 +341,7 @@ typedef struct pq_op {
     int32_t flags;
     union {
         pq_conv1x1_fwd_args c1f; pq_conv1x1_dgrad_args c1d; pq_conv1x1_wgrad_args c1w;
-        pq_dw3x3_fwd_args dwf; pq_dw3x3_dgrad_args dwd; pq_dw3x3_wgrad_args dww;
+        pq_dw3x3_fwd_args dwf; pq_dw3x3_dgrad_args dwd; pq_dw3x3_wgrad_args dww; pq_dw3x3_bwd_args dwb;
         pq_stem3x3_fwd_args stf; pq_stem3x3_wgrad_args stw;
         pq_bn_fwd_finalize_args bnf; pq_bn_bwd_finalize_args bnb;
         pq_copy_args cp; pq_route_bwd_args rb;

@@ -66,6 +66,11 @@ class DwWgrad(C.Structure):
                 ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('stride', i32)]
 
 
+class DwBwd(C.Structure):
+    _fields_ = [('dy', GSrc), ('inp', Src), ('w', c_fp), ('dx', GSink), ('dw', c_fp), ('scratch', c_fp),
+                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('stride', i32)]
+
+
 class StemFwd(C.Structure):
     _fields_ = [('image', c_fp), ('w', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('B', i32), ('CI', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('O', i32),
@@ -144,7 +149,7 @@ class Fill(C.Structure):
 
 class _OpU(C.Union):
     _fields_ = [('c1f', Conv1x1Fwd), ('c1d', Conv1x1Dgrad), ('c1w', Conv1x1Wgrad),
-                ('dwf', DwFwd), ('dwd', DwDgrad), ('dww', DwWgrad), ('stf', StemFwd), ('stw', StemWgrad),
+                ('dwf', DwFwd), ('dwd', DwDgrad), ('dww', DwWgrad), ('dwb', DwBwd), ('stf', StemFwd), ('stw', StemWgrad),
                 ('bnf', BnFwdFin), ('bnb', BnBwdFin), ('cp', Copy), ('rb', RouteBwd),
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill)]
 
@@ -157,13 +162,13 @@ class Op(C.Structure):
 
 
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
- OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL) = range(1, 18)
+ OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD) = range(1, 19)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
     OP_DW_WGRAD: 'dww', OP_STEM_FWD: 'stf', OP_STEM_WGRAD: 'stw', OP_BN_FWD_FIN: 'bnf', OP_BN_BWD_FIN: 'bnb',
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
-    OP_FILL: 'fill',
+    OP_FILL: 'fill', OP_DW_BWD: 'dwb',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -175,9 +180,14 @@ SIGNATURES = {
     'pq_conv1x1_wgrad_scratch_bytes': (i64, [i32, i32, i32]),
     'pq_dw3x3_fwd': (C.c_int, [C.POINTER(DwFwd), C.c_void_p]),
     'pq_dw3x3_blocks': (i32, [i32, i32, i32, i32]),
+    'pq_dw3x3_fwd_blocks': (i32, [i32, i32, i32, i32, i32]),
+    'pq_dw3x3_bwd_fused_pays': (i32, [i32, i32, i32]),
+    'pq_dw3x3_bwd_blocks': (i32, [i32, i32, i32, i32]),
     'pq_dw3x3_dgrad': (C.c_int, [C.POINTER(DwDgrad), C.c_void_p]),
     'pq_dw3x3_wgrad': (C.c_int, [C.POINTER(DwWgrad), C.c_void_p]),
     'pq_dw3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32]),
+    'pq_dw3x3_bwd': (C.c_int, [C.POINTER(DwBwd), C.c_void_p]),
+    'pq_dw3x3_bwd_scratch_bytes': (i64, [i32, i32, i32, i32, i32, i32, i32]),
     'pq_stem3x3_fwd': (C.c_int, [C.POINTER(StemFwd), C.c_void_p]),
     'pq_stem3x3_wgrad': (C.c_int, [C.POINTER(StemWgrad), C.c_void_p]),
     'pq_stem3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32, i32]),

@@ -17,6 +17,7 @@ SOURCES = {            # file -> extra flags
     'api.hip': [],
     'gemm.hip': [],
     'dwconv.hip': [],
+    'dwtile.hip': [],
     'ew.hip': [],
     'yolo.hip': [],
     'post.hip': ['-ffp-contract=off'],   # NMS comparisons must not see FMA contraction (bit-exact selection)

@@ -36,6 +36,7 @@ static int run_one(const pq_op& op, void* stream) {
         case PQ_OP_LOSS_BWD: return pq_yolo_loss_bwd(&op.u.loss, stream);
         case PQ_OP_ADAM: return pq_adam_step(&op.u.adam, stream);
         case PQ_OP_FILL: return pq_fill(op.u.fill.dst, op.u.fill.value, op.u.fill.n, stream);
+        case PQ_OP_DW_BWD: return pq_dw3x3_bwd(&op.u.dwb, stream);
         default:
             pq_set_error("pq_run_ops: unknown op code %d", op.code);
             return PQ_EINVAL;
@@ -135,6 +136,7 @@ extern "C" int32_t pq_abi_sizeof(int32_t code) {
         case PQ_OP_LOSS_FWD: case PQ_OP_LOSS_BWD: return (int32_t)sizeof(pq_yolo_loss_args);
         case PQ_OP_ADAM: return (int32_t)sizeof(pq_adam_args);
         case PQ_OP_FILL: return (int32_t)sizeof(pq_fill_args);
+        case PQ_OP_DW_BWD: return (int32_t)sizeof(pq_dw3x3_bwd_args);
         case 100: return (int32_t)sizeof(pq_recover_args);
         case 101: return (int32_t)sizeof(pq_nms_args);
         case 102: return (int32_t)sizeof(pq_decode_bwd_args);

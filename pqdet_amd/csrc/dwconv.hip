@@ -415,11 +415,8 @@ static int check_dw_common(int B, int IH, int IW, int OH, int OW, int C, int str
     return 1;
 }
 
-extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
-    PQ_CHECK_ARG(a && a->in.x && a->w && a->out, "null pointer");
-    PQ_CHECK_ARG(check_dw_common(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need C%4==0, stride 1|2, pad 1)");
-    PQ_CHECK_ARG((a->in.ld & 3) == 0 && (a->ldo & 3) == 0, "pitches must be multiples of 4");
-    if (act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
+// streaming (register-window) forward; the LDS-tiled variant lives in dwtile.hip, pq_dw3x3_fwd picks one per shape
+int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream) {
     DwP p{};
     p.in = a->in; p.w = a->w; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;
@@ -486,6 +483,7 @@ extern "C" int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream) {
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
+
 
 // ------------------------------------------------------------------------------------------------ stem host
 static int stem_check(int B, int CI, int IH, int IW, int OH, int OW, int O, int stride) {

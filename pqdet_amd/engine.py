@@ -278,7 +278,7 @@ class Plan:
                         nblk = l.pq_conv1x1_blocks(rows, Cout)
                         self._deferred.append(('c1_fwd', i, out, nblk, src, s))
                     elif k == 3 and groups == Cin == Cout and conv.padding[0] == 1:
-                        nblk = l.pq_dw3x3_blocks(B, OH, OW, Cout)
+                        nblk = l.pq_dw3x3_fwd_blocks(B, OH, OW, Cout, s)
                         self._deferred.append(('dw_fwd', i, out, nblk, src, s))
                     else:
                         raise NotImplementedError(
@@ -487,14 +487,23 @@ class Plan:
                                                      src.C, out.C)
                                 self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
                         else:
-                            need = l.pq_dw3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C)
-                            a = abi.DwWgrad(dy, src.src(), flat.grad_ptr(conv.weight), None, B, src.H, src.W, out.H, out.W,
-                                            out.C, s)
-                            idx = self._op(self.bwd, abi.OP_DW_WGRAD, a)
-                            wg_ops.append((idx, 'dww', need))
-                            d = abi.DwDgrad(dy, ptr(conv.weight), self._sink(src, l.pq_ew_blocks(src.rows, src.C)), B, src.H,
-                                            src.W, out.H, out.W, out.C, s)
-                            self._op(self.bwd, abi.OP_DW_DGRAD, d)
+                            if l.pq_dw3x3_bwd_fused_pays(src.H, src.W, s) and (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0)):
+                                # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
+                                need = l.pq_dw3x3_bwd_scratch_bytes(B, src.H, src.W, out.H, out.W, out.C, s)
+                                buf = self._new(max(need, 64) // 4 + 16)
+                                a = abi.DwBwd(dy, src.src(), ptr(conv.weight),
+                                              self._sink(src, l.pq_dw3x3_bwd_blocks(B, src.H, src.W, s)),
+                                              flat.grad_ptr(conv.weight), ptr(buf), B, src.H, src.W, out.H, out.W, out.C, s)
+                                self._op(self.bwd, abi.OP_DW_BWD, a)
+                            else:
+                                need = l.pq_dw3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C)
+                                a = abi.DwWgrad(dy, src.src(), flat.grad_ptr(conv.weight), None, B, src.H, src.W, out.H, out.W,
+                                                out.C, s)
+                                idx = self._op(self.bwd, abi.OP_DW_WGRAD, a)
+                                wg_ops.append((idx, 'dww', need))
+                                d = abi.DwDgrad(dy, ptr(conv.weight), self._sink(src, l.pq_ew_blocks(src.rows, src.C)), B, src.H,
+                                                src.W, out.H, out.W, out.C, s)
+                                self._op(self.bwd, abi.OP_DW_DGRAD, d)
                 plist = list(m.parameters())
                 if plist:
                     lo = min(flat.offsets[flat.index[id(p)]] for p in plist)

@@ -241,7 +241,7 @@ def test_conv1x1_wgrad(M, I, O, two, bias):
 
 # ----------------------------------------------------------------------------------------------- depthwise 3x3
 @pytest.mark.parametrize('B,H,W,Cc,stride', [(2, 9, 13, 32, 1), (2, 10, 14, 96, 2), (1, 7, 7, 144, 1), (2, 8, 8, 960, 1),
-                                             (1, 5, 9, 576, 2)])
+                                             (1, 5, 9, 576, 2), (2, 40, 36, 48, 2), (1, 33, 50, 16, 1)])
 def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     g = torch.Generator().manual_seed(B * H * W + Cc)
     l = abi.lib()
@@ -256,7 +256,7 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     xd, wd = x.to(DEV), w.to(DEV)
     scd, shd = chan_vec(sc), chan_vec(sh)
     out = torch.full((B, OH, OW, Cc), float('nan'), device=DEV)
-    nblk = l.pq_dw3x3_blocks(B, OH, OW, Cc)
+    nblk = l.pq_dw3x3_fwd_blocks(B, OH, OW, Cc, stride)
     ldp = Cc
     partial = torch.zeros(nblk * 2 * ldp, device=DEV)
     a = abi.DwFwd(abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), Cc, 2), wd.data_ptr(), out.data_ptr(), partial.data_ptr(),
@@ -309,6 +309,25 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     abi.check(l.pq_dw3x3_wgrad(C.byref(wg), stream()))
     torch.cuda.synchronize()
     close(dw.view(Cc, 1, 3, 3), wr.grad, rt=1e-3, at=1e-3, what='dw wgrad')
+
+    # fused, LDS-tiled backward entry point: same results from one kernel (stride 2 needs even input sizes)
+    if stride == 2 and (H % 2 or W % 2):
+        return
+    gdst2 = torch.full((B, H, W, Cc), float('nan'), device=DEV)
+    nb3 = l.pq_dw3x3_bwd_blocks(B, H, W, stride)
+    part3 = torch.zeros(nb3 * 2 * ldp, device=DEV)
+    dw2 = torch.full((Cc, 9), float('nan'), device=DEV)
+    sc2 = torch.empty(l.pq_dw3x3_bwd_scratch_bytes(B, H, W, OH, OW, Cc, stride) // 4 + 16, device=DEV)
+    fb = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(gdst2.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
+                                                         sv[1].data_ptr(), part3.data_ptr(), Cc, Cc, 2, 0, 1, ldp),
+                   dw2.data_ptr(), sc2.data_ptr(), B, H, W, OH, OW, Cc, stride)
+    abi.check(l.pq_dw3x3_bwd(C.byref(fb), stream()))
+    torch.cuda.synchronize()
+    close(gdst2, gwant, what='fused dw dgrad')
+    close(dw2.view(Cc, 1, 3, 3), wr.grad, rt=1e-3, at=1e-3, what='fused dw wgrad')
+    t1, t2 = reduce_partial(part3, nb3, ldp, Cc)
+    close(t1.float(), gwant.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum')
+    close(t2.float(), (gwant.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum xhat')
 
 
 # ----------------------------------------------------------------------------------------------- stem

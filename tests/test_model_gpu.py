@@ -60,7 +60,7 @@ def test_golden_g5_mobilenetv2_64(golden, g5_names):
     # At 64x64 / batch 2 the stride-32 BatchNorms see 8 samples per channel: fp32 round-off is amplified to a few
     # percent in the gradients (the reference's own fp32 run differs from an fp64 run by as much, see
     # test_train_step_gradients_within_fp32_noise_of_fp64_oracle), so gradient norms are only sanity-checked here.
-    np.testing.assert_allclose(gn, golden['g5_mbv2_64_gradnorm'], rtol=0.25, atol=1e-3)
+    np.testing.assert_allclose(gn, golden['g5_mbv2_64_gradnorm'], rtol=0.25, atol=1e-6 * gn.max())
     sd = net.state_dict()
     rm = [k for k in sd if k.endswith('running_mean')]
     np.testing.assert_allclose(sd[rm[0]].cpu().numpy(), golden['g5_mbv2_64_rmean_first'], rtol=1e-4, atol=1e-5)
