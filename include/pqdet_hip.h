@@ -80,7 +80,7 @@ typedef struct pq_gsink {
  *   fwd  : out[m][o] = sum_i in'[m][i] * w[o][i] (+ bias[o]);  rows m = B*H*W, optional spatial subsampling
  *          (sub>1: row (b,oy,ox) reads input pixel (b,oy*sub,ox*sub) -- strided 1x1 conv);
  *          partial!=NULL: also emit per-channel partial sums of out and out^2 (train-mode BN statistics).
- *   dgrad: dz[m][i] = sum_o dy'[m][o] * w[o][i]  -> sink
+ *   dgrad: dz[m][i] = sum_o dy'[m][o] * w[o][i]  -> sink (sub>1: scattered to the strided input pixels)
  *   wgrad: dw[o][i] = sum_m dy'[m][o] * in'[m][i]   (split over m into `splits` slabs, then reduced) */
 typedef struct pq_conv1x1_fwd_args {
     pq_src in;
@@ -100,6 +100,8 @@ typedef struct pq_conv1x1_dgrad_args {
     const float* w;      /* [O][I] */
     pq_gsink dx;
     int32_t M, I, O;
+    int32_t sub, OH, OW, IH, IW;   /* sub>1 (strided 1x1 conv): row (b,oy,ox) of dz lands on sink pixel (b,oy*sub,ox*sub); the
+                                      sink must then be accumulate-only (finalize==0) -- untouched pixels keep their value */
 } pq_conv1x1_dgrad_args;
 int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream);
 
@@ -110,6 +112,7 @@ typedef struct pq_conv1x1_wgrad_args {
     float* dbias;        /* [O] or NULL: column sums of dy' */
     float* scratch;      /* >= pq_conv1x1_wgrad_scratch_bytes(M,I,O) */
     int32_t M, I, O;
+    int32_t sub, OH, OW, IH, IW;   /* sub>1: in' rows are gathered at (b,oy*sub,ox*sub) as in the forward */
 } pq_conv1x1_wgrad_args;
 int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream);
 int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t O);
@@ -162,6 +165,42 @@ int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH
 int32_t pq_dw3x3_bwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t stride);
 /* 1 when the fused tiled backward beats pq_dw3x3_dgrad + pq_dw3x3_wgrad for this plane size (measured heuristic) */
 int32_t pq_dw3x3_bwd_fused_pays(int32_t IH, int32_t IW, int32_t stride);
+
+/* ------------------------------------------------------------------ grouped 3x3 convolution, pad 1, stride 1|2
+ * replaces nn.Conv2d(k=3, groups=C/gw) fwd/bwd in the conv blocks of model/parser.py:389-410 (regnetx-600m-fpn/pan: group
+ * width 24 in the backbone, 16 in the neck; also a dense 3x3 with C == gw <= 32).  gw % 4 == 0, gw <= 32, C % gw == 0.
+ * w is OIHW [C][gw][3][3].  Implicit GEMM on the fp32 MFMA, no im2col buffer.
+ *   fwd  : out[b,oy,ox,o] = sum_{tap,i} in'[b, oy*s+ky-1, ox*s+kx-1, grp(o)*gw+i] * w[o][i][tap]   (+ BN partial sums)
+ *   dgrad: transposed convolution of dy' -> sink (rows of the input plane)
+ *   wgrad: dw[o][i][tap] = sum_pixels dy'[p][o] * in'[p*s+tap-1][i] */
+typedef struct pq_gconv3x3_fwd_args {
+    pq_src in;
+    const float* w;
+    float* out;          /* raw, pitch ldo */
+    float* partial;      /* [pq_gconv3x3_blocks(B, OH, OW)][2][ldp] or NULL */
+    int32_t B, IH, IW, OH, OW, C, gw, stride, ldo, ldp;
+} pq_gconv3x3_fwd_args;
+int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream);
+/* partial-sum rows written by a launch over a (B, H, W) pixel grid: forward H,W = output plane; dgrad sink H,W = input plane */
+int32_t pq_gconv3x3_blocks(int32_t B, int32_t H, int32_t W);
+
+typedef struct pq_gconv3x3_dgrad_args {
+    pq_gsrc dy;          /* on the (B, OH, OW) plane */
+    const float* w;
+    pq_gsink dx;         /* on the (B, IH, IW) plane */
+    int32_t B, IH, IW, OH, OW, C, gw, stride;
+} pq_gconv3x3_dgrad_args;
+int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream);
+
+typedef struct pq_gconv3x3_wgrad_args {
+    pq_gsrc dy;
+    pq_src in;
+    float* dw;           /* [C][gw][3][3] */
+    float* scratch;      /* >= pq_gconv3x3_wgrad_scratch_bytes(B, OH, OW, C, gw) */
+    int32_t B, IH, IW, OH, OW, C, gw, stride;
+} pq_gconv3x3_wgrad_args;
+int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream);
+int64_t pq_gconv3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_t OW, int32_t C, int32_t gw);
 
 /* ------------------------------------------------------------------ network stem: dense 3x3 conv on the NCHW image
  * (3 input channels, pad 1, stride 1|2), the first section of every shipped detector cfg. */
@@ -332,7 +371,8 @@ int64_t pq_nms_scratch_bytes(int32_t N, int32_t C);
 enum {
     PQ_OP_CONV1X1_FWD = 1, PQ_OP_CONV1X1_DGRAD, PQ_OP_CONV1X1_WGRAD, PQ_OP_DW_FWD, PQ_OP_DW_DGRAD, PQ_OP_DW_WGRAD,
     PQ_OP_STEM_FWD, PQ_OP_STEM_WGRAD, PQ_OP_BN_FWD_FIN, PQ_OP_BN_BWD_FIN, PQ_OP_COPY_FWD, PQ_OP_ROUTE_BWD,
-    PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD
+    PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD,
+    PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -343,6 +383,7 @@ typedef struct pq_op {
         pq_conv1x1_fwd_args c1f; pq_conv1x1_dgrad_args c1d; pq_conv1x1_wgrad_args c1w;
         pq_dw3x3_fwd_args dwf; pq_dw3x3_dgrad_args dwd; pq_dw3x3_wgrad_args dww; pq_dw3x3_bwd_args dwb;
         pq_stem3x3_fwd_args stf; pq_stem3x3_wgrad_args stw;
+        pq_gconv3x3_fwd_args gcf; pq_gconv3x3_dgrad_args gcd; pq_gconv3x3_wgrad_args gcw;
         pq_bn_fwd_finalize_args bnf; pq_bn_bwd_finalize_args bnb;
         pq_copy_args cp; pq_route_bwd_args rb;
         pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill;

@@ -42,12 +42,30 @@ class Conv1x1Fwd(C.Structure):
 
 
 class Conv1x1Dgrad(C.Structure):
-    _fields_ = [('dy', GSrc), ('w', c_fp), ('dx', GSink), ('M', i32), ('I', i32), ('O', i32)]
+    _fields_ = [('dy', GSrc), ('w', c_fp), ('dx', GSink), ('M', i32), ('I', i32), ('O', i32),
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32)]
 
 
 class Conv1x1Wgrad(C.Structure):
     _fields_ = [('dy', GSrc), ('inp', Src), ('dw', c_fp), ('dbias', c_fp), ('scratch', c_fp),
-                ('M', i32), ('I', i32), ('O', i32)]
+                ('M', i32), ('I', i32), ('O', i32),
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32)]
+
+
+class GconvFwd(C.Structure):
+    _fields_ = [('inp', Src), ('w', c_fp), ('out', c_fp), ('partial', c_fp),
+                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('gw', i32), ('stride', i32),
+                ('ldo', i32), ('ldp', i32)]
+
+
+class GconvDgrad(C.Structure):
+    _fields_ = [('dy', GSrc), ('w', c_fp), ('dx', GSink),
+                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('gw', i32), ('stride', i32)]
+
+
+class GconvWgrad(C.Structure):
+    _fields_ = [('dy', GSrc), ('inp', Src), ('dw', c_fp), ('scratch', c_fp),
+                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('gw', i32), ('stride', i32)]
 
 
 class DwFwd(C.Structure):
@@ -151,7 +169,8 @@ class _OpU(C.Union):
     _fields_ = [('c1f', Conv1x1Fwd), ('c1d', Conv1x1Dgrad), ('c1w', Conv1x1Wgrad),
                 ('dwf', DwFwd), ('dwd', DwDgrad), ('dww', DwWgrad), ('dwb', DwBwd), ('stf', StemFwd), ('stw', StemWgrad),
                 ('bnf', BnFwdFin), ('bnb', BnBwdFin), ('cp', Copy), ('rb', RouteBwd),
-                ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill)]
+                ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
+                ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad)]
 
 
 OPF_SIDE = 1
@@ -162,13 +181,14 @@ class Op(C.Structure):
 
 
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
- OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD) = range(1, 19)
+ OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
+ OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD) = range(1, 22)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
     OP_DW_WGRAD: 'dww', OP_STEM_FWD: 'stf', OP_STEM_WGRAD: 'stw', OP_BN_FWD_FIN: 'bnf', OP_BN_BWD_FIN: 'bnb',
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
-    OP_FILL: 'fill', OP_DW_BWD: 'dwb',
+    OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -188,6 +208,11 @@ SIGNATURES = {
     'pq_dw3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32]),
     'pq_dw3x3_bwd': (C.c_int, [C.POINTER(DwBwd), C.c_void_p]),
     'pq_dw3x3_bwd_scratch_bytes': (i64, [i32, i32, i32, i32, i32, i32, i32]),
+    'pq_gconv3x3_fwd': (C.c_int, [C.POINTER(GconvFwd), C.c_void_p]),
+    'pq_gconv3x3_blocks': (i32, [i32, i32, i32]),
+    'pq_gconv3x3_dgrad': (C.c_int, [C.POINTER(GconvDgrad), C.c_void_p]),
+    'pq_gconv3x3_wgrad': (C.c_int, [C.POINTER(GconvWgrad), C.c_void_p]),
+    'pq_gconv3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32, i32]),
     'pq_stem3x3_fwd': (C.c_int, [C.POINTER(StemFwd), C.c_void_p]),
     'pq_stem3x3_wgrad': (C.c_int, [C.POINTER(StemWgrad), C.c_void_p]),
     'pq_stem3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32, i32]),

@@ -18,6 +18,7 @@ SOURCES = {            # file -> extra flags
     'gemm.hip': [],
     'dwconv.hip': [],
     'dwtile.hip': [],
+    'gconv.hip': [],
     'ew.hip': [],
     'yolo.hip': [],
     'post.hip': ['-ffp-contract=off'],   # NMS comparisons must not see FMA contraction (bit-exact selection)

@@ -37,6 +37,9 @@ static int run_one(const pq_op& op, void* stream) {
         case PQ_OP_ADAM: return pq_adam_step(&op.u.adam, stream);
         case PQ_OP_FILL: return pq_fill(op.u.fill.dst, op.u.fill.value, op.u.fill.n, stream);
         case PQ_OP_DW_BWD: return pq_dw3x3_bwd(&op.u.dwb, stream);
+        case PQ_OP_GCONV_FWD: return pq_gconv3x3_fwd(&op.u.gcf, stream);
+        case PQ_OP_GCONV_DGRAD: return pq_gconv3x3_dgrad(&op.u.gcd, stream);
+        case PQ_OP_GCONV_WGRAD: return pq_gconv3x3_wgrad(&op.u.gcw, stream);
         default:
             pq_set_error("pq_run_ops: unknown op code %d", op.code);
             return PQ_EINVAL;
@@ -137,6 +140,9 @@ extern "C" int32_t pq_abi_sizeof(int32_t code) {
         case PQ_OP_ADAM: return (int32_t)sizeof(pq_adam_args);
         case PQ_OP_FILL: return (int32_t)sizeof(pq_fill_args);
         case PQ_OP_DW_BWD: return (int32_t)sizeof(pq_dw3x3_bwd_args);
+        case PQ_OP_GCONV_FWD: return (int32_t)sizeof(pq_gconv3x3_fwd_args);
+        case PQ_OP_GCONV_DGRAD: return (int32_t)sizeof(pq_gconv3x3_dgrad_args);
+        case PQ_OP_GCONV_WGRAD: return (int32_t)sizeof(pq_gconv3x3_wgrad_args);
         case 100: return (int32_t)sizeof(pq_recover_args);
         case 101: return (int32_t)sizeof(pq_nms_args);
         case 102: return (int32_t)sizeof(pq_decode_bwd_args);

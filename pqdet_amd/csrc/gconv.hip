@@ -1,0 +1,437 @@
+// Grouped / dense 3x3 convolution (pad 1, stride 1|2, group width a multiple of 4 and <= 32) as an implicit GEMM on the
+// fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.  RegNetX: group width 24 (backbone) and 16 (neck).
+//
+// A workgroup owns an 8x16 tile of output pixels (4 waves x 32 pixels) of ONE group.  The input tile with halo is staged
+// once into LDS ([pixel][channel quad], operand transform applied at staging time, zero padding after the transform); no
+// im2col buffer exists: for tap (ky,kx) and channel quad the MFMA A fragment of a lane is one ds_read_b128 at
+// ((py*S+ky)*ITW + px*S+kx) * pitch + quad.  The group's weights are gathered once per workgroup into a [32][9*gw] LDS image
+// with k = tap*gw + i.  K = 9*gw is consumed in 8-wide steps (gw is a multiple of 8 or 4 -> steps never straddle a tap when
+// gw % 8 == 0; for gw % 8 == 4 the kernel uses 4-wide steps).
+//
+// The same kernel is the data gradient: A = dy' (closed-form BN backward applied at staging), weights gathered transposed
+// and flipped, output through the gradient sink.  For stride 2 the dy' plane is read as its zero-inserted upsampling
+// (u even ? dy'[u/2] : 0), which turns the transposed convolution into the stride-1 form.
+//
+// wgrad: dw[o][i][tap] = sum_p dy'[p][o] * x'[p*S+tap-1][i] -- persistent workgroups walk pixel tiles of one group, the
+// four waves split the pixels of a tile (split-K), 32 x (9*gw) accumulators per wave, deterministic two-level reduction.
+#include "common.h"
+
+namespace pq {
+
+struct GcP {
+    // operand (forward: src; backward: gsrc) living on an AH x AW plane with C channels
+    pq_src in; pq_gsrc dy; int grad;      // grad = 1: A operand is dy'
+    int up;                               // dgrad of a stride-2 conv: A(u,v) = dy'(u/2, v/2) if both even else 0 (plane DH x DW)
+    int DH, DW;                           // real dy plane when up
+    const float* w; int wmode;            // 0: forward B[o][tap*gw+i] = w[go+o][i][tap]; 1: dgrad B[i][tap*gw+o] = w[go+o][i][8-tap]
+    float* out; float* partial; int ldo, ldp;
+    pq_gsink sink;
+    int B, AH, AW, OH, OW, C, gw, S, tilesH, tilesW;
+};
+
+constexpr int GTH = 8, GTW = 16;          // output tile
+
+__device__ __forceinline__ f32x16 gmfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+template <int EMODE>     // 1: raw store + BN statistics, 2: gradient sink
+__global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int gw = p.gw, gq = gw >> 2, pitch = gq + 1;          // quads per pixel (+1 pad)
+    const int K = 9 * gw, KP = K + 4;
+    const int S = p.S;
+    const int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3;
+    float4* At = reinterpret_cast<float4*>(smem);                       // [ITH*ITW][pitch]
+    float* Bt = smem + (size_t)ITH * ITW * pitch * 4;                   // [32][KP]
+    float* red = Bt + 32 * KP;                                          // [2][4][32]
+
+    const int tIdx = blockIdx.x;
+    const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
+    const int g = blockIdx.y;
+    const int oy0 = th * GTH, ox0 = tw * GTW;
+    const int ay0 = oy0 * S - 1, ax0 = ox0 * S - 1;
+    const int cbase = g * gw;
+
+    // ---- stage A (operand tile with halo)
+    const int npix = ITH * ITW;
+    const ActParam aact = act_param(p.in.act);
+    for (int e = t; e < npix * gq; e += 256) {
+        const int pix = e / gq, qd = e - pix * gq;
+        const int py = pix / ITW, px = pix - py * ITW;
+        const int ay = ay0 + py, ax = ax0 + px;
+        const int c = cbase + 4 * qd;
+        bool ok = ay >= 0 && ay < p.AH && ax >= 0 && ax < p.AW;
+        float4 v = f4zero();
+        if (!p.grad) {
+            if (ok) {
+                const float4 r = ldg4(p.in.x + (((size_t)b * p.AH + ay) * p.AW + ax) * p.in.ld + c);
+                float e4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sc = p.in.scale ? p.in.scale[c + j] : 1.f, sh = p.in.scale ? p.in.shift[c + j] : 0.f;
+                    e4[j] = act_fwd(fmaf(sc, e4[j], sh), aact);
+                }
+                v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            }
+        } else {
+            int dyy = ay, dxx = ax;
+            if (p.up) { ok = ok && !(ay & 1) && !(ax & 1); dyy = ay >> 1; dxx = ax >> 1; ok = ok && dyy < p.DH && dxx < p.DW; }
+            if (ok) {
+                const int PH = p.up ? p.DH : p.AH, PW = p.up ? p.DW : p.AW;
+                const size_t r = ((size_t)b * PH + dyy) * PW + dxx;
+                const float4 gg = ldg4(p.dy.g + r * p.dy.ldg + c);
+                float e4[4] = {gg.x, gg.y, gg.z, gg.w};
+                if (p.dy.y) {
+                    const float4 yy = ldg4(p.dy.y + r * p.dy.ldy + c);
+                    const float y4[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        e4[j] = fmaf(p.dy.p[c + j], e4[j], fmaf(p.dy.q[c + j], y4[j] - p.dy.mu[c + j], p.dy.r[c + j]));
+                }
+                v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            }
+        }
+        At[pix * pitch + qd] = v;
+    }
+    // ---- stage B (this group's weights, k = tap*gw + i)
+    for (int e = t; e < 32 * K; e += 256) {
+        const int n = e / K, k = e - n * K;
+        const int tap = k / gw, j = k - tap * gw;
+        float v = 0.f;
+        if (n < gw) {
+            if (p.wmode == 0) v = p.w[((size_t)(cbase + n) * gw + j) * 9 + tap];           // n = o, j = i
+            else v = p.w[((size_t)(cbase + j) * gw + n) * 9 + (8 - tap)];                  // n = i, j = o, flipped tap
+        }
+        Bt[n * KP + k] = v;
+    }
+    __syncthreads();
+
+    // ---- MFMA: wave wv owns pixels 32*wv .. +31 of the tile (two tile rows), all 32 (padded) output channels
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int pp = 32 * wv + lrow, py = pp >> 4, px = pp & 15;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float4* bq = reinterpret_cast<const float4*>(Bt);
+    const int KPq = KP >> 2;
+    if ((gw & 7) == 0) {
+        const int steps = gw >> 3;                  // 8-wide k steps per tap
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const float4* arow = At + ((py * S + ky) * ITW + px * S + kx) * pitch;
+            const float4* brow = bq + lrow * KPq + (tap * gw >> 2);
+            for (int s = 0; s < steps; ++s) {
+                const float4 af = arow[2 * s + lh];
+                const float4 bf = brow[2 * s + lh];
+                acc = gmfma(af.x, bf.x, acc);
+                acc = gmfma(af.y, bf.y, acc);
+                acc = gmfma(af.z, bf.z, acc);
+                acc = gmfma(af.w, bf.w, acc);
+            }
+        }
+    } else {
+        // gw % 8 == 4: 4-wide steps, lane half h takes k pair (2h, 2h+1) of the quad
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const float* arow = reinterpret_cast<const float*>(At + ((py * S + ky) * ITW + px * S + kx) * pitch);
+            const float* brow = Bt + lrow * KP + tap * gw;
+            for (int s = 0; s < gq; ++s) {
+                const float a0 = arow[4 * s + 2 * lh], a1 = arow[4 * s + 2 * lh + 1];
+                const float b0 = brow[4 * s + 2 * lh], b1 = brow[4 * s + 2 * lh + 1];
+                acc = gmfma(a0, b0, acc);
+                acc = gmfma(a1, b1, acc);
+            }
+        }
+    }
+
+    // ---- epilogue: C row = pixel (r&3) + 8*(r>>2) + 4*lh of this wave's 32, column = channel lrow (< gw valid)
+    const int n = lrow;
+    const bool nok = n < gw;
+    const int ch = cbase + (nok ? n : 0);
+    float s1 = 0.f, s2 = 0.f;
+    bool want_stats = false;
+    if (EMODE == 1) {
+        want_stats = p.partial != nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
+            if (nok && oy < p.OH && ox < p.OW) {
+                const float v = acc[r];
+                p.out[(((size_t)b * p.OH + oy) * p.OW + ox) * p.ldo + ch] = v;
+                s1 += v; s2 = fmaf(v, v, s2);
+            }
+        }
+    } else {
+        const pq_gsink& sk = p.sink;
+        const bool affine = sk.scale != nullptr;
+        const bool stats = sk.mean != nullptr && sk.partial != nullptr;
+        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
+        want_stats = sk.finalize && stats;
+        const ActParam sact = act_param(sk.act);
+        const float ca = affine ? sk.scale[ch] : 1.f, cb = affine ? sk.shift[ch] : 0.f;
+        const float cm = stats ? sk.mean[ch] : 0.f, ci = stats ? sk.invstd[ch] : 0.f;
+        float yv[16], gv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int oy = min(oy0 + (q >> 4), p.OH - 1), ox = min(ox0 + (q & 15), p.OW - 1);
+            const size_t row = ((size_t)b * p.OH + oy) * p.OW + ox;
+            yv[r] = need_y ? sk.y[row * sk.ldy + ch] : 0.f;
+            gv[r] = sk.accumulate ? sk.g[row * sk.ldg + ch] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
+            float dz = acc[r] + gv[r];
+            if (need_y) dz *= act_bwd(fmaf(ca, yv[r], cb), sact);
+            if (nok && oy < p.OH && ox < p.OW) {
+                sk.g[(((size_t)b * p.OH + oy) * p.OW + ox) * sk.ldg + ch] = dz;
+                if (stats) { s1 += dz; s2 = fmaf(dz, (yv[r] - cm) * ci, s2); }
+            }
+        }
+    }
+    if (want_stats) {       // uniform
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0) { red[(0 * 4 + wv) * 32 + lrow] = s1; red[(1 * 4 + wv) * 32 + lrow] = s2; }
+        __syncthreads();
+        if (t < 32 && t < gw) {
+            float a = 0.f, bsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a += red[(0 * 4 + q) * 32 + t]; bsum += red[(1 * 4 + q) * 32 + t]; }
+            float* part = (EMODE == 2) ? p.sink.partial : p.partial;
+            const int ldp = (EMODE == 2) ? p.sink.ldp : p.ldp;
+            float* dst = part + (size_t)blockIdx.x * 2 * ldp;
+            dst[cbase + t] = a;
+            dst[ldp + cbase + t] = bsum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct GcWP {
+    pq_gsrc dy; pq_src in;
+    float* partial;          // [G][nsplit][gw][9*gw]   (k = tap*gw + i)
+    int B, IH, IW, OH, OW, C, gw, S, tilesH, tilesW, nsplit;
+};
+
+template <int NC>      // 32-wide column chunks of the (tap, i) axis: ceil(9*gw/32) <= NC
+__global__ __launch_bounds__(256) void gconv_wgrad_kernel(GcWP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int gw = p.gw, gq = gw >> 2, pitch = gq + 1, S = p.S;
+    const int K = 9 * gw, NCH = (K + 31) / 32;
+    const int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3;
+    float* Xt = smem;                                            // [ITH*ITW][pitch*4]
+    float* Yt = Xt + (size_t)ITH * ITW * pitch * 4;              // [128][32]  dy' (o padded to 32)
+    float* red = Yt + 128 * 32;                                  // [4][32*32]
+    const int g = blockIdx.x, split = blockIdx.y;
+    const int cbase = g * gw;
+    const int ntiles = p.B * p.tilesH * p.tilesW;
+    const ActParam aact = act_param(p.in.act);
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    // per-lane decode of its B column j = 32*c + lrow -> (tap, i) -> LDS offset relative to the pixel's tile origin
+    int boff[NC];
+    bool bok[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int k = 32 * c + lrow;
+        bok[c] = c < NCH && k < K;
+        const int kk = bok[c] ? k : 0;
+        const int tap = kk / gw, i = kk - tap * gw;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        boff[c] = (ky * ITW + kx) * pitch * 4 + i;
+    }
+
+    for (int tile = split; tile < ntiles; tile += p.nsplit) {
+        const int tw = tile % p.tilesW, th = (tile / p.tilesW) % p.tilesH, b = tile / (p.tilesW * p.tilesH);
+        const int oy0 = th * GTH, ox0 = tw * GTW;
+        const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        __syncthreads();
+        // stage x' tile
+        for (int e = t; e < ITH * ITW * gq; e += 256) {
+            const int pix = e / gq, qd = e - pix * gq;
+            const int py = pix / ITW, px = pix - py * ITW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const int c = cbase + 4 * qd;
+            float4 v = f4zero();
+            if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) {
+                const float4 r = ldg4(p.in.x + (((size_t)b * p.IH + iy) * p.IW + ix) * p.in.ld + c);
+                float e4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sc = p.in.scale ? p.in.scale[c + j] : 1.f, sh = p.in.scale ? p.in.shift[c + j] : 0.f;
+                    e4[j] = act_fwd(fmaf(sc, e4[j], sh), aact);
+                }
+                v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            }
+            *reinterpret_cast<float4*>(&Xt[(pix * pitch + qd) * 4]) = v;
+        }
+        // stage dy' tile: [pixel 0..127][o 0..31]
+        for (int e = t; e < 128 * 8; e += 256) {
+            const int pix = e >> 3, qd = e & 7;
+            const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+            float4 v = f4zero();
+            if (qd < gq && oy < p.OH && ox < p.OW) {
+                const int c = cbase + 4 * qd;
+                const size_t r = ((size_t)b * p.OH + oy) * p.OW + ox;
+                const float4 gg = ldg4(p.dy.g + r * p.dy.ldg + c);
+                float e4[4] = {gg.x, gg.y, gg.z, gg.w};
+                if (p.dy.y) {
+                    const float4 yy = ldg4(p.dy.y + r * p.dy.ldy + c);
+                    const float y4[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        e4[j] = fmaf(p.dy.p[c + j], e4[j], fmaf(p.dy.q[c + j], y4[j] - p.dy.mu[c + j], p.dy.r[c + j]));
+                }
+                v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            }
+            *reinterpret_cast<float4*>(&Yt[pix * 32 + 4 * qd]) = v;
+        }
+        __syncthreads();
+        // wave wv: pixels 32*wv .. +31 (k dimension), 16 steps of 2 pixels
+        for (int ks = 0; ks < 16; ++ks) {
+            const int pp = 32 * wv + 2 * ks + lh;
+            const int py = pp >> 4, px = pp & 15;
+            const float a = Yt[pp * 32 + lrow];
+            const float* xb = Xt + ((py * S) * ITW + px * S) * pitch * 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (c < NCH) {
+                    const float bv = bok[c] ? xb[boff[c]] : 0.f;
+                    acc[c] = gmfma(a, bv, acc[c]);
+                }
+            }
+        }
+    }
+    // reduce the four waves' accumulators chunk by chunk; D[o][j]: row o = (r&3)+8*(r>>2)+4*lh, column j = lrow
+    float* dst = p.partial + ((size_t)(g * p.nsplit + split) * gw) * K;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < NCH) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wv * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lrow] = acc[c][r];
+            __syncthreads();
+            for (int e = t; e < 1024; e += 256) {
+                const int o = e >> 5, j = e & 31;
+                const int k = 32 * c + j;
+                if (o < gw && k < K) dst[(size_t)o * K + k] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+            }
+        }
+    }
+}
+
+// dw[(cbase+o)][i][tap] = sum_split partial[g][split][o][tap*gw+i]
+__global__ void gconv_wgrad_reduce_kernel(const float* partial, int G, int nsplit, int gw, float* dw) {
+    const int K = 9 * gw;
+    const int total = G * gw * K;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int k = e % K, o = (e / K) % gw, g = e / (K * gw);
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)(g * nsplit + sp) * gw + o) * K + k];
+        const int tap = k / gw, i = k - tap * gw;
+        dw[((size_t)(g * gw + o) * gw + i) * 9 + tap] = s;
+    }
+}
+
+}  // namespace pq
+
+using namespace pq;
+
+static int gc_check(int B, int IH, int IW, int OH, int OW, int C, int gw, int stride) {
+    if (B <= 0 || IH <= 0 || IW <= 0 || C <= 0 || gw <= 0 || gw > 32 || (gw & 3) || C % gw) return 0;
+    if (stride != 1 && stride != 2) return 0;
+    return OH == (IH - 1) / stride + 1 && OW == (IW - 1) / stride + 1;
+}
+static size_t gc_lds_bytes(int gw, int S) {
+    const int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3, pitch = gw / 4 + 1;
+    return ((size_t)ITH * ITW * pitch * 4 + 32 * (9 * gw + 4) + 2 * 4 * 32) * sizeof(float);
+}
+extern "C" int32_t pq_gconv3x3_blocks(int32_t B, int32_t H, int32_t W) { return B * ((H + GTH - 1) / GTH) * ((W + GTW - 1) / GTW); }
+
+extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->in.x && a->w && a->out, "null pointer");
+    PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape (group width multiple of 4 and <= 32, stride 1|2, pad 1)");
+    PQ_CHECK_ARG((a->in.ld & 3) == 0, "input pitch must be a multiple of 4");
+    if (act_is_special(a->in.act)) { pq_set_error("pq_gconv3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
+    GcP p{};
+    p.in = a->in; p.grad = 0; p.up = 0; p.w = a->w; p.wmode = 0; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
+    p.B = a->B; p.AH = a->IH; p.AW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.gw = a->gw; p.S = a->stride;
+    p.tilesH = (a->OH + GTH - 1) / GTH; p.tilesW = (a->OW + GTW - 1) / GTW;
+    const size_t lds = gc_lds_bytes(a->gw, a->stride);
+    hipFuncSetAttribute((const void*)gconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((gconv_kernel<1>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->dy.g && a->w && a->dx.g, "null pointer");
+    PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape (group width multiple of 4 and <= 32, stride 1|2, pad 1)");
+    PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    if (act_is_special(a->dx.act)) { pq_set_error("pq_gconv3x3_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }
+    GcP p{};
+    p.dy = a->dy; p.grad = 1; p.w = a->w; p.wmode = 1; p.sink = a->dx;
+    p.up = a->stride == 2; p.DH = a->OH; p.DW = a->OW;
+    // the transposed conv runs as a stride-1 conv over the (zero-inserted) dy plane laid out on the INPUT grid
+    p.B = a->B; p.AH = a->IH; p.AW = a->IW; p.OH = a->IH; p.OW = a->IW; p.C = a->C; p.gw = a->gw; p.S = 1;
+    if (a->stride == 1) { p.AH = a->OH; p.AW = a->OW; }
+    p.tilesH = (a->IH + GTH - 1) / GTH; p.tilesW = (a->IW + GTW - 1) / GTW;
+    const size_t lds = gc_lds_bytes(a->gw, 1);
+    hipFuncSetAttribute((const void*)gconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((gconv_kernel<2>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+static int gc_nsplit(int ntiles, int G) {
+    int want = (512 + G - 1) / G;
+    if (want > ntiles) want = ntiles;
+    if (want < 1) want = 1;
+    return want;
+}
+extern "C" int64_t pq_gconv3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_t OW, int32_t C, int32_t gw) {
+    const int G = C / gw, ntiles = pq_gconv3x3_blocks(B, OH, OW);
+    return (int64_t)G * gc_nsplit(ntiles, G) * gw * 9 * gw * 4;
+}
+
+extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->dw && a->scratch, "null pointer");
+    PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape (group width multiple of 4 and <= 32, stride 1|2, pad 1)");
+    if (act_is_special(a->in.act)) { pq_set_error("pq_gconv3x3_wgrad: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
+    GcWP p{};
+    p.dy = a->dy; p.in = a->in; p.partial = a->scratch;
+    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.gw = a->gw; p.S = a->stride;
+    p.tilesH = (a->OH + GTH - 1) / GTH; p.tilesW = (a->OW + GTW - 1) / GTW;
+    const int G = a->C / a->gw, ntiles = a->B * p.tilesH * p.tilesW;
+    p.nsplit = gc_nsplit(ntiles, G);
+    const int S = a->stride, ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3, pitch = a->gw / 4 + 1;
+    const size_t lds = ((size_t)ITH * ITW * pitch * 4 + 128 * 32 + 4 * 1024) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (9 * a->gw + 31) / 32;
+    if (nch <= 5) {
+        hipFuncSetAttribute((const void*)gconv_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(gconv_wgrad_kernel<5>, dim3(G, p.nsplit), dim3(256), lds, st, p);
+    } else if (nch <= 7) {
+        hipFuncSetAttribute((const void*)gconv_wgrad_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(gconv_wgrad_kernel<7>, dim3(G, p.nsplit), dim3(256), lds, st, p);
+    } else {
+        hipFuncSetAttribute((const void*)gconv_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(gconv_wgrad_kernel<9>, dim3(G, p.nsplit), dim3(256), lds, st, p);
+    }
+    PQ_CHECK_LAUNCH();
+    const int total = G * a->gw * 9 * a->gw;
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)a->scratch, G, p.nsplit, a->gw, a->dw);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}

@@ -21,7 +21,7 @@ struct GemmP {
     const float* a0; const float* a1;          // x | g , y
     const float* c0; const float* c1; const float* c2; const float* c3;   // scale,shift | p,q,mu,r
     int lda0, lda1, act;
-    int sub, OH, OW, IH, IW;                    // strided row gather (forward only)
+    int sub, OH, OW, IH, IW;                    // strided 1x1 conv: forward gathers A rows, the sink epilogue scatters rows
     // B operand
     const float* b; int ldb;
     int M, N, K;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         int m = m0 + ar0 + 32 * i;
         avalid[i] = m < M;
         size_t src = (size_t)(avalid[i] ? m : 0);
-        if (p.sub > 1) {
+        if (EMODE != 2 && p.sub > 1) {
             int ox = (int)(src % p.OW); size_t tt = src / p.OW; int oy = (int)(tt % p.OH); size_t bb = tt / p.OH;
             src = (bb * p.IH + (size_t)oy * p.sub) * p.IW + (size_t)ox * p.sub;
         }
@@ -300,11 +300,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             for (int i = 0; i < TI; ++i) {
                 // batch the 16 (y, old g) loads of this 32x32 tile at clamped addresses, then compute and store
                 float yv[16], gv[16];
+                size_t srow[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mc = min(m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
-                    yv[r] = need_y ? sk.y[(size_t)mc * sk.ldy + nc] : 0.f;
-                    gv[r] = sk.accumulate ? sk.g[(size_t)mc * sk.ldg + nc] : 0.f;
+                    srow[r] = (size_t)mc;
+                    if (p.sub > 1) {      // strided 1x1 conv: output row (b,oy,ox) scatters to input pixel (b,oy*sub,ox*sub)
+                        const int ox = mc % p.OW, tt = mc / p.OW, oy = tt % p.OH, bb = tt / p.OH;
+                        srow[r] = ((size_t)bb * p.IH + (size_t)oy * p.sub) * p.IW + (size_t)ox * p.sub;
+                    }
+                    yv[r] = need_y ? sk.y[srow[r] * sk.ldy + nc] : 0.f;
+                    gv[r] = sk.accumulate ? sk.g[srow[r] * sk.ldg + nc] : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                         dz *= act_bwd(u, sact);
                     }
                     if (m < M && nok) {
-                        sk.g[(size_t)m * sk.ldg + n] = dz;
+                        sk.g[srow[r] * sk.ldg + n] = dz;
                         if (stats) { s1[j] += dz; s2[j] = fmaf(dz, (yv[r] - cm) * ci, s2[j]); }
                     }
                 }
@@ -375,6 +381,7 @@ struct GemmTP {
     float* slab;       // [splits][O*I (+O bias)] or final when splits==1
     int M, O, I, rows_per_split, want_bias;
     size_t slab_stride;
+    int sub, OH, OW, IH, IW;     // strided 1x1 conv: x rows are gathered at (b, oy*sub, ox*sub)
 };
 
 template <int BO, int BIc>
@@ -421,7 +428,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTP p) {
 #pragma unroll
             for (int l = 0; l < IL; ++l) {
                 const int m = min(mb + xr0 + IRP * l, mend - 1);
-                rx[l] = ldg4(p.x.x + (size_t)m * p.x.ld + icl);
+                size_t xr = (size_t)m;
+                if (p.sub > 1) {
+                    const int ox = m % p.OW, tt = m / p.OW, oy = tt % p.OH, bb = tt / p.OH;
+                    xr = ((size_t)bb * p.IH + (size_t)oy * p.sub) * p.IW + (size_t)ox * p.sub;
+                }
+                rx[l] = ldg4(p.x.x + xr * p.x.ld + icl);
             }
         }
     };
@@ -611,10 +623,15 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "gradient pitch must be a multiple of 4");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_conv1x1_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }
+    if (a->sub > 1) {
+        PQ_CHECK_ARG(a->OH > 0 && a->OW > 0 && a->M % (a->OH * a->OW) == 0, "strided dgrad: M must be B*OH*OW");
+        PQ_CHECK_ARG((a->OH - 1) * a->sub < a->IH && (a->OW - 1) * a->sub < a->IW, "strided dgrad: input plane too small");
+        PQ_CHECK_ARG(!a->dx.finalize, "strided dgrad: the sink must be accumulate-only (finalize it with pq_route_bwd)");
+    }
     GemmP p{};
     p.a0 = a->dy.g; p.a1 = a->dy.y; p.lda0 = a->dy.ldg; p.lda1 = a->dy.ldy;
     p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
-    p.sub = 1;
+    p.sub = a->sub > 1 ? a->sub : 1; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->I; p.K = a->O;
     p.sink = a->dx;
     hipStream_t st = (hipStream_t)stream;
@@ -651,6 +668,11 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
     GemmTP p{};
     p.dy = a->dy; p.x = a->in; p.slab = a->scratch; p.M = a->M; p.O = a->O; p.I = a->I;
     p.rows_per_split = rows; p.want_bias = a->dbias != nullptr;
+    p.sub = a->sub > 1 ? a->sub : 1; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
+    if (a->sub > 1) {
+        PQ_CHECK_ARG(a->OH > 0 && a->OW > 0 && a->M % (a->OH * a->OW) == 0, "strided wgrad: M must be B*OH*OW");
+        PQ_CHECK_ARG((a->OH - 1) * a->sub < a->IH && (a->OW - 1) * a->sub < a->IW, "strided wgrad: input plane too small");
+    }
     p.slab_stride = (size_t)a->O * a->I + a->O;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(tiles, splits), blk(256);

@@ -214,7 +214,7 @@ class Plan:
                 use(resolve(m._from, i))
             elif t == 'route':
                 srcs = [resolve(j, i) for j in m._layers]
-                if m.single:
+                if m.single or len(srcs) == 1:     # a one-source route is the source itself (cat of one tensor)
                     alias[i] = srcs[0]
                     h, w, c = shapes[srcs[0]]
                 else:
@@ -280,10 +280,14 @@ class Plan:
                     elif k == 3 and groups == Cin == Cout and conv.padding[0] == 1:
                         nblk = l.pq_dw3x3_fwd_blocks(B, OH, OW, Cout, s)
                         self._deferred.append(('dw_fwd', i, out, nblk, src, s))
+                    elif (k == 3 and conv.padding[0] == 1 and Cin == Cout and Cin % groups == 0 and
+                          (Cin // groups) % 4 == 0 and Cin // groups <= 32 and s in (1, 2) and conv.bias is None):
+                        nblk = l.pq_gconv3x3_blocks(B, OH, OW)
+                        self._deferred.append(('gc_fwd', i, out, nblk, src, s))
                     else:
                         raise NotImplementedError(
-                            'conv k=%d groups=%d (%d->%d) has no HIP kernel yet (dense/grouped 3x3 is a later row)' %
-                            (k, groups, Cin, Cout))
+                            'conv k=%d groups=%d (%d->%d) has no HIP kernel yet (3x3 convs need equal in/out channels and a '
+                            'group width that is a multiple of 4 and at most 32)' % (k, groups, Cin, Cout))
                 if bn is not None:
                     bn.fwd_nblk = nblk
                     if want_stats:
@@ -298,7 +302,7 @@ class Plan:
                 T.append(out)
             elif t == 'route':
                 srcs = [T[resolve(j, i)] for j in m._layers]
-                if m.single:
+                if m.single or len(srcs) == 1:
                     T.append(srcs[0])
                 else:
                     Ctot = sum(s_.C for s_ in srcs)
@@ -364,6 +368,13 @@ class Plan:
                 a = abi.DwFwd(src.src(), ptr(conv.weight), ptr(out.raw), ptr(part), B, src.H, src.W, out.H, out.W, out.C, s,
                               out.ld, out.bn.ldp if out.bn else 0)
                 self._op(self.fwd, abi.OP_DW_FWD, a)
+            elif kind == 'gc_fwd':
+                _, i, out, nblk, src, s = item
+                conv = mods[i].conv
+                part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
+                a = abi.GconvFwd(src.src(), ptr(conv.weight), ptr(out.raw), ptr(part), B, src.H, src.W, out.H, out.W, out.C,
+                                 out.C // conv.groups, s, out.ld, out.bn.ldp if out.bn else 0)
+                self._op(self.fwd, abi.OP_GCONV_FWD, a)
             elif kind == 'bn_fwd':
                 _, i, out = item
                 b = out.bn
@@ -474,18 +485,42 @@ class Plan:
                     else:
                         src = T[resolve(i - 1, i)]
                         if k == 1:
-                            if s != 1:
-                                raise NotImplementedError('backward of a strided 1x1 conv is not implemented yet')
                             need = l.pq_conv1x1_wgrad_scratch_bytes(out.rows, src.C, out.C)
                             a = abi.Conv1x1Wgrad(dy, src.src(), flat.grad_ptr(conv.weight),
                                                  flat.grad_ptr(conv.bias) if conv.bias is not None else None, None,
-                                                 out.rows, src.C, out.C)
+                                                 out.rows, src.C, out.C, s, out.H, out.W, src.H, src.W)
                             idx = self._op(self.bwd, abi.OP_CONV1X1_WGRAD, a)
                             wg_ops.append((idx, 'c1w', need))
-                            if src.needs_grad:
+                            if src.needs_grad and s == 1:
                                 d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), self._sink(src, l.pq_conv1x1_blocks(src.rows, src.C)), out.rows,
                                                      src.C, out.C)
                                 self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
+                            elif src.needs_grad:
+                                # strided 1x1: dz only lands on every s-th pixel.  The GEMM accumulates into a (zeroed if it
+                                # is the first contribution) gradient plane; if it was the last contribution an in-place
+                                # element-wise pass finalises the whole plane (activation derivative + BN sums).
+                                sk = self._sink(src, l.pq_ew_blocks(src.rows, src.C))
+                                if not sk.accumulate:
+                                    self._op(self.bwd, abi.OP_FILL, abi.Fill(ptr(src.grad), 0.0, src.rows * src.ld))
+                                acc = abi.GSink(sk.g, sk.y, None, None, None, None, None, src.ld, src.ld, 0, 1, 0, 0)
+                                d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), acc, out.rows, src.C, out.C, s, out.H, out.W, src.H,
+                                                     src.W)
+                                self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
+                                if sk.finalize:
+                                    sk.accumulate = 0
+                                    r = abi.RouteBwd(ptr(src.grad), sk, src.B, src.H, src.W, src.C, src.ld, 0, 1)
+                                    self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+                        elif conv.groups != conv.in_channels or conv.in_channels // conv.groups > 1:
+                            gw = conv.in_channels // conv.groups
+                            need = l.pq_gconv3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C, gw)
+                            a = abi.GconvWgrad(dy, src.src(), flat.grad_ptr(conv.weight), None, B, src.H, src.W, out.H, out.W,
+                                               out.C, gw, s)
+                            idx = self._op(self.bwd, abi.OP_GCONV_WGRAD, a)
+                            wg_ops.append((idx, 'gcw', need))
+                            if src.needs_grad:
+                                d = abi.GconvDgrad(dy, ptr(conv.weight), self._sink(src, l.pq_gconv3x3_blocks(B, src.H, src.W)),
+                                                   B, src.H, src.W, out.H, out.W, out.C, gw, s)
+                                self._op(self.bwd, abi.OP_GCONV_DGRAD, d)
                         else:
                             if l.pq_dw3x3_bwd_fused_pays(src.H, src.W, s) and (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0)):
                                 # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
@@ -516,7 +551,7 @@ class Plan:
                                          srcT.W, srcT.C, out.ld, 0, 1)
                         self._op(self.bwd, abi.OP_ROUTE_BWD, r)
             elif t == 'route':
-                if not m.single:
+                if not m.single and len(m._layers) > 1:
                     out = T[i]
                     off = 0
                     for j in m._layers:

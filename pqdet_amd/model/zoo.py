@@ -101,8 +101,88 @@ def mobilenetv2_fpn(classes: int = 20) -> str:
     return c.text()
 
 
+def _xblock(c: _Cfg, width: int, stride: int, group_width: int, project: bool) -> int:
+    """RegNet X block: 1x1 -> grouped 3x3 (stride) -> 1x1 (linear) + identity / strided 1x1 projection, then ReLU."""
+    if project:
+        c.conv(width, 1, stride=stride, act='linear')      # projection of the block input, consumed by the shortcut
+        c.route(-2)                                        # back to the block input
+    c.conv(width, 1, act='relu')
+    c.conv(width, 3, stride=stride, groups=width // group_width, act='relu')
+    c.conv(width, 1, act='linear')
+    return c.shortcut(-5 if project else -4, act='relu')
+
+
+def _regnetx_600m_backbone(c: _Cfg) -> Dict[int, int]:
+    """RegNetX-600MF (Radosavovic et al. 2020): stem 32, depths 1-3-5-7, widths 48-96-240-528, group width 24.
+    Returns {stride: index of the last layer at that stride}."""
+    c.conv(32, 3, stride=2, act='relu')
+    cin, stride_now, ends = 32, 2, {}
+    for depth, width in ((1, 48), (3, 96), (5, 240), (7, 528)):
+        for i in range(depth):
+            st = 2 if i == 0 else 1
+            last = _xblock(c, width, st, 24, project=(st != 1 or cin != width))
+            cin = width
+            stride_now *= st
+        ends[stride_now] = last
+    return ends
+
+
+def regnetx_600m_fpn(classes: int = 20) -> str:
+    c = _Cfg()
+    ends = _regnetx_600m_backbone(c)
+    per_anchor = 3 * (5 + classes)
+    cin = 528
+    widths, taps = (352, 176, 80), (ends[16], ends[8])
+    for level, width in enumerate(widths):
+        for i in range(3):
+            _xblock(c, width, 1, 16, project=(i == 0))
+        c.conv(per_anchor, 1, act='linear', bn=False)
+        c.yolo(classes)
+        if level == len(widths) - 1:
+            break
+        c.route(-7)
+        c.conv(widths[level + 1], 1, act='relu')
+        c.upsample(2)
+        c.route([-1, taps[level]])
+    return c.text()
+
+
+def _gsep(c: _Cfg, width: int, stride: int = 1) -> int:
+    """1x1 -> grouped 3x3 (group width 16) -> 1x1, all ReLU (the PAN neck's unit)."""
+    c.conv(width, 1, act='relu')
+    c.conv(width, 3, stride=stride, groups=width // 16, act='relu')
+    return c.conv(width, 1, act='relu')
+
+
+def regnetx_600m_pan(classes: int = 20) -> str:
+    c = _Cfg()
+    ends = _regnetx_600m_backbone(c)
+    per_anchor = 3 * (5 + classes)
+    # top-down
+    p5 = _gsep(c, 352)
+    c.upsample(2)
+    c.route([-1, ends[16]])
+    p4 = _gsep(c, 176)
+    c.upsample(2)
+    c.route([-1, ends[8]])
+    _gsep(c, 96)
+    c.conv(per_anchor, 1, act='linear', bn=False)
+    c.yolo(classes)
+    # bottom-up
+    for width, lateral in ((176, p4), (352, p5)):
+        c.route(-3)
+        _gsep(c, width, stride=2)
+        c.route([-1, lateral - c.n])
+        _gsep(c, width)
+        c.conv(per_anchor, 1, act='linear', bn=False)
+        c.yolo(classes)
+    return c.text()
+
+
 _ZOO: Dict[str, Callable[..., str]] = {
     'mobilenetv2-fpn': mobilenetv2_fpn,
+    'regnetx-600m-fpn': regnetx_600m_fpn,
+    'regnetx-600m-pan': regnetx_600m_pan,
 }
 
 

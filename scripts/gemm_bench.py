@@ -48,8 +48,10 @@ for (M, I, O) in SHAPES:
     if 'dgrad' in which:
         nb = l.pq_conv1x1_blocks(M, I); ldp = (I + 15) // 16 * 16
         part = torch.empty(nb * 2 * ldp, device=dev)
-        a = abi.Conv1x1Dgrad(abi.GSrc(g.data_ptr(), y.data_ptr(), p.data_ptr(), q.data_ptr(), mu.data_ptr(), r.data_ptr(), ldo, ldo), w.data_ptr(),
-                             abi.GSink(gin.data_ptr(), x.data_ptr(), a2.data_ptr(), b2.data_ptr(), mn.data_ptr(), iv.data_ptr(), part.data_ptr(), I, I, 2, 0, 1, ldp),
+        two = os.environ.get('DG_ONE') is None
+        fin = 0 if os.environ.get('DG_NOFIN') else 1
+        a = abi.Conv1x1Dgrad(abi.GSrc(g.data_ptr(), y.data_ptr() if two else None, p.data_ptr(), q.data_ptr(), mu.data_ptr(), r.data_ptr(), ldo, ldo), w.data_ptr(),
+                             abi.GSink(gin.data_ptr(), x.data_ptr(), a2.data_ptr(), b2.data_ptr(), mn.data_ptr(), iv.data_ptr(), part.data_ptr(), I, I, 2, 0, fin, ldp),
                              M, I, O)
         ms = timeit(lambda: abi.check(l.pq_conv1x1_dgrad(C.byref(a), st)))
         tot['dgrad'] = tot.get('dgrad', 0) + ms

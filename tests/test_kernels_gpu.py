@@ -331,6 +331,124 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
 
 
 # ----------------------------------------------------------------------------------------------- stem
+# ----------------------------------------------------------------------------------------------- grouped 3x3
+@pytest.mark.parametrize('B,H,W,Cc,gw,stride', [(2, 9, 13, 48, 24, 1), (2, 10, 14, 48, 24, 2), (1, 16, 32, 96, 24, 2),
+                                                (1, 7, 7, 80, 16, 1), (2, 12, 12, 96, 16, 2), (1, 17, 20, 32, 32, 1),
+                                                (1, 8, 8, 24, 12, 1), (1, 9, 9, 528, 24, 1), (2, 9, 11, 176, 16, 2)])
+def test_gconv3x3_fwd_bwd(B, H, W, Cc, gw, stride):
+    g = torch.Generator().manual_seed(B * H * W + Cc + gw)
+    l = abi.lib()
+    G = Cc // gw
+    x = rnd(B, H, W, Cc, g=g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, rnd(Cc, g=g, scale=0.3)
+    w = rnd(Cc, gw, 3, 3, g=g, scale=0.2)
+    xin = (x * sc + sh).clamp(min=0).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(xin, wr, stride=stride, padding=1, groups=G)
+    OH, OW = y.shape[2:]
+    yn = y.permute(0, 2, 3, 1).contiguous()
+    xd, wd = x.to(DEV), w.to(DEV)
+    scd, shd = chan_vec(sc), chan_vec(sh)
+    out = torch.full((B, OH, OW, Cc), float('nan'), device=DEV)
+    nblk = l.pq_gconv3x3_blocks(B, OH, OW)
+    ldp = Cc
+    partial = torch.zeros(nblk * 2 * ldp, device=DEV)
+    a = abi.GconvFwd(abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), Cc, 1), wd.data_ptr(), out.data_ptr(),
+                     partial.data_ptr(), B, H, W, OH, OW, Cc, gw, stride, Cc, ldp)
+    abi.check(l.pq_gconv3x3_fwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(out, yn, what='gconv fwd')
+    s1, s2 = reduce_partial(partial, nblk, ldp, Cc)
+    close(s1.float(), yn.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='gconv sum')
+    close(s2.float(), (yn.double() ** 2).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='gconv sumsq')
+
+    # backward: upstream gradient through a BN on y (two-tensor operand), sink with relu' and BN-backward sums
+    gy = rnd(B, OH, OW, Cc, g=g)
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    p, q, mu, r, _ = _bn_bwd_coeffs(gy.view(-1, Cc), yn.detach().view(-1, Cc), gamma)
+    dy = p * gy + q * (yn.detach() - mu) + r
+    y.backward(dy.permute(0, 3, 1, 2))
+    dxin = xin.grad.permute(0, 2, 3, 1)
+    u = x * sc + sh
+    gwant = dxin * (u > 0).float()
+    mean_in = x.view(-1, Cc).mean(0)
+    inv_in = 1 / torch.sqrt(x.view(-1, Cc).var(0, unbiased=False) + 1e-5)
+    gyd, ynd = gy.to(DEV), yn.detach().to(DEV)
+    vecs = [chan_vec(v) for v in (p, q, mu, r)]
+    sv = [chan_vec(v) for v in (mean_in, inv_in)]
+    for accumulate in (0, 1):
+        prev = rnd(B, H, W, Cc, g=g) if accumulate else None
+        gdst = prev.to(DEV).clone() if accumulate else torch.full((B, H, W, Cc), float('nan'), device=DEV)
+        nb2 = l.pq_gconv3x3_blocks(B, H, W)
+        part2 = torch.zeros(nb2 * 2 * ldp, device=DEV)
+        d = abi.GconvDgrad()
+        d.dy = abi.GSrc(gyd.data_ptr(), ynd.data_ptr(), *[v.data_ptr() for v in vecs], Cc, Cc)
+        d.w = wd.data_ptr()
+        d.dx = abi.GSink(gdst.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
+                         part2.data_ptr(), Cc, Cc, 1, accumulate, 1, ldp)
+        d.B, d.IH, d.IW, d.OH, d.OW, d.C, d.gw, d.stride = B, H, W, OH, OW, Cc, gw, stride
+        abi.check(l.pq_gconv3x3_dgrad(C.byref(d), stream()))
+        torch.cuda.synchronize()
+        want = (dxin + prev) * (u > 0).float() if accumulate else gwant
+        close(gdst, want, what='gconv dgrad acc=%d' % accumulate)
+        s1, s2 = reduce_partial(part2, nb2, ldp, Cc)
+        xh = (x.double() - mean_in.double()) * inv_in.double()
+        close(s1.float(), want.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='gconv dgrad sum')
+        close(s2.float(), (want.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='gconv dgrad sum xhat')
+
+    scratch = torch.empty(l.pq_gconv3x3_wgrad_scratch_bytes(B, OH, OW, Cc, gw) // 4, device=DEV)
+    dw = torch.full((Cc, gw, 3, 3), float('nan'), device=DEV)
+    wg = abi.GconvWgrad()
+    wg.dy = d.dy
+    wg.inp = a.inp
+    wg.dw, wg.scratch = dw.data_ptr(), scratch.data_ptr()
+    wg.B, wg.IH, wg.IW, wg.OH, wg.OW, wg.C, wg.gw, wg.stride = B, H, W, OH, OW, Cc, gw, stride
+    abi.check(l.pq_gconv3x3_wgrad(C.byref(wg), stream()))
+    torch.cuda.synchronize()
+    close(dw, wr.grad, rt=1e-3, at=1e-3, what='gconv wgrad')
+
+
+def test_conv1x1_strided_backward():
+    """Backward of a stride-2 1x1 conv: dz scatters (accumulating) onto every second pixel, the weight gradient gathers them."""
+    g = torch.Generator().manual_seed(77)
+    l = abi.lib()
+    B, H, W, I, O, s = 2, 10, 14, 32, 48, 2
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    x = rnd(B, H, W, I, g=g)
+    w = rnd(O, I, g=g, scale=0.3)
+    gy = rnd(B, OH, OW, O, g=g)
+    prev = rnd(B, H, W, I, g=g)
+    xin = x.clamp(min=0).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wr = w.clone().view(O, I, 1, 1).requires_grad_(True)
+    y = F.conv2d(xin, wr, stride=s)
+    y.backward(gy.permute(0, 3, 1, 2))
+    want = prev + xin.grad.permute(0, 2, 3, 1)
+    xd, wd, gyd = x.to(DEV), w.to(DEV), gy.to(DEV)
+    gdst = prev.to(DEV).clone()
+    d = abi.Conv1x1Dgrad()
+    d.dy = abi.GSrc(gyd.data_ptr(), None, None, None, None, None, O, O)
+    d.w = wd.data_ptr()
+    d.dx = abi.GSink(gdst.data_ptr(), None, None, None, None, None, None, I, I, 0, 1, 0, 0)
+    d.M, d.I, d.O = B * OH * OW, I, O
+    d.sub, d.OH, d.OW, d.IH, d.IW = s, OH, OW, H, W
+    abi.check(l.pq_conv1x1_dgrad(C.byref(d), stream()))
+    torch.cuda.synchronize()
+    close(gdst, want, what='strided dgrad')
+    d.dx.finalize = 1
+    assert l.pq_conv1x1_dgrad(C.byref(d), stream()) == -1          # must be accumulate-only
+    scratch = torch.empty(l.pq_conv1x1_wgrad_scratch_bytes(B * OH * OW, I, O) // 4, device=DEV)
+    dw = torch.full((O, I), float('nan'), device=DEV)
+    wg = abi.Conv1x1Wgrad()
+    wg.dy = d.dy
+    wg.inp = abi.Src(xd.data_ptr(), None, None, I, 1)
+    wg.dw, wg.scratch = dw.data_ptr(), scratch.data_ptr()
+    wg.M, wg.I, wg.O = B * OH * OW, I, O
+    wg.sub, wg.OH, wg.OW, wg.IH, wg.IW = s, OH, OW, H, W
+    abi.check(l.pq_conv1x1_wgrad(C.byref(wg), stream()))
+    torch.cuda.synchronize()
+    close(dw, wr.grad.view(O, I), rt=1e-3, at=1e-3, what='strided wgrad')
+
+
 @pytest.mark.parametrize('B,H,W,O,stride', [(2, 16, 20, 32, 2), (1, 9, 9, 16, 1)])
 def test_stem(B, H, W, O, stride):
     g = torch.Generator().manual_seed(77 + H)
