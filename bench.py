@@ -39,6 +39,9 @@ KERNEL_CLASS = {
     abi.OP_CONV1X1_WGRAD: ('conv1x1_wgrad (gemm_tn, fp32 MFMA)', 'mfma'),
     abi.OP_DW_FWD: ('dw3x3_fwd', 'hbm'), abi.OP_DW_DGRAD: ('dw3x3_dgrad', 'hbm'), abi.OP_DW_WGRAD: ('dw3x3_wgrad', 'hbm'),
     abi.OP_DW_BWD: ('dw3x3_bwd (fused dgrad+wgrad, LDS tiles)', 'hbm'),
+    abi.OP_GCONV_FWD: ('gconv3x3_fwd (implicit GEMM, fp32 MFMA)', 'mfma'),
+    abi.OP_GCONV_DGRAD: ('gconv3x3_dgrad (implicit GEMM, fp32 MFMA)', 'mfma'),
+    abi.OP_GCONV_WGRAD: ('gconv3x3_wgrad (implicit GEMM, fp32 MFMA)', 'mfma'),
     abi.OP_STEM_FWD: ('stem3x3_fwd', 'hbm'), abi.OP_STEM_WGRAD: ('stem3x3_wgrad', 'hbm'),
     abi.OP_BN_FWD_FIN: ('bn_fwd_finalize', 'hbm'), abi.OP_BN_BWD_FIN: ('bn_bwd_finalize', 'hbm'),
     abi.OP_COPY_FWD: ('copy_fwd (shortcut/route/upsample)', 'hbm'), abi.OP_ROUTE_BWD: ('route_bwd', 'hbm'),
@@ -63,6 +66,10 @@ def op_work(op):
         a = op.u.dwb
         n_in, n_out = a.B * a.IH * a.IW * a.C, a.B * a.OH * a.OW * a.C
         return 2.0 * 2.0 * 9 * n_out, 2.0 * 4.0 * (n_in + n_out + 9 * a.C)
+    if c in (abi.OP_GCONV_FWD, abi.OP_GCONV_DGRAD, abi.OP_GCONV_WGRAD):
+        a = {abi.OP_GCONV_FWD: op.u.gcf, abi.OP_GCONV_DGRAD: op.u.gcd, abi.OP_GCONV_WGRAD: op.u.gcw}[c]
+        n_in, n_out = a.B * a.IH * a.IW * a.C, a.B * a.OH * a.OW * a.C
+        return 2.0 * 9 * a.gw * n_out, 4.0 * (n_in + n_out + 9 * a.gw * a.C)
     if c in (abi.OP_STEM_FWD, abi.OP_STEM_WGRAD):
         a = op.u.stf if c == abi.OP_STEM_FWD else op.u.stw
         n_in, n_out = a.B * a.CI * a.IH * a.IW, a.B * a.OH * a.OW * a.O
@@ -82,17 +89,20 @@ def op_work(op):
     return 0.0, 0.0
 
 
-def profile_kernels(plan, x, tgt, passes=3):
-    """Per-kernel-class device time of one step, HIP events on the launch stream (profiling pass, not the timed run)."""
+def profile_kernels(plan, x, tgt, side=None, passes=3):
+    """Per-kernel-class device time of one step: HIP events around every op on the stream it is launched on, replayed
+    exactly as in the timed steps (weight-gradient kernels overlap the data-gradient chain on the side stream), so the
+    averages are directly comparable with a rocprofv3 kernel trace of this command (profiles/r1_kernel_stats.csv)."""
     l = abi.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sd = C.c_void_p(side.cuda_stream) if side is not None else None
     plan._patch(x, tgt)
     acc = {}
     for arr, n in ((plan.fwd_arr, len(plan.fwd)), (plan.bwd_arr, len(plan.bwd))):
         ms = (C.c_float * n)()
         tot = [0.0] * n
         for _ in range(passes):
-            abi.check(l.pq_run_ops_timed(arr, n, st, ms), 'profiling pass')
+            abi.check(l.pq_run_ops2_timed(arr, n, st, sd, ms), 'profiling pass')
             for k in range(n):
                 tot[k] += ms[k] / passes
         for k in range(n):
@@ -101,6 +111,32 @@ def profile_kernels(plan, x, tgt, passes=3):
             e = acc.setdefault(name, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0, 'bound': bound})
             e['ms'] += tot[k]; e['flops'] += fl; e['bytes'] += by; e['launches'] += 1
     return acc
+
+
+# kernel class -> regex over the kernel names of profiles/r1_pmc_summary.csv (gemm_nt template args: BM,BN,WM,WN,AMODE,BKN,EMODE,..)
+PMC_PATTERN = {
+    'conv1x1_dgrad (gemm_nt, fp32 MFMA)': r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, 2, ',
+    'conv1x1_fwd (gemm_nt, fp32 MFMA)': r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], ',
+    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': r'gemm_tn_kernel<',
+}
+
+
+def measured_traffic(kernel_class, model_name):
+    """HBM bytes per launch of a kernel class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs of this command, gfx950 read correction applied -- scripts/pmc_summary.py).  None if unavailable."""
+    import csv
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc_summary.csv')
+    pat = PMC_PATTERN.get(kernel_class)
+    if model_name != 'mobilenetv2-fpn' or pat is None or not os.path.exists(path):
+        return None
+    calls = tot = 0.0
+    for r in csv.DictReader(open(path)):
+        if re.search(pat, r['kernel']):
+            n = float(r['calls'])
+            calls += n
+            tot += n * (float(r['hbm_read_mb_per_launch(2x)']) + float(r['hbm_write_mb_per_launch'])) * 1e6
+    return round(tot / calls) if calls else None
 
 
 def log(*a):
@@ -119,14 +155,14 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(batch, size, steps=2):
+def cpu_baseline(batch, size, steps=2, model='mobilenetv2-fpn'):
     """The CPU oracle (oracle/, PyTorch-CPU restatement pinned against the reference's golden vectors) timed on the
     host cores on the same workload shape.  Reported baseline only -- never part of the measured path."""
     from oracle.net import OracleNet
     threads = usable_cores()
     torch.set_num_threads(threads)
     log('cpu baseline on %d threads (os.cpu_count=%s)' % (threads, os.cpu_count()))
-    net = OracleNet(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
+    net = OracleNet(io.StringIO(zoo.cfg_text(model)))
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=4e-4)
     x = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(0))
@@ -142,8 +178,8 @@ def cpu_baseline(batch, size, steps=2):
             times.append(time.perf_counter() - t0)
     dt = sum(times) / len(times)
     return {'value': batch / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d timed train steps (after 1 warm-up) of mobilenetv2-fpn %dx%d batch %d on the CPU oracle, '
-                      '%.2f s/step' % (steps, size, size, batch, dt)}
+            'sample': '%d timed train steps (after 1 warm-up) of %s %dx%d batch %d on the CPU oracle, '
+                      '%.2f s/step' % (steps, model, size, size, batch, dt)}
 
 
 def main():
@@ -153,6 +189,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--model', default='mobilenetv2-fpn', choices=zoo.available(),
+                    help='BASELINE.json configs: mobilenetv2-fpn (the metric), regnetx-600m-fpn / -pan (configs 3, 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -169,7 +207,7 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(0)
-    model = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn'))).to(dev)
+    model = DetectionModel(io.StringIO(zoo.cfg_text(args.model))).to(dev)
     model.train()
     model.nan_check = 'deferred'
     runner = model
@@ -216,7 +254,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         plan = list(model._plans.values())[0]
-        prof = profile_kernels(plan, x, tgt)
+        prof = profile_kernels(plan, x, tgt, side=model._side_stream())
         dom_name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
         if dom['bound'] == 'mfma':
             achieved, peak, unit = dom['flops'] / (dom['ms'] * 1e-3) / 1e12, PEAK_FP32_TFLOPS, 'TFLOP/s'
@@ -224,22 +262,26 @@ def main():
             achieved, peak, unit = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9, PEAK_HBM_GBS, 'GB/s'
         total_ms = sum(v['ms'] for v in prof.values())
         roofline = {'bound': dom['bound'], 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
-                    'frac': round(achieved / peak, 4), 'traffic': None, 'kernel': dom_name,
+                    'frac': round(achieved / peak, 4), 'traffic': measured_traffic(dom_name, args.model),
+                    'traffic_unit': 'HBM bytes per launch (profiles/r1_pmc_summary.csv)',
+                    'algorithmic_per_launch': round((dom['flops'] if dom['bound'] == 'mfma' else dom['bytes']) / dom['launches']),
+                    'algorithmic_bytes_per_launch': round(dom['bytes'] / dom['launches']), 'kernel': dom_name,
+                    'kernel_avg_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
                     'kernel_ms_per_step': round(dom['ms'], 3), 'launches_per_step': dom['launches'],
                     'device_ms_per_step_all_kernels': round(total_ms, 3),
                     'breakdown_ms': {k: round(v['ms'], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}}
         line = {
-            'metric': 'images/sec train step, mobilenetv2-fpn 512x512 bs16/GPU', 'value': round(value, 2),
+            'metric': 'images/sec train step, %s %dx%d bs%d/GPU' % (args.model, S, S, B), 'value': round(value, 2),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'mobilenetv2-fpn.cfg train step (fwd + YOLO loss + bwd + Adam), %dx%d, batch %d per GPU, '
-                                   'C=20, random-init weights' % (S, S, B),
+            'config': {'workload': '%s.cfg train step (fwd + YOLO loss + bwd + Adam), %dx%d, batch %d per GPU, '
+                                   'C=20, random-init weights' % (args.model, S, S, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(B, S)
+            line['cpu_baseline'] = cpu_baseline(B, S, model=args.model)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

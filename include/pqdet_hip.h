@@ -397,6 +397,9 @@ int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side_stream);
 /* profiling variant: brackets every op with HIP events on `stream`, synchronises at the end and writes the elapsed
  * milliseconds of op k to ms[k] (used by bench.py for the live roofline figure; never on the timed path) */
 int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms);
+/* same for the two-stream replay: every op is bracketed on the stream it is launched on, so the figures are the in-situ
+ * durations (overlapping kernels share the chip), i.e. what a rocprofv3 kernel trace of the training step reports */
+int pq_run_ops2_timed(const pq_op* ops, int32_t n, void* stream, void* side_stream, float* ms);
 /* index of the first failing op of the last pq_run_ops (or -1) and its message */
 int pq_last_failed_op(void);
 const char* pq_last_error(void);

@@ -101,7 +101,7 @@ extern "C" int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float
     static thread_local hipEvent_t* ev = nullptr;
     static thread_local int nev = 0;
     if (nev < n + 1) {
-        for (int i = 0; i < nev; ++i) hipEventDestroy(ev[i]);
+        for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
         delete[] ev;
         ev = new hipEvent_t[n + 1];
         nev = n + 1;
@@ -109,14 +109,62 @@ extern "C" int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float
             if (hipEventCreate(&ev[i]) != hipSuccess) { pq_set_error("pq_run_ops_timed: hipEventCreate failed"); return PQ_ELAUNCH; }
     }
     hipStream_t st = (hipStream_t)stream;
-    hipEventRecord(ev[0], st);
+    (void)hipEventRecord(ev[0], st);
     for (int i = 0; i < n; ++i) {
         const int rc = run_one(ops[i], stream);
         if (rc != PQ_OK) { g_failed_op = i; return rc; }
-        hipEventRecord(ev[i + 1], st);
+        (void)hipEventRecord(ev[i + 1], st);
     }
     if (hipEventSynchronize(ev[n]) != hipSuccess) { pq_set_error("pq_run_ops_timed: sync failed"); return PQ_ELAUNCH; }
-    for (int i = 0; i < n; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    for (int i = 0; i < n; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    return PQ_OK;
+}
+
+extern "C" int pq_run_ops2_timed(const pq_op* ops, int32_t n, void* stream, void* side_stream, float* ms) {
+    g_failed_op = -1;
+    if (!ops || n < 0 || !ms) { pq_set_error("pq_run_ops2_timed: bad arguments"); return PQ_EINVAL; }
+    if (!side_stream || side_stream == stream) return pq_run_ops_timed(ops, n, stream, ms);
+    static thread_local hipEvent_t* ev = nullptr;
+    static thread_local int nev = 0;
+    const int need = 2 * n + 2;
+    if (nev < need) {
+        for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+        delete[] ev;
+        ev = new hipEvent_t[need];
+        nev = need;
+        for (int i = 0; i < nev; ++i)
+            if (hipEventCreate(&ev[i]) != hipSuccess) { pq_set_error("pq_run_ops2_timed: hipEventCreate failed"); return PQ_ELAUNCH; }
+    }
+    hipStream_t main_s = (hipStream_t)stream, side_s = (hipStream_t)side_stream;
+    hipEvent_t fork = ev[2 * n], join = ev[2 * n + 1];
+    bool used_side = false, main_dirty = true;
+    for (int i = 0; i < n; ++i) {
+        const bool side = (ops[i].flags & PQ_OPF_SIDE) != 0;
+        if (side) {
+            if (main_dirty) {
+                // one reusable fork event is enough here: hipStreamWaitEvent captures the record that precedes it
+                if (hipEventRecord(fork, main_s) != hipSuccess || hipStreamWaitEvent(side_s, fork, 0) != hipSuccess) {
+                    pq_set_error("pq_run_ops2_timed: fork failed"); g_failed_op = i; return PQ_ELAUNCH;
+                }
+                main_dirty = false;
+            }
+            used_side = true;
+        } else {
+            main_dirty = true;
+        }
+        hipStream_t st = side ? side_s : main_s;
+        (void)hipEventRecord(ev[2 * i], st);
+        const int rc = run_one(ops[i], st);
+        if (rc != PQ_OK) { g_failed_op = i; return rc; }
+        (void)hipEventRecord(ev[2 * i + 1], st);
+    }
+    if (used_side) {
+        if (hipEventRecord(join, side_s) != hipSuccess || hipStreamWaitEvent(main_s, join, 0) != hipSuccess) {
+            pq_set_error("pq_run_ops2_timed: join failed"); return PQ_ELAUNCH;
+        }
+    }
+    if (hipStreamSynchronize(main_s) != hipSuccess) { pq_set_error("pq_run_ops2_timed: sync failed"); return PQ_ELAUNCH; }
+    for (int i = 0; i < n; ++i) (void)hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]);
     return PQ_OK;
 }
 

@@ -369,7 +369,7 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
     p.B = a->B; p.AH = a->IH; p.AW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.gw = a->gw; p.S = a->stride;
     p.tilesH = (a->OH + GTH - 1) / GTH; p.tilesW = (a->OW + GTW - 1) / GTW;
     const size_t lds = gc_lds_bytes(a->gw, a->stride);
-    hipFuncSetAttribute((const void*)gconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((gconv_kernel<1>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -388,7 +388,7 @@ extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) 
     if (a->stride == 1) { p.AH = a->OH; p.AW = a->OW; }
     p.tilesH = (a->IH + GTH - 1) / GTH; p.tilesW = (a->IW + GTW - 1) / GTW;
     const size_t lds = gc_lds_bytes(a->gw, 1);
-    hipFuncSetAttribute((const void*)gconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((gconv_kernel<2>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -420,13 +420,13 @@ extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) 
     hipStream_t st = (hipStream_t)stream;
     const int nch = (9 * a->gw + 31) / 32;
     if (nch <= 5) {
-        hipFuncSetAttribute((const void*)gconv_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(gconv_wgrad_kernel<5>, dim3(G, p.nsplit), dim3(256), lds, st, p);
     } else if (nch <= 7) {
-        hipFuncSetAttribute((const void*)gconv_wgrad_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_wgrad_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(gconv_wgrad_kernel<7>, dim3(G, p.nsplit), dim3(256), lds, st, p);
     } else {
-        hipFuncSetAttribute((const void*)gconv_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gconv_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(gconv_wgrad_kernel<9>, dim3(G, p.nsplit), dim3(256), lds, st, p);
     }
     PQ_CHECK_LAUNCH();

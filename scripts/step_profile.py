@@ -15,7 +15,7 @@ def log(*a):
 B, S = int(sys.argv[1]), int(sys.argv[2])
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 torch.manual_seed(0)
-model = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn'))).cuda(); model.train()
+model = DetectionModel(io.StringIO(zoo.cfg_text(os.environ.get('MODEL', 'mobilenetv2-fpn')))).cuda(); model.train()
 x = torch.randn(B, 3, S, S).cuda()
 tgt = tuple(t.cuda() for t in labels.synthetic_targets(B, S, 20, seed=1))
 log('building plan')
@@ -40,6 +40,9 @@ for tag, arr, n in (('fwd', plan.fwd_arr, len(plan.fwd)), ('bwd', plan.bwd_arr, 
         elif op.code in (abi.OP_DW_FWD, abi.OP_DW_DGRAD, abi.OP_DW_WGRAD):
             a = {abi.OP_DW_FWD: op.u.dwf, abi.OP_DW_DGRAD: op.u.dwd, abi.OP_DW_WGRAD: op.u.dww}[op.code]
             desc = 'B=%d %dx%d->%dx%d C=%d s=%d' % (a.B, a.IH, a.IW, a.OH, a.OW, a.C, a.stride)
+        elif op.code in (abi.OP_GCONV_FWD, abi.OP_GCONV_DGRAD, abi.OP_GCONV_WGRAD):
+            a = {abi.OP_GCONV_FWD: op.u.gcf, abi.OP_GCONV_DGRAD: op.u.gcd, abi.OP_GCONV_WGRAD: op.u.gcw}[op.code]
+            desc = 'B=%d %dx%d->%dx%d C=%d gw=%d s=%d' % (a.B, a.IH, a.IW, a.OH, a.OW, a.C, a.gw, a.stride)
         rows.append((ms[k], tag, k, name, desc, fl, by))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
