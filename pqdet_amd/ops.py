@@ -201,3 +201,12 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
     args = abi.Adam(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
                     weight_decay, bc1, bc2, grad_scale)
     check(lib().pq_adam_step(C.byref(args), _stream()), 'pq_adam_step')
+
+
+def sign_l1(grad: torch.Tensor, weight: torch.Tensor, ratio: float):
+    """grad += ratio * sign(weight), in place (``pq_sign_l1``)."""
+    _need_cuda(grad, weight)
+    if not (grad.is_contiguous() and weight.is_contiguous()) or grad.numel() != weight.numel():
+        raise ValueError('sign_l1 needs contiguous tensors of equal size')
+    check(lib().pq_sign_l1(ptr(grad), ptr(weight), grad.numel(), float(ratio), _stream()), 'pq_sign_l1')
+    return grad

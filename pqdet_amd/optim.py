@@ -58,3 +58,14 @@ class Adam(torch.optim.Optimizer):
                 ops.adam_step(p.data, g, st['m'], st['v'], float(group['lr']), b1, b2, group['eps'],
                               group['weight_decay'], st['step'], self.grad_scale)
         return loss
+
+
+def sparse_l1(bn_modules, ratio: float):
+    """Sparsity penalty of network-slimming training, applied between ``backward()`` and ``optimizer.step()``:
+    ``gamma.grad += ratio * sign(gamma)`` for every collected BatchNorm (reference ``trainer.py:236-239``; the modules
+    come from ``tools.get_bn_layers``).  One ``pq_sign_l1`` launch per BatchNorm on the gradient views."""
+    for m in bn_modules:
+        w = m.weight
+        if w.grad is None:
+            continue
+        ops.sign_l1(w.grad, w.data, float(ratio))

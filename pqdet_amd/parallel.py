@@ -49,7 +49,11 @@ class GradReducer:
             ready.record(torch.cuda.current_stream())
             self.stream.wait_event(ready)
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+                if dist.get_backend(self.group) == 'nccl':          # RCCL: averaging all-reduce, asynchronous on the stream
+                    dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+                else:                                               # gloo on device tensors (single-GPU rehearsal): SUM, scale
+                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                    chunk.div_(self.world)
         else:   # gloo (CPU rehearsal): no AVG -> SUM then scale
             h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.handles.append((h, chunk))

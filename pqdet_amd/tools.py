@@ -73,6 +73,44 @@ def torch_nms(bboxes: torch.Tensor, score_threshold: float, iou_threshold: float
     return dets[:k]
 
 
+def nms(bboxes: np.ndarray, score_threshold: float, iou_threshold: float, sigma: float = 0.3, method: str = 'nms'):
+    """Host-side per-class NMS on arg-maxed detections (reference :507-538; not on the evaluator path, kept for API parity).
+
+    ``bboxes`` (N, 6) = x1,y1,x2,y2,score,class.  Per class (in ``list(set(classes))`` order): take the best remaining
+    box, then either drop what overlaps it by more than ``iou_threshold`` (``'nms'``) or decay the remaining scores by
+    ``exp(-iou^2/sigma)`` (``'soft-nms'``, the input rows' scores are modified like in the reference), and drop scores
+    ``<= score_threshold``.  Hard NMS is done from one score-sorted pass over a precomputed IoU matrix."""
+    assert method in ['nms', 'soft-nms']
+    picked = []
+    for cls in list(set(bboxes[:, 5])):
+        rows = bboxes[bboxes[:, 5] == cls]
+        n = len(rows)
+        if method == 'nms':
+            order = np.argsort(-rows[:, 4], kind='stable')          # equal scores: first occurrence first, like argmax
+            cand = rows[order]
+            alive = cand[:, 4] > score_threshold
+            alive[0] = True                                          # the best box of a class is always reported
+            iou = iou_calc1(cand[:, None, :4], cand[None, :, :4])
+            for i in range(n):
+                if alive[i]:
+                    picked.append(cand[i])
+                    alive[i + 1:] &= ~(iou[i, i + 1:] > iou_threshold)
+        else:
+            score = rows[:, 4].copy()
+            alive = np.ones(n, dtype=bool)
+            while alive.any():
+                j = int(np.argmax(np.where(alive, score, -np.inf)))
+                best = rows[j].copy()
+                best[4] = score[j]
+                picked.append(best)
+                alive[j] = False
+                idx = np.nonzero(alive)[0]
+                w = np.exp(-(1.0 * iou_calc1(rows[j][np.newaxis, :4], rows[idx, :4]) ** 2 / sigma))
+                score[idx] = (score[idx] * w).astype(rows.dtype)
+                alive[idx] = score[idx] > score_threshold
+    return np.array(picked)
+
+
 # ----------------------------------------------------------------------------------------------- weights / build
 def _state_dict_is_dp(state_dict: Dict) -> bool:
     for k in state_dict:

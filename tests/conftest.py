@@ -31,3 +31,8 @@ def g1():
 def g5_names():
     with open(os.path.join(GOLDEN_DIR, 'g5_param_names.json')) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def golden_extra():
+    return np.load(os.path.join(GOLDEN_DIR, 'golden_extra.npz'))

@@ -1,0 +1,58 @@
+"""Host-side glue around the hot path against fixtures recorded from the reference: LR schedules (G10), evaluator mAP
+bookkeeping (G11), the in-repo NumPy NMS (G7).  No GPU needed."""
+import types
+
+import numpy as np
+
+from pqdet_amd import schedule, tools
+from pqdet_amd.eval import Evaluator, average_precision
+
+
+def _sched(kind, g):
+    warm, spe, max_ep, init_lr, end_lr, gamma = g['g10_params']
+    opt = types.SimpleNamespace(param_groups=[{'lr': 0.0}, {'lr': 1.0}])
+    s = schedule.LRScheduler(opt, kind, float(init_lr), float(end_lr), int(warm), int(max_ep), int(spe),
+                             milestones=[int(m) for m in g['g10_milestones']], gamma=float(gamma))
+    return s, opt
+
+
+def test_lr_schedules_match_reference(golden_extra):
+    g = golden_extra
+    for kind, key in (('cosine', 'g10_cosine'), ('step', 'g10_step')):
+        s, opt = _sched(kind, g)
+        got = np.array([s(int(st)) for st in g['g10_steps']])
+        np.testing.assert_array_equal(got, g[key])                  # same double-precision expression -> bit equal
+        assert all(grp['lr'] == got[-1] for grp in opt.param_groups)
+    assert schedule.cosine_lr(0, 4e-4, 1e-6, 74, 1110) == 0.0
+
+
+def test_evaluator_ap_bookkeeping_matches_reference(golden_extra):
+    g = golden_extra
+    for tag in 'ab':
+        ev = Evaluator(None, classes=['c%d' % i for i in range(4)])
+        for i in range(6):
+            ev.add_detections('img%d' % i, g['g11%s_dets%d' % (tag, i)])
+            ev.add_labels('img%d' % i, g['g11%s_labels%d' % (tag, i)], g['g11%s_diffs%d' % (tag, i)])
+        m = ev.AP()
+        np.testing.assert_array_equal(m.raw, g['g11%s_raw' % tag])          # NaN rows (class never labelled) included
+        np.testing.assert_array_equal(m.mAPs, g['g11%s_mAPs' % tag])
+        np.testing.assert_array_equal(m.APs, g['g11%s_APs' % tag])
+        np.testing.assert_array_equal(np.asarray(m.AP), g['g11%s_AP' % tag])
+        np.testing.assert_array_equal(m.iou_thresholds, g['g11%s_iou_thresholds' % tag])
+        assert ev.detections_count == 0 and not ev.labels                    # statistics are reset after AP()
+    assert Evaluator(None, classes=['a']).AP() is None                       # nothing added -> the reference returns None too
+
+
+def test_average_precision_envelope():
+    rec = np.array([[0.1, 0.2, 0.2, 0.5]])
+    prec = np.array([[1.0, 0.5, 0.66, 0.4]])
+    # envelope 1.0, 0.66, 0.66, 0.4 over recall steps 0.1, 0.1, 0, 0.3 (+ 0 for the tail to recall 1)
+    np.testing.assert_allclose(average_precision(rec, prec), [0.1 * 1.0 + 0.1 * 0.66 + 0.3 * 0.4])
+
+
+def test_numpy_nms_matches_reference(golden):
+    for method, key in (('nms', 'g7_nms'), ('soft-nms', 'g7_softnms')):
+        out = tools.nms(golden['g7_in'].copy(), 0.1, 0.45, method=method)
+        np.testing.assert_array_equal(out, golden[key])
+    one = np.array([[0, 0, 10, 10, 0.05, 2]], dtype=np.float32)
+    np.testing.assert_array_equal(tools.nms(one, 0.1, 0.45), one)             # a class's best box is reported regardless

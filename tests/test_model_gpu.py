@@ -185,6 +185,53 @@ def test_eval_then_recover_then_nms_pipeline():
         np.testing.assert_array_equal(a, b)
 
 
+def test_batched_evaluator_matches_per_image_nms_and_sparse_l1():
+    from pqdet_amd import optim as poptim, tools
+    from pqdet_amd.dataset import RECOVER_BBOXES_REGISTER
+    from pqdet_amd.eval import Evaluator
+    net, _ = _pair(seed=8)
+    net.eval()
+    x = seeded_images(3, 96, 128, 2).to(DEV)
+    shapes = torch.FloatTensor([[80, 120], [96, 100], [60, 128]])
+    ev = Evaluator(net, dataset_name='voc', classes=['c%d' % i for i in range(20)], input_size=(96, 128),
+                   score_threshold=0.3, iou_threshold=0.45)
+    dets = ev.detect(x, shapes)
+    with torch.no_grad():
+        pred = net(x)
+    boxes = RECOVER_BBOXES_REGISTER['voc'](pred, torch.FloatTensor([96, 128]).to(DEV), shapes.to(DEV))
+    for i in range(3):
+        want = tools.torch_nms(boxes[i], 0.3, 0.45).cpu().numpy()
+        assert dets[i].shape == want.shape and len(want) > 0
+        np.testing.assert_array_equal(dets[i], want)
+    # sparse-L1 on the BN scales: grad += ratio * sign(gamma)
+    net.train()
+    net(x, tuple(t.to(DEV) for t in _targets(3, 96, 128, 20)))['loss'].mean().backward()
+    bns = tools.get_bn_layers(net)
+    before = [m.weight.grad.clone() for m in bns]
+    poptim.sparse_l1(bns, 1e-2)
+    for m, g0 in zip(bns, before):
+        assert torch.equal(m.weight.grad, g0 + 1e-2 * torch.sign(m.weight.data))
+
+
+def test_config4_shape_regnetx_pan_960_batch8():
+    """BASELINE config 4: regnetx-600m-pan at 960x960, batch 8 -- runs, finite, heads in cfg order (stride 8, 16, 32)."""
+    net = DetectionModel(io.StringIO(zoo.cfg_text('regnetx-600m-pan'))).to(DEV)
+    net.train()
+    x = seeded_images(8, 960, 960, 4).to(DEV)
+    tgt = tuple(t.to(DEV) for t in _targets(8, 960, 960, 20))
+    out = net(x, tgt)
+    out['loss'].mean().backward()
+    net.check_nan()
+    assert all(torch.isfinite(v).all() for v in (out['loss'], out['giou_loss'], out['conf_loss'], out['class_loss']))
+    assert len(out['loss_per_branch']) == 3
+    _, grad = net.flat_buffers()
+    assert torch.isfinite(grad).all() and grad.abs().max().item() > 0
+    net.eval()
+    with torch.no_grad():
+        ev = net(x[:2])
+    assert ev.shape == (2, 3 * (120 * 120 + 60 * 60 + 30 * 30), 25)
+
+
 def test_no_cpu_fallback():
     from pqdet_amd import abi
     net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
