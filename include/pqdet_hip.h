@@ -239,6 +239,8 @@ typedef struct pq_bn_fwd_finalize_args {
     float* shift;           /* out [C]: beta - mean*scale */
     int32_t nblk, ldp, C, train;
     float count, eps, momentum;
+    double* scratch;        /* >= pq_bn_finalize_scratch_bytes(C), or NULL: one block per 64 channels walks all rows */
+    uint32_t* tickets;      /* pq_bn_finalize_tickets(C) counters, zero before the first use (self re-arming), or NULL */
 } pq_bn_fwd_finalize_args;
 int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream);
 
@@ -253,8 +255,13 @@ typedef struct pq_bn_bwd_finalize_args {
     float* r;
     int32_t nblk, ldp, C, train;
     float count;
+    double* scratch;        /* as in pq_bn_fwd_finalize_args; the two may share buffers when issued on one stream */
+    uint32_t* tickets;
 } pq_bn_bwd_finalize_args;
 int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream);
+/* long partial lists are reduced by several blocks per channel group through this scratch (deterministic order) */
+int64_t pq_bn_finalize_scratch_bytes(int32_t C);
+int32_t pq_bn_finalize_tickets(int32_t C);
 
 /* ------------------------------------------------------------------ shortcut / route / upsample
  * forward  (model/parser.py:149-156 ShortCut, :178-183 Route, :450-452 UpsamplingNearest2d):

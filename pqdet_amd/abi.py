@@ -103,13 +103,14 @@ class StemWgrad(C.Structure):
 class BnFwdFin(C.Structure):
     _fields_ = [('partial', c_fp), ('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp),
                 ('num_batches_tracked', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp), ('shift', c_fp),
-                ('nblk', i32), ('ldp', i32), ('C', i32), ('train', i32), ('count', f32), ('eps', f32), ('momentum', f32)]
+                ('nblk', i32), ('ldp', i32), ('C', i32), ('train', i32), ('count', f32), ('eps', f32), ('momentum', f32),
+                ('scratch', c_fp), ('tickets', c_fp)]
 
 
 class BnBwdFin(C.Structure):
     _fields_ = [('partial', c_fp), ('gamma', c_fp), ('invstd', c_fp), ('dgamma', c_fp), ('dbeta', c_fp),
                 ('p', c_fp), ('q', c_fp), ('r', c_fp), ('nblk', i32), ('ldp', i32), ('C', i32), ('train', i32),
-                ('count', f32)]
+                ('count', f32), ('scratch', c_fp), ('tickets', c_fp)]
 
 
 class Copy(C.Structure):
@@ -218,6 +219,8 @@ SIGNATURES = {
     'pq_stem3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32, i32]),
     'pq_bn_fwd_finalize': (C.c_int, [C.POINTER(BnFwdFin), C.c_void_p]),
     'pq_bn_bwd_finalize': (C.c_int, [C.POINTER(BnBwdFin), C.c_void_p]),
+    'pq_bn_finalize_scratch_bytes': (i64, [i32]),
+    'pq_bn_finalize_tickets': (i32, [i32]),
     'pq_copy_fwd': (C.c_int, [C.POINTER(Copy), C.c_void_p]),
     'pq_route_bwd': (C.c_int, [C.POINTER(RouteBwd), C.c_void_p]),
     'pq_ew_blocks': (i32, [i32, i32]),

@@ -5,46 +5,117 @@
 namespace pq {
 
 // ------------------------------------------------------------------------------------------------ BN finalize
-// One block of 256 threads = 16 channels x 16 row-lanes; partial is [nblk][2][ldp].
-// block = 16 channels x BN_RL row lanes; BN_RL = 8 for short partial lists (most layers), 64 for the 256x256 layers
-template <int BN_RL>
-__global__ __launch_bounds__(16 * BN_RL) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize_args a) {
-    __shared__ double sh[2][16][BN_RL + 1];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    if (a.train) {
-        double s1 = 0.0, s2 = 0.0;
-        if (c < a.C)
-            for (int k = rl; k < a.nblk; k += BN_RL) {
-                const float* row = a.partial + (size_t)k * 2 * a.ldp;
-                s1 += (double)row[c];
-                s2 += (double)row[a.ldp + c];
+// partial is [nblk][2][ldp] (one row pair per producer row-block).  Block = 64 channels x 4 row lanes (a wave reads 256
+// contiguous bytes of one partial row); grid = (ceil(C/64), R).  Each block sums its slice of the rows with 8 independent
+// loads in flight per thread (the kernel is pure load latency).  R > 1 (long partial lists, up to 8192 rows for the
+// 1M-pixel layers): slices go to a double scratch, an agent-scope ticket elects the last block of a channel group, which
+// adds the R slices in fixed order (deterministic) and finalises; it also re-arms the ticket for the next launch.
+constexpr int BNF_CH = 64, BNF_RL = 4, BNF_UNROLL = 8, BNF_MAXR = 64;
+
+__device__ __forceinline__ bool bn_reduce_partials(const float* partial, int nblk, int ldp, int C, double* scratch,
+                                                    unsigned* tickets, double& t1, double& t2) {
+    __shared__ double sh[2][BNF_RL][BNF_CH];
+    __shared__ unsigned s_ticket;
+    const int cl = threadIdx.x & (BNF_CH - 1), rl = threadIdx.x >> 6;
+    const int cg = blockIdx.x, c = cg * BNF_CH + cl;
+    const int R = gridDim.y, r = blockIdx.y;
+    const int per = (nblk + R - 1) / R;
+    const int k0 = r * per, k1 = min(nblk, k0 + per);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        int k = k0 + rl;
+        for (; k + (BNF_UNROLL - 1) * BNF_RL < k1; k += BNF_UNROLL * BNF_RL) {
+            float a[BNF_UNROLL], b[BNF_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BNF_UNROLL; ++u) {
+                const float* row = partial + (size_t)(k + u * BNF_RL) * 2 * ldp;
+                a[u] = row[c];
+                b[u] = row[ldp + c];
             }
-        sh[0][cl][rl] = s1;
-        sh[1][cl][rl] = s2;
-        __syncthreads();
-        if (rl == 0 && c < a.C) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int k = 0; k < BN_RL; ++k) { t1 += sh[0][cl][k]; t2 += sh[1][cl][k]; }
-            const double n = (double)a.count;
-            const double mean = t1 / n;
-            double var = t2 / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float inv = (float)(1.0 / sqrt(var + (double)a.eps));
-            const float g = a.gamma[c], b = a.beta[c];
-            a.mean[c] = (float)mean;
-            a.invstd[c] = inv;
-            const float sc = g * inv;
-            a.scale[c] = sc;
-            a.shift[c] = b - (float)mean * sc;
-            if (a.running_mean) {
-                const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-                a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
-            }
+#pragma unroll
+            for (int u = 0; u < BNF_UNROLL; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
-    } else if (rl == 0 && c < a.C) {
+        for (; k < k1; k += BNF_RL) {
+            const float* row = partial + (size_t)k * 2 * ldp;
+            s1 += (double)row[c];
+            s2 += (double)row[ldp + c];
+        }
+    }
+    sh[0][rl][cl] = s1;
+    sh[1][rl][cl] = s2;
+    __syncthreads();
+    t1 = t2 = 0.0;
+    if (rl == 0) {
+#pragma unroll
+        for (int q = 0; q < BNF_RL; ++q) { t1 += sh[0][q][cl]; t2 += sh[1][q][cl]; }
+    }
+    if (R == 1) return rl == 0 && c < C;
+    double* mine = scratch + ((size_t)(cg * R + r) * 2) * BNF_CH;
+    if (rl == 0) { mine[cl] = t1; mine[BNF_CH + cl] = t2; }
+    __threadfence();                                   // release the slice (agent scope: L2s are per XCD)
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&tickets[cg], 1u);
+    __syncthreads();
+    if (s_ticket != (unsigned)(R - 1)) return false;   // uniform per block
+    __threadfence();                                   // acquire the other blocks' slices
+    // every row lane adds a quarter of the slices (independent loads in flight), then the four sums are combined in
+    // fixed order: the result does not depend on which block came last
+    double u1 = 0.0, u2 = 0.0;
+    {
+        int q = rl;
+        for (; q + 3 * BNF_RL < R; q += 4 * BNF_RL) {
+            double x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double* sl = scratch + ((size_t)(cg * R + q + u * BNF_RL) * 2) * BNF_CH;
+                x[u] = sl[cl];
+                y[u] = sl[BNF_CH + cl];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { u1 += x[u]; u2 += y[u]; }
+        }
+        for (; q < R; q += BNF_RL) {
+            const double* sl = scratch + ((size_t)(cg * R + q) * 2) * BNF_CH;
+            u1 += sl[cl];
+            u2 += sl[BNF_CH + cl];
+        }
+    }
+    __syncthreads();
+    sh[0][rl][cl] = u1;
+    sh[1][rl][cl] = u2;
+    __syncthreads();
+    if (rl == 0) {
+        t1 = t2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < BNF_RL; ++q) { t1 += sh[0][q][cl]; t2 += sh[1][q][cl]; }
+    }
+    if (threadIdx.x == 0) tickets[cg] = 0u;            // re-arm (the next launch is stream-ordered after this one)
+    return rl == 0 && c < C;
+}
+
+__global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize_args a) {
+    const int c = blockIdx.x * BNF_CH + (threadIdx.x & (BNF_CH - 1));
+    if (a.train) {
+        double t1, t2;
+        if (!bn_reduce_partials(a.partial, a.nblk, a.ldp, a.C, a.scratch, a.tickets, t1, t2)) return;
+        const double n = (double)a.count;
+        const double mean = t1 / n;
+        double var = t2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float inv = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float g = a.gamma[c], b = a.beta[c];
+        a.mean[c] = (float)mean;
+        a.invstd[c] = inv;
+        const float sc = g * inv;
+        a.scale[c] = sc;
+        a.shift[c] = b - (float)mean * sc;
+        if (a.running_mean) {
+            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+        }
+        if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    } else if (threadIdx.x < BNF_CH && blockIdx.y == 0 && c < a.C) {
         const float inv = 1.f / sqrtf(a.running_var[c] + a.eps);
         const float sc = a.gamma[c] * inv;
         a.mean[c] = a.running_mean[c];
@@ -54,36 +125,21 @@ __global__ __launch_bounds__(16 * BN_RL) void bn_fwd_finalize_kernel(pq_bn_fwd_f
     }
 }
 
-template <int BN_RL>
-__global__ __launch_bounds__(16 * BN_RL) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize_args a) {
-    __shared__ double sh[2][16][BN_RL + 1];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < a.C)
-        for (int k = rl; k < a.nblk; k += BN_RL) {
-            const float* row = a.partial + (size_t)k * 2 * a.ldp;
-            s1 += (double)row[c];
-            s2 += (double)row[a.ldp + c];
-        }
-    sh[0][cl][rl] = s1;
-    sh[1][cl][rl] = s2;
-    __syncthreads();
-    if (rl == 0 && c < a.C) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < BN_RL; ++k) { t1 += sh[0][cl][k]; t2 += sh[1][cl][k]; }
-        const float inv = a.invstd[c];
-        const float pc = a.gamma[c] * inv;
-        a.dbeta[c] = (float)t1;
-        a.dgamma[c] = (float)t2;
-        a.p[c] = pc;
-        if (a.train) {
-            a.q[c] = (float)(-(double)pc * (double)inv * t2 / (double)a.count);
-            a.r[c] = (float)(-(double)pc * t1 / (double)a.count);
-        } else {   // statistics frozen: dy = gamma*invstd*g
-            a.q[c] = 0.f;
-            a.r[c] = 0.f;
-        }
+__global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize_args a) {
+    const int c = blockIdx.x * BNF_CH + (threadIdx.x & (BNF_CH - 1));
+    double t1, t2;
+    if (!bn_reduce_partials(a.partial, a.nblk, a.ldp, a.C, a.scratch, a.tickets, t1, t2)) return;
+    const float inv = a.invstd[c];
+    const float pc = a.gamma[c] * inv;
+    a.dbeta[c] = (float)t1;
+    a.dgamma[c] = (float)t2;
+    a.p[c] = pc;
+    if (a.train) {
+        a.q[c] = (float)(-(double)pc * (double)inv * t2 / (double)a.count);
+        a.r[c] = (float)(-(double)pc * t1 / (double)a.count);
+    } else {   // statistics frozen: dy = gamma*invstd*g
+        a.q[c] = 0.f;
+        a.r[c] = 0.f;
     }
 }
 
@@ -195,13 +251,21 @@ __global__ void sign_l1_kernel(float* grad, const float* w, int64_t n, float rat
 
 using namespace pq;
 
+static int bn_row_groups(int nblk, bool have_scratch) {
+    if (!have_scratch || nblk <= 256) return 1;          // the ticket round trip costs ~3 us: only for long lists
+    const int r = (nblk + 127) / 128;
+    return r > BNF_MAXR ? BNF_MAXR : r;
+}
+extern "C" int64_t pq_bn_finalize_scratch_bytes(int32_t C) { return (int64_t)((C + BNF_CH - 1) / BNF_CH) * BNF_MAXR * 2 * BNF_CH * 8; }
+extern "C" int32_t pq_bn_finalize_tickets(int32_t C) { return (C + BNF_CH - 1) / BNF_CH; }
+
 extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->gamma && a->beta && a->mean && a->invstd && a->scale && a->shift, "null pointer");
     PQ_CHECK_ARG(a->C > 0, "empty");
     PQ_CHECK_ARG(!a->train || (a->partial && a->nblk > 0 && a->count > 0.f), "train mode needs partial sums");
     PQ_CHECK_ARG(a->train || (a->running_mean && a->running_var), "eval mode needs running statistics");
-    if (a->nblk > 256) hipLaunchKernelGGL((bn_fwd_finalize_kernel<64>), dim3((a->C + 15) / 16), dim3(16 * 64), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL((bn_fwd_finalize_kernel<8>), dim3((a->C + 15) / 16), dim3(16 * 8), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, a->train ? bn_row_groups(a->nblk, a->scratch && a->tickets) : 1),
+                       dim3(BNF_CH * BNF_RL), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -209,8 +273,8 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
 extern "C" int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->partial && a->gamma && a->invstd && a->dgamma && a->dbeta && a->p && a->q && a->r, "null pointer");
     PQ_CHECK_ARG(a->C > 0 && a->nblk > 0 && a->count > 0.f, "empty");
-    if (a->nblk > 256) hipLaunchKernelGGL((bn_bwd_finalize_kernel<64>), dim3((a->C + 15) / 16), dim3(16 * 64), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL((bn_bwd_finalize_kernel<8>), dim3((a->C + 15) / 16), dim3(16 * 8), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, bn_row_groups(a->nblk, a->scratch && a->tickets)),
+                       dim3(BNF_CH * BNF_RL), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -152,6 +152,20 @@ class Plan:
         self.keep.append(t)
         return t
 
+    def _bn_scratch(self, C_):
+        """(scratch, tickets) shared by every BN finalize of this plan (all are issued on the main stream, in order)."""
+        l = lib()
+        need, nt = l.pq_bn_finalize_scratch_bytes(C_), l.pq_bn_finalize_tickets(C_)
+        cur = getattr(self, '_bnfin', None)
+        if cur is None or cur[0].numel() * 8 < need or cur[1].numel() < nt:
+            cmax = max(C_, 2048)
+            need, nt = l.pq_bn_finalize_scratch_bytes(cmax), l.pq_bn_finalize_tickets(cmax)
+            sc = torch.empty(need // 8, device=self.device, dtype=torch.float64)
+            tk = torch.zeros(nt, device=self.device, dtype=torch.int32)
+            self.keep += [sc, tk]
+            self._bnfin = cur = (sc, tk)
+        return cur[0].data_ptr(), cur[1].data_ptr()
+
     def _op(self, lst, code, args) -> int:
         op = abi.Op()
         op.code = code
@@ -380,10 +394,11 @@ class Plan:
                 b = out.bn
                 bm = b.module
                 train = self.bn_train
+                sc, tk = self._bn_scratch(b.C)
                 a = abi.BnFwdFin(ptr(b.fwd_partial) if train else None, ptr(bm.weight), ptr(bm.bias), ptr(bm.running_mean),
                                  ptr(bm.running_var), ptr(bm.num_batches_tracked) if train else None, ptr(b.mean),
                                  ptr(b.invstd), ptr(b.scale), ptr(b.shift), b.fwd_nblk, b.ldp, b.C, int(train), b.count,
-                                 float(bm.eps), float(bm.momentum if bm.momentum is not None else 0.1))
+                                 float(bm.eps), float(bm.momentum if bm.momentum is not None else 0.1), sc, tk)
                 self._op(self.fwd, abi.OP_BN_FWD_FIN, a)
             elif kind == 'copy':
                 _, i, out, a_, b_, coff, up = item
@@ -441,8 +456,9 @@ class Plan:
         def bn_bwd(out: TensorRef):
             b = out.bn
             bm = b.module
+            sc, tk = self._bn_scratch(b.C)
             a = abi.BnBwdFin(ptr(b.bwd_partial), ptr(bm.weight), ptr(b.invstd), flat.grad_ptr(bm.weight), flat.grad_ptr(bm.bias),
-                             ptr(b.p), ptr(b.q), ptr(b.r), b.bwd_nblk, b.ldp, b.C, int(self.bn_train), b.count)
+                             ptr(b.p), ptr(b.q), ptr(b.r), b.bwd_nblk, b.ldp, b.C, int(self.bn_train), b.count, sc, tk)
             self._op(self.bwd, abi.OP_BN_BWD_FIN, a)
 
         def zero_params(m):

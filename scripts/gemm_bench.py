@@ -9,6 +9,8 @@ SHAPES = [(1048576, 16, 96), (1048576, 32, 16), (262144, 24, 144), (262144, 144,
           (65536, 128, 256), (65536, 256, 128), (16384, 64, 384), (16384, 384, 64), (16384, 96, 576), (16384, 576, 96),
           (16384, 256, 512), (16384, 512, 256), (4096, 160, 960), (4096, 960, 160), (4096, 320, 1280), (4096, 1280, 512),
           (4096, 512, 1024), (4096, 1024, 512)]
+if os.environ.get('SWEEP'):
+    SHAPES = [(m, k, n) for (m, n) in ((4096, 512), (4096, 1024), (16384, 256), (65536, 128), (262144, 128)) for k in (32, 64, 128, 256, 512, 1024, 2048)]
 which = sys.argv[1] if len(sys.argv) > 1 else 'fwd,dgrad,wgrad'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 l = abi.lib()

@@ -540,6 +540,52 @@ def test_bn_finalize_matches_batchnorm2d():
     close(y.to(DEV) * sc + sh, bn(yin).detach().view(N, Cc), what='eval normalised')
 
 
+@pytest.mark.parametrize('nblk,Cc', [(1, 16), (64, 40), (65, 100), (700, 96), (8192, 24), (5000, 1280)])
+def test_bn_finalize_long_partial_lists(nblk, Cc):
+    """Several blocks per channel group (ticketed, scratch) give the same sums as one block (no scratch) and as fp64
+    math, twice in a row (the tickets re-arm themselves)."""
+    g = torch.Generator().manual_seed(nblk + Cc)
+    l = abi.lib()
+    ldp = (Cc + 15) // 16 * 16
+    rows = 64.0
+    part = torch.zeros(nblk, 2, ldp)
+    part[:, 0, :Cc] = rnd(nblk, Cc, g=g) * 8 + 3 * rows
+    part[:, 1, :Cc] = part[:, 0, :Cc] ** 2 / rows + torch.rand(nblk, Cc, generator=g) * rows
+    n = rows * nblk
+    s1, s2 = part[:, 0, :Cc].double().sum(0), part[:, 1, :Cc].double().sum(0)
+    mean64 = s1 / n
+    var64 = (s2 / n - mean64 ** 2).clamp(min=0)
+    gam, bet = torch.rand(Cc, generator=g) + 0.5, rnd(Cc, g=g)
+    pd = part.to(DEV)
+    scratch = torch.empty(l.pq_bn_finalize_scratch_bytes(Cc) // 8, dtype=torch.float64, device=DEV)
+    tickets = torch.zeros(l.pq_bn_finalize_tickets(Cc), dtype=torch.int32, device=DEV)
+    res = []
+    for use_scratch in (True, True, False):
+        rm, rv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+        mean, inv, sc, sh = (torch.full((Cc,), float('nan'), device=DEV) for _ in range(4))
+        gd, bd = gam.to(DEV), bet.to(DEV)
+        a = abi.BnFwdFin(pd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr(), None,
+                         mean.data_ptr(), inv.data_ptr(), sc.data_ptr(), sh.data_ptr(), nblk, ldp, Cc, 1, n, 1e-5, 0.1,
+                         scratch.data_ptr() if use_scratch else None, tickets.data_ptr() if use_scratch else None)
+        abi.check(l.pq_bn_fwd_finalize(C.byref(a), stream()))
+        dgam, dbet, pp, qq, rr = (torch.full((Cc,), float('nan'), device=DEV) for _ in range(5))
+        b = abi.BnBwdFin(pd.data_ptr(), gd.data_ptr(), inv.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), pp.data_ptr(),
+                         qq.data_ptr(), rr.data_ptr(), nblk, ldp, Cc, 1, n,
+                         scratch.data_ptr() if use_scratch else None, tickets.data_ptr() if use_scratch else None)
+        abi.check(l.pq_bn_bwd_finalize(C.byref(b), stream()))
+        torch.cuda.synchronize()
+        assert int(tickets.abs().sum().item()) == 0
+        res.append([t.cpu() for t in (mean, inv, sc, sh, rm, rv, dgam, dbet, pp, qq, rr)])
+    for x1, x2 in zip(res[0], res[1]):
+        assert torch.equal(x1, x2)                      # deterministic
+    for x1, x3 in zip(res[0], res[2]):
+        close(x1, x3, rt=1e-6, at=1e-6, what='scratch vs single block')
+    close(res[0][0], mean64.float(), rt=1e-6, at=1e-6, what='mean')
+    close(res[0][1], (1 / torch.sqrt(var64 + 1e-5)).float(), rt=1e-5, at=1e-6, what='invstd')
+    close(res[0][7], s1.float(), rt=1e-6, at=1e-3, what='dbeta = sum of row 0')
+    close(res[0][6], s2.float(), rt=1e-6, at=1e-3, what='dgamma = sum of row 1')
+
+
 # ----------------------------------------------------------------------------------------------- copy / route
 def test_copy_and_route():
     g = torch.Generator().manual_seed(3)
