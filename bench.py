@@ -46,6 +46,7 @@ KERNEL_CLASS = {
     abi.OP_BN_FWD_FIN: ('bn_fwd_finalize', 'hbm'), abi.OP_BN_BWD_FIN: ('bn_bwd_finalize', 'hbm'),
     abi.OP_COPY_FWD: ('copy_fwd (shortcut/route/upsample)', 'hbm'), abi.OP_ROUTE_BWD: ('route_bwd', 'hbm'),
     abi.OP_LOSS_FWD: ('yolo_loss_fwd', 'hbm'), abi.OP_LOSS_BWD: ('yolo_loss_bwd', 'hbm'), abi.OP_FILL: ('fill', 'hbm'),
+    abi.OP_TRANSPOSE: ('weight transposes (one launch)', 'hbm'),
 }
 
 

@@ -102,6 +102,7 @@ typedef struct pq_conv1x1_dgrad_args {
     int32_t M, I, O;
     int32_t sub, OH, OW, IH, IW;   /* sub>1 (strided 1x1 conv): row (b,oy,ox) of dz lands on sink pixel (b,oy*sub,ox*sub); the
                                       sink must then be accumulate-only (finalize==0) -- untouched pixels keep their value */
+    const float* wt;     /* optional [I][O] transposed copy of w (pq_transpose2d): K-contiguous B operand, faster LDS path */
 } pq_conv1x1_dgrad_args;
 int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream);
 
@@ -373,13 +374,27 @@ typedef struct pq_nms_args {
 int pq_nms(const pq_nms_args* a, void* stream);
 int64_t pq_nms_scratch_bytes(int32_t N, int32_t C);
 
+/* ------------------------------------------------------------------ batched 2-D transposes (weights for the dgrad GEMMs)
+ * dst[c][r] = src[r][c] for every item, ONE launch for the whole table (the table itself lives in device memory).
+ * tile0 = number of 32x32 tiles of all previous items, tiles_c = ceil(cols/32). */
+typedef struct pq_transpose_item {
+    const float* src;    /* [rows][cols] */
+    float* dst;          /* [cols][rows] */
+    int32_t rows, cols, tile0, tiles_c;
+} pq_transpose_item;
+typedef struct pq_transpose_args {
+    const pq_transpose_item* items;   /* device pointer */
+    int32_t n_items, total_tiles;
+} pq_transpose_args;
+int pq_transpose_batch(const pq_transpose_args* a, void* stream);
+
 /* ------------------------------------------------------------------ batched executor
  * The engine compiles one training / inference step into an array of pq_op and replays it with ONE host call. */
 enum {
     PQ_OP_CONV1X1_FWD = 1, PQ_OP_CONV1X1_DGRAD, PQ_OP_CONV1X1_WGRAD, PQ_OP_DW_FWD, PQ_OP_DW_DGRAD, PQ_OP_DW_WGRAD,
     PQ_OP_STEM_FWD, PQ_OP_STEM_WGRAD, PQ_OP_BN_FWD_FIN, PQ_OP_BN_BWD_FIN, PQ_OP_COPY_FWD, PQ_OP_ROUTE_BWD,
     PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD,
-    PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD
+    PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD, PQ_OP_TRANSPOSE
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -393,7 +408,7 @@ typedef struct pq_op {
         pq_gconv3x3_fwd_args gcf; pq_gconv3x3_dgrad_args gcd; pq_gconv3x3_wgrad_args gcw;
         pq_bn_fwd_finalize_args bnf; pq_bn_bwd_finalize_args bnb;
         pq_copy_args cp; pq_route_bwd_args rb;
-        pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill;
+        pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill; pq_transpose_args tr;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);

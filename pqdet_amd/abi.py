@@ -43,7 +43,7 @@ class Conv1x1Fwd(C.Structure):
 
 class Conv1x1Dgrad(C.Structure):
     _fields_ = [('dy', GSrc), ('w', c_fp), ('dx', GSink), ('M', i32), ('I', i32), ('O', i32),
-                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32)]
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('wt', c_fp)]
 
 
 class Conv1x1Wgrad(C.Structure):
@@ -166,12 +166,20 @@ class Fill(C.Structure):
     _fields_ = [('dst', c_fp), ('value', f32), ('n', i64)]
 
 
+class TransposeItem(C.Structure):
+    _fields_ = [('src', c_fp), ('dst', c_fp), ('rows', i32), ('cols', i32), ('tile0', i32), ('tiles_c', i32)]
+
+
+class Transpose(C.Structure):
+    _fields_ = [('items', c_fp), ('n_items', i32), ('total_tiles', i32)]
+
+
 class _OpU(C.Union):
     _fields_ = [('c1f', Conv1x1Fwd), ('c1d', Conv1x1Dgrad), ('c1w', Conv1x1Wgrad),
                 ('dwf', DwFwd), ('dwd', DwDgrad), ('dww', DwWgrad), ('dwb', DwBwd), ('stf', StemFwd), ('stw', StemWgrad),
                 ('bnf', BnFwdFin), ('bnb', BnBwdFin), ('cp', Copy), ('rb', RouteBwd),
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
-                ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad)]
+                ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose)]
 
 
 OPF_SIDE = 1
@@ -183,13 +191,14 @@ class Op(C.Structure):
 
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
- OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD) = range(1, 22)
+ OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE) = range(1, 23)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
     OP_DW_WGRAD: 'dww', OP_STEM_FWD: 'stf', OP_STEM_WGRAD: 'stw', OP_BN_FWD_FIN: 'bnf', OP_BN_BWD_FIN: 'bnb',
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
+    OP_TRANSPOSE: 'tr',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -230,6 +239,7 @@ SIGNATURES = {
     'pq_yolo_loss_bwd': (C.c_int, [C.POINTER(YoloLoss), C.c_void_p]),
     'pq_yolo_loss_blocks': (i32, [i32, i32, i32]),
     'pq_iou_pairs': (C.c_int, [c_fp, c_fp, c_fp, i32, i32, C.c_void_p]),
+    'pq_transpose_batch': (C.c_int, [C.POINTER(Transpose), C.c_void_p]),
     'pq_adam_step': (C.c_int, [C.POINTER(Adam), C.c_void_p]),
     'pq_sign_l1': (C.c_int, [c_fp, c_fp, i64, f32, C.c_void_p]),
     'pq_fill': (C.c_int, [c_fp, f32, i64, C.c_void_p]),

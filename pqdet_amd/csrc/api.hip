@@ -40,6 +40,7 @@ static int run_one(const pq_op& op, void* stream) {
         case PQ_OP_GCONV_FWD: return pq_gconv3x3_fwd(&op.u.gcf, stream);
         case PQ_OP_GCONV_DGRAD: return pq_gconv3x3_dgrad(&op.u.gcd, stream);
         case PQ_OP_GCONV_WGRAD: return pq_gconv3x3_wgrad(&op.u.gcw, stream);
+        case PQ_OP_TRANSPOSE: return pq_transpose_batch(&op.u.tr, stream);
         default:
             pq_set_error("pq_run_ops: unknown op code %d", op.code);
             return PQ_EINVAL;
@@ -191,6 +192,8 @@ extern "C" int32_t pq_abi_sizeof(int32_t code) {
         case PQ_OP_GCONV_FWD: return (int32_t)sizeof(pq_gconv3x3_fwd_args);
         case PQ_OP_GCONV_DGRAD: return (int32_t)sizeof(pq_gconv3x3_dgrad_args);
         case PQ_OP_GCONV_WGRAD: return (int32_t)sizeof(pq_gconv3x3_wgrad_args);
+        case PQ_OP_TRANSPOSE: return (int32_t)sizeof(pq_transpose_args);
+        case 103: return (int32_t)sizeof(pq_transpose_item);
         case 100: return (int32_t)sizeof(pq_recover_args);
         case 101: return (int32_t)sizeof(pq_nms_args);
         case 102: return (int32_t)sizeof(pq_decode_bwd_args);

@@ -202,6 +202,32 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     if (part) block_reduce_store_stats<256>(s1, s2, part, a.dx.ldp, c0, a.C, lds);
 }
 
+// ------------------------------------------------------------------------------------------------ batched transpose
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const pq_transpose_item* items, int n) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.x;
+    int lo = 0, hi = n - 1;                      // last item whose tile0 <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+    }
+    const pq_transpose_item it = items[lo];
+    const int local = t - it.tile0;
+    const int r0 = (local / it.tiles_c) * 32, c0 = (local % it.tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < it.rows && c < it.cols) ? it.src[(size_t)r * it.cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < it.cols && r < it.rows) it.dst[(size_t)c * it.rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Adam etc.
 __global__ __launch_bounds__(256) void adam_kernel(pq_adam_args a) {
     const int64_t n4 = a.n / 4;
@@ -303,6 +329,13 @@ extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
     hipLaunchKernelGGL(route_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float),
                        (hipStream_t)stream, p);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_transpose_batch(const pq_transpose_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->items && a->n_items > 0 && a->total_tiles > 0, "bad args");
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(a->total_tiles), dim3(256), 0, (hipStream_t)stream, a->items, a->n_items);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

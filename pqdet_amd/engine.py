@@ -466,6 +466,21 @@ class Plan:
                 o = flat.index[id(p)]
                 self._op(self.bwd, abi.OP_FILL, abi.Fill(flat.grad_views[o].data_ptr(), 0.0, p.numel()))
 
+        # slot 0: one batched transpose of the 1x1 weights whose data gradient is needed (filled in after the loop)
+        tr_idx = self._op(self.bwd, abi.OP_TRANSPOSE, abi.Transpose(None, 0, 0))
+        tr_items = []
+
+        def transposed(conv):
+            """Device address of the [I][O] copy of a 1x1 weight, refreshed at the start of every backward."""
+            O_, I_ = conv.out_channels, conv.in_channels
+            if O_ % 4:
+                return None
+            wt = self._new(I_ * O_)
+            tile0 = tr_items[-1][4] + tr_items[-1][6] if tr_items else 0
+            tiles_c = (I_ + 31) // 32
+            tr_items.append((ptr(conv.weight), wt.data_ptr(), O_, I_, tile0, tiles_c, ((O_ + 31) // 32) * tiles_c))
+            return wt.data_ptr()
+
         for i in range(len(mods) - 1, -1, -1):
             m = mods[i]
             t = m._type
@@ -509,7 +524,7 @@ class Plan:
                             wg_ops.append((idx, 'c1w', need))
                             if src.needs_grad and s == 1:
                                 d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), self._sink(src, l.pq_conv1x1_blocks(src.rows, src.C)), out.rows,
-                                                     src.C, out.C)
+                                                     src.C, out.C, 1, 0, 0, 0, 0, transposed(conv))
                                 self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
                             elif src.needs_grad:
                                 # strided 1x1: dz only lands on every s-th pixel.  The GEMM accumulates into a (zeroed if it
@@ -520,7 +535,7 @@ class Plan:
                                     self._op(self.bwd, abi.OP_FILL, abi.Fill(ptr(src.grad), 0.0, src.rows * src.ld))
                                 acc = abi.GSink(sk.g, sk.y, None, None, None, None, None, src.ld, src.ld, 0, 1, 0, 0)
                                 d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), acc, out.rows, src.C, out.C, s, out.H, out.W, src.H,
-                                                     src.W)
+                                                     src.W, transposed(conv))
                                 self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
                                 if sk.finalize:
                                     sk.accumulate = 0
@@ -585,6 +600,17 @@ class Plan:
                     r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B, srcT.H,
                                      srcT.W, srcT.C, out.ld, 0, f)
                     self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+        if tr_items:
+            table = (abi.TransposeItem * len(tr_items))(*[abi.TransposeItem(*it[:6]) for it in tr_items])
+            dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
+            self.keep.append(dev_table)
+            self.bwd[tr_idx].u.tr = abi.Transpose(dev_table.data_ptr(), len(tr_items), tr_items[-1][4] + tr_items[-1][6])
+        else:                                   # nothing to transpose: turn slot 0 into a no-op
+            dummy = self._new(4)
+            nop = abi.Op()
+            nop.code = abi.OP_FILL
+            nop.u.fill = abi.Fill(dummy.data_ptr(), 0.0, 0)
+            self.bwd[tr_idx] = nop
         # weight-gradient ops only feed the optimiser: they get private scratch and may run on the side stream
         for idx, field, need in wg_ops:
             buf = self._new(max(need, 64) // 4 + 16)

@@ -55,6 +55,9 @@ for (M, I, O) in SHAPES:
         a = abi.Conv1x1Dgrad(abi.GSrc(g.data_ptr(), y.data_ptr() if two else None, p.data_ptr(), q.data_ptr(), mu.data_ptr(), r.data_ptr(), ldo, ldo), w.data_ptr(),
                              abi.GSink(gin.data_ptr(), x.data_ptr(), a2.data_ptr(), b2.data_ptr(), mn.data_ptr(), iv.data_ptr(), part.data_ptr(), I, I, 2, 0, fin, ldp),
                              M, I, O)
+        if os.environ.get('DG_WT'):
+            wt = w.t().contiguous()
+            a.wt = wt.data_ptr()
         ms = timeit(lambda: abi.check(l.pq_conv1x1_dgrad(C.byref(a), st)))
         tot['dgrad'] = tot.get('dgrad', 0) + ms
         line += '| dgrad %.3f ms %5.1f TF %6.0f GB/s ' % (ms, flops / ms / 1e9, byts / ms / 1e6)
