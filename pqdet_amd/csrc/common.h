@@ -150,12 +150,33 @@ __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k
     stg4(gp, dz);
 }
 
+// ---- XCD-aware block numbering ---------------------------------------------------------------------------------
+// MI355X has 8 XCDs with private L2s and deals workgroups to them round-robin by linear block id, so consecutive ids
+// (which normally work on neighbouring rows / tiles and therefore share halo rows or operand panels) land in eight
+// different L2s and every one of them fetches the shared data again.  Every kernel here derives its logical block
+// coordinates from xcd_block(): the ids that one XCD receives (x, x+8, x+16, ...) are mapped onto one CONTIGUOUS slice of
+// the logical index space, so neighbours share an L2.  Pure renumbering (a bijection): correctness never depends on
+// the hardware's actual placement.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    constexpr int NX = 8;
+    if (total < 2 * NX) return lin;
+    const int per = total / NX, rem = total - per * NX;
+    const int x = lin % NX, j = lin / NX;
+    return x * per + min(x, rem) + j;
+}
+__device__ __forceinline__ void xcd_block(int& bx, int& by) {
+    const int gx = gridDim.x;
+    const int t = xcd_remap(blockIdx.y * gx + blockIdx.x, gx * (int)gridDim.y);
+    by = t / gx;
+    bx = t - by * gx;
+}
+
 // ---- 2-D thread layout used by the NHWC elementwise / depthwise kernels ----------------------------------------
 // blockDim = (CX, PY): CX lanes walk channel quads (float4), PY walks rows / pixel groups.
-// Reduce two float4 accumulators over threadIdx.y and store to partial[blockIdx.x][0|1][ldp].
+// Reduce two float4 accumulators over threadIdx.y and store to partial[bx][0|1][ldp] (bx = logical row-block).
 template <int MAXT>
 __device__ __forceinline__ void block_reduce_store_stats(float4 s1, float4 s2, float* partial, int ldp, int c0, int C,
-                                                         float* lds /* >= MAXT*8 floats */) {
+                                                         float* lds /* >= MAXT*8 floats */, int bx) {
     const int tx = threadIdx.x, ty = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
     float* slot = lds + (size_t)(ty * nx + tx) * 8;
     slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
@@ -170,7 +191,7 @@ __device__ __forceinline__ void block_reduce_store_stats(float4 s1, float4 s2, f
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += o[j];
         }
-        float* dst = partial + (size_t)blockIdx.x * 2 * ldp;
+        float* dst = partial + (size_t)bx * 2 * ldp;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (c0 + j < C) { dst[c0 + j] = acc[j]; dst[ldp + c0 + j] = acc[4 + j]; }

@@ -35,7 +35,9 @@ template <int S, int TW, bool GRAD>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int c4 = blockIdx.y * blockDim.x + tx;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx;
     const int c0 = c4 * 4;
     const bool cok = c4 < p.C4;
     const int OWG = (p.OW + TW - 1) / TW;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
     const SinkCoef4 sk = sink_coef4(p.sink, c0, p.C);
     float4 s1 = f4zero(), s2 = f4zero();
 
-    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
+    for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int oxg = (int)(it % OWG);
         const int t2 = it / OWG;
         const int oy = (int)(t2 % p.OH);
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
         }
     }
     float* part = GRAD ? ((p.sink.finalize && p.sink.mean) ? p.sink.partial : nullptr) : p.partial;
-    if (part) block_reduce_store_stats<256>(s1, s2, part, GRAD ? p.sink.ldp : p.ldp, c0, p.C, lds);
+    if (part) block_reduce_store_stats<256>(s1, s2, part, GRAD ? p.sink.ldp : p.ldp, c0, p.C, lds, bx);
 }
 
 // ---- dgrad, generic stride (used for stride 2): one input pixel per thread step, predicated taps.
@@ -112,7 +114,9 @@ template <int S>
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int c4 = blockIdx.y * blockDim.x + tx;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx;
     const int c0 = c4 * 4;
     const bool cok = c4 < p.C4;
     const int items = p.B * p.IH * p.IW;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwP p) {
     const GsrcCoef4 gk = gsrc_coef4(p.dy, c0, p.C);
     const SinkCoef4 sk = sink_coef4(p.sink, c0, p.C);
     float4 s1 = f4zero(), s2 = f4zero();
-    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
+    for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int ix = (int)(it % p.IW);
         const int t2 = it / p.IW;
         const int iy = (int)(t2 % p.IH);
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwP p) {
         sink_emit4(p.sink, sk, (size_t)it, c0, acc, s1, s2);
     }
     float* part = (p.sink.finalize && p.sink.mean) ? p.sink.partial : nullptr;
-    if (part) block_reduce_store_stats<256>(s1, s2, part, p.sink.ldp, c0, p.C, lds);
+    if (part) block_reduce_store_stats<256>(s1, s2, part, p.sink.ldp, c0, p.C, lds, bx);
 }
 
 // ---- wgrad: dw[c][ky][kx] = sum dy'[b,oy,ox,c] * x'[b,oy*S+ky-1,ox*S+kx-1,c]
@@ -169,7 +173,9 @@ template <int S, int TW>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tx = threadIdx.x, ty = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
-    const int c4 = blockIdx.y * blockDim.x + tx;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx;
     const int c0 = c4 * 4;
     const bool cok = c4 < p.C4;
     const int OWG = (p.OW + TW - 1) / TW;
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwP p) {
     float4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f4zero();
-    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
+    for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int oxg = (int)(it % OWG);
         const int t2 = it / OWG;
         const int oy = (int)(t2 % p.OH);
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwP p) {
         if (ty == 0 && cok) {
             float4 s = f4zero();
             for (int y = 0; y < ny; ++y) s = f4add(s, l4[y * nx + tx]);
-            float* dst = p.wpartial + ((size_t)blockIdx.x * p.C + c0) * 9 + t;
+            float* dst = p.wpartial + ((size_t)bx * p.C + c0) * 9 + t;
             if (c0 + 0 < p.C) dst[0] = s.x;
             if (c0 + 1 < p.C) dst[9] = s.y;
             if (c0 + 2 < p.C) dst[18] = s.z;
@@ -276,7 +282,9 @@ template <int CI>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int c4 = blockIdx.y * blockDim.x + tx, c0 = c4 * 4;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx, c0 = c4 * 4;
     const bool cok = c4 < p.O4;
     float4 wk[CI * 9];
 #pragma unroll
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemP p) {
     const int items = p.B * p.OH * p.OW;
     const size_t plane = (size_t)p.IH * p.IW;
     float4 s1 = f4zero(), s2 = f4zero();
-    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
+    for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int ox = (int)(it % p.OW);
         const int t2 = it / p.OW;
         const int oy = (int)(t2 % p.OH);
@@ -326,14 +334,16 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemP p) {
         s1 = f4add(s1, acc);
         s2 = f4fma(acc, acc, s2);
     }
-    if (p.partial) block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, lds);
+    if (p.partial) block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, lds, bx);
 }
 
 template <int CI>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tx = threadIdx.x, ty = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
-    const int c4 = blockIdx.y * blockDim.x + tx, c0 = c4 * 4;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx, c0 = c4 * 4;
     const bool cok = c4 < p.O4;
     const GsrcCoef4 gk = gsrc_coef4(p.dy, c0, p.O);
     float4 acc[CI * 9];
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemP p) {
     for (int t = 0; t < CI * 9; ++t) acc[t] = f4zero();
     const int items = p.B * p.OH * p.OW;
     const size_t plane = (size_t)p.IH * p.IW;
-    for (int it = blockIdx.x * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
+    for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int ox = (int)(it % p.OW);
         const int t2 = it / p.OW;
         const int oy = (int)(t2 % p.OH);
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemP p) {
         if (ty == 0 && cok) {
             float4 s = f4zero();
             for (int y = 0; y < ny; ++y) s = f4add(s, l4[y * nx + tx]);
-            float* dst = p.wpartial + ((size_t)blockIdx.x * p.O + c0) * (CI * 9) + t;
+            float* dst = p.wpartial + ((size_t)bx * p.O + c0) * (CI * 9) + t;
             if (c0 + 0 < p.O) dst[0] = s.x;
             if (c0 + 1 < p.O) dst[CI * 9] = s.y;
             if (c0 + 2 < p.O) dst[2 * CI * 9] = s.z;

@@ -44,11 +44,12 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
     __shared__ float red[32 * 8 * 8];
     const int t = threadIdx.x;
     const int q = t & 7, pl = t >> 3;                       // quad, pixel lane
-    const int tIdx = blockIdx.x;
+    int tIdx, bcy;
+    xcd_block(tIdx, bcy);
     const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
     const int oy0 = th * T::OTH, ox0 = tw * T::OTW;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-    const int cq0 = blockIdx.y * CBQ;                       // first quad of this block's channel chunk
+    const int cq0 = bcy * CBQ;                       // first quad of this block's channel chunk
     const int c0 = (cq0 + q) * 4;
     const bool cok = cq0 + q < p.C4;
     const int cc = cok ? c0 : 0;                            // clamped channel offset for address generation
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
             const int c = (cq0 + qq) * 4 + (comp & 3);
-            if (c < p.C) p.partial[(size_t)blockIdx.x * 2 * p.ldp + (comp >> 2) * p.ldp + c] = a;
+            if (c < p.C) p.partial[(size_t)tIdx * 2 * p.ldp + (comp >> 2) * p.ldp + c] = a;
         }
     }
 }
@@ -169,10 +170,11 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
     __shared__ float red[32 * 8 * 8];
     const int t = threadIdx.x;
     const int q = t & 7, pl = t >> 3;
-    const int tIdx = blockIdx.x;
+    int tIdx, bcy;
+    xcd_block(tIdx, bcy);
     const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
     const int y0 = th * TH, x0 = tw * TWD;
-    const int cq0 = blockIdx.y * CBQ;
+    const int cq0 = bcy * CBQ;
     const int c0 = (cq0 + q) * 4;
     const bool cok = cq0 + q < p.C4;
     const int cc = cok ? c0 : 0;
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 4 + comp];
             const int c = (cq0 + qq) * 4 + comp;
-            if (c < p.C) p.wpartial[((size_t)blockIdx.x * p.C + c) * 9 + k] = a;
+            if (c < p.C) p.wpartial[((size_t)tIdx * p.C + c) * 9 + k] = a;
         }
     }
     if (p.sink.finalize && p.sink.mean && p.sink.partial) {     // uniform
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
             const int c = (cq0 + qq) * 4 + (comp & 3);
-            if (c < p.C) p.sink.partial[(size_t)blockIdx.x * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
+            if (c < p.C) p.sink.partial[(size_t)tIdx * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
         }
     }
 }
@@ -323,12 +325,13 @@ __global__ __launch_bounds__(256) void dwt_bwd_kernel(DwTP p) {
     __shared__ float red[32 * 8 * 8];
     const int t = threadIdx.x;
     const int q = t & 7, pl = t >> 3;
-    const int tIdx = blockIdx.x;
+    int tIdx, bcy;
+    xcd_block(tIdx, bcy);
     const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
     const int y0 = th * T::DXH, x0 = tw * T::DXW;                        // first input pixel of the dx tile
     const int oy0 = (S == 1) ? y0 - 1 : y0 / 2, ox0 = (S == 1) ? x0 - 1 : x0 / 2;     // first output pixel of the dy' tile
     const int xy0 = y0 - 1, xx0 = x0 - 1;                                  // first input pixel of the x' tile
-    const int cq0 = blockIdx.y * CBQ;
+    const int cq0 = bcy * CBQ;
     const int c0 = (cq0 + q) * 4;
     const bool cok = cq0 + q < p.C4;
     const int cc = cok ? c0 : 0;
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(256) void dwt_bwd_kernel(DwTP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 4 + comp];
             const int c = (cq0 + qq) * 4 + comp;
-            if (c < p.C) p.wpartial[((size_t)blockIdx.x * p.C + c) * 9 + k] = a;
+            if (c < p.C) p.wpartial[((size_t)tIdx * p.C + c) * 9 + k] = a;
         }
     }
     if (p.sink.finalize && p.sink.mean && p.sink.partial) {     // uniform
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(256) void dwt_bwd_kernel(DwTP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
             const int c = (cq0 + qq) * 4 + (comp & 3);
-            if (c < p.C) p.sink.partial[(size_t)blockIdx.x * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
+            if (c < p.C) p.sink.partial[(size_t)tIdx * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
         }
     }
 }

@@ -148,14 +148,16 @@ struct CopyP { pq_copy_args a; int C4; };
 
 __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
     const pq_copy_args& a = p.a;
-    const int c4 = blockIdx.y * blockDim.x + threadIdx.x, c0 = c4 * 4;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + threadIdx.x, c0 = c4 * 4;
     if (c4 >= p.C4) return;
     const SrcCoef4 ka = src_coef4(a.a, c0, a.C);
     const SrcCoef4 kb = src_coef4(a.b, c0, a.C);
     const bool two = a.b.x != nullptr;
     const int rows = a.B * a.H * a.W;
     const int SH = a.H / a.up, SW = a.W / a.up;
-    for (int r = blockIdx.x * blockDim.y + threadIdx.y; r < rows; r += gridDim.x * blockDim.y) {
+    for (int r = bx * blockDim.y + threadIdx.y; r < rows; r += gridDim.x * blockDim.y) {
         size_t sr = (size_t)r;
         if (a.up > 1) {
             const int x = (int)(r % a.W);
@@ -175,13 +177,15 @@ struct RouteP { pq_route_bwd_args a; int C4; };
 __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pq_route_bwd_args& a = p.a;
-    const int c4 = blockIdx.y * blockDim.x + threadIdx.x, c0 = c4 * 4;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + threadIdx.x, c0 = c4 * 4;
     const bool cok = c4 < p.C4;
     const SinkCoef4 sk = sink_coef4(a.dx, c0, a.C);
     const int rows = a.B * a.H * a.W;
     const int OH = a.H * a.up, OW = a.W * a.up;
     float4 s1 = f4zero(), s2 = f4zero();
-    for (int r = blockIdx.x * blockDim.y + threadIdx.y; r < rows && cok; r += gridDim.x * blockDim.y) {
+    for (int r = bx * blockDim.y + threadIdx.y; r < rows && cok; r += gridDim.x * blockDim.y) {
         float4 dz = f4zero();
         if (a.up == 1) {
             dz = ldg4(a.gout + (size_t)r * a.ldgo + a.coff + c0);
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
         sink_emit4(a.dx, sk, (size_t)r, c0, dz, s1, s2);
     }
     float* part = (a.dx.finalize && a.dx.mean) ? a.dx.partial : nullptr;
-    if (part) block_reduce_store_stats<256>(s1, s2, part, a.dx.ldp, c0, a.C, lds);
+    if (part) block_reduce_store_stats<256>(s1, s2, part, a.dx.ldp, c0, a.C, lds, bx);
 }
 
 // ------------------------------------------------------------------------------------------------ batched transpose

@@ -45,9 +45,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
     float* Bt = smem + (size_t)ITH * ITW * pitch * 4;                   // [32][KP]
     float* red = Bt + 32 * KP;                                          // [2][4][32]
 
-    const int tIdx = blockIdx.x;
+    int tIdx, g;
+    xcd_block(tIdx, g);
     const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
-    const int g = blockIdx.y;
     const int oy0 = th * GTH, ox0 = tw * GTW;
     const int ay0 = oy0 * S - 1, ax0 = ox0 * S - 1;
     const int cbase = g * gw;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
             for (int q = 0; q < 4; ++q) { a += red[(0 * 4 + q) * 32 + t]; bsum += red[(1 * 4 + q) * 32 + t]; }
             float* part = (EMODE == 2) ? p.sink.partial : p.partial;
             const int ldp = (EMODE == 2) ? p.sink.ldp : p.ldp;
-            float* dst = part + (size_t)blockIdx.x * 2 * ldp;
+            float* dst = part + (size_t)tIdx * 2 * ldp;
             dst[cbase + t] = a;
             dst[ldp + cbase + t] = bsum;
         }

@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w / NWN, wn = w % NWN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bnx, bmy;              // XCD-aware numbering: one L2 serves all column tiles of a row panel
+    xcd_block(bnx, bmy);
+    const int m0 = bmy * BM, n0 = bnx * BN;
     const int M = p.M, N = p.N, K = p.K;
     const ActParam aact = act_param(p.act);
 
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             for (int q = 0; q < BM / WM; ++q) { a += red[(0 * 4 + q) * 192 + t]; b += red[(1 * 4 + q) * 192 + t]; }
             const int n = n0 + t;
             if (n < N) {
-                float* dst = part + (size_t)blockIdx.y * 2 * ldp;
+                float* dst = part + (size_t)bmy * 2 * ldp;
                 dst[n] = a;
                 dst[ldp + n] = b;
             }
@@ -396,9 +398,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTP p) {
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wo = w >> 1, wi = w & 1;
     const int tiles_i = (p.I + BIc - 1) / BIc;
-    const int to = blockIdx.x / tiles_i, ti = blockIdx.x % tiles_i;
+    int btile, split;
+    xcd_block(btile, split);
+    const int to = btile / tiles_i, ti = btile % tiles_i;
     const int o0 = to * BO, i0 = ti * BIc;
-    const int split = blockIdx.y;
     const int mbeg = split * p.rows_per_split;
     const int mend = min(p.M, mbeg + p.rows_per_split);
 
