@@ -358,6 +358,25 @@ typedef struct pq_recover_args {
 } pq_recover_args;
 int pq_recover(const pq_recover_args* a, void* stream);
 
+/* Label assignment for a batch: TrainDataset.create_label + collate_batch padding (dataset/train_dataset.py:16-43,109-150).
+ *   gt [B][G][6] = x1,y1,x2,y2,class,mix-up weight (rows >= counts[b] ignored; counts NULL: all G rows are boxes)
+ *   label[s] [B][H[s]][W[s]][3][6+C] (fully written: zeros, mix-up weight 1, then the assigned rows in box order)
+ *   boxes[s] [B][cap][4] zero padded, insertion order, duplicates kept; box_counts [B][3] rows used (may be NULL).
+ *   The reference pads the lists to the batch maximum; any cap >= that maximum is equivalent for the loss (all-zero rows
+ *   have IoU 0 with every prediction), cap = 3*G always suffices. */
+typedef struct pq_create_label_args {
+    const float* gt;
+    const int32_t* counts;
+    const float* anchors;    /* [9][2] (w,h), scale-major: 3 per scale */
+    float* label[3];
+    float* boxes[3];
+    int32_t* box_counts;
+    int32_t H[3], W[3], stride[3];
+    int32_t B, G, C, gt_per_grid, cap;
+    float iou_threshold;
+} pq_create_label_args;
+int pq_create_label(const pq_create_label_args* a, void* stream);
+
 /* NMS: tools.py:540-566 torch_nms (+ torchvision batched_nms, restated).  One image per call.
  *   in  : bboxes [N][4+C] (recovered), score_thr, iou_thr
  *   out : dets [cap][6] rows (x1,y1,x2,y2,score,class) in score-descending order, *count = K (device int32)
@@ -427,7 +446,7 @@ int pq_last_failed_op(void);
 const char* pq_last_error(void);
 const char* pq_version(void);
 /* sizeof() of the argument struct of op `code` (0: pq_op, 100: pq_recover_args, 101: pq_nms_args,
- * 102: pq_decode_bwd_args) -- lets a foreign-language binding verify its struct layout at load time */
+ * 102: pq_decode_bwd_args, 103: pq_transpose_item, 104: pq_create_label_args) -- lets a foreign-language binding verify its struct layout at load time */
 int32_t pq_abi_sizeof(int32_t code);
 
 #ifdef __cplusplus

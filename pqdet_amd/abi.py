@@ -162,6 +162,12 @@ class Nms(C.Structure):
                 ('N', i32), ('C', i32), ('cap', i32), ('score_thr', f32), ('iou_thr', f32)]
 
 
+class CreateLabel(C.Structure):
+    _fields_ = [('gt', c_fp), ('counts', c_fp), ('anchors', c_fp), ('label', c_fp * 3), ('boxes', c_fp * 3),
+                ('box_counts', c_fp), ('H', i32 * 3), ('W', i32 * 3), ('stride', i32 * 3),
+                ('B', i32), ('G', i32), ('C', i32), ('gt_per_grid', i32), ('cap', i32), ('iou_threshold', f32)]
+
+
 class Fill(C.Structure):
     _fields_ = [('dst', c_fp), ('value', f32), ('n', i64)]
 
@@ -244,6 +250,7 @@ SIGNATURES = {
     'pq_sign_l1': (C.c_int, [c_fp, c_fp, i64, f32, C.c_void_p]),
     'pq_fill': (C.c_int, [c_fp, f32, i64, C.c_void_p]),
     'pq_recover': (C.c_int, [C.POINTER(Recover), C.c_void_p]),
+    'pq_create_label': (C.c_int, [C.POINTER(CreateLabel), C.c_void_p]),
     'pq_nms': (C.c_int, [C.POINTER(Nms), C.c_void_p]),
     'pq_nms_scratch_bytes': (i64, [i32, i32]),
     'pq_run_ops': (C.c_int, [C.POINTER(Op), i32, C.c_void_p]),

@@ -194,6 +194,7 @@ extern "C" int32_t pq_abi_sizeof(int32_t code) {
         case PQ_OP_GCONV_WGRAD: return (int32_t)sizeof(pq_gconv3x3_wgrad_args);
         case PQ_OP_TRANSPOSE: return (int32_t)sizeof(pq_transpose_args);
         case 103: return (int32_t)sizeof(pq_transpose_item);
+        case 104: return (int32_t)sizeof(pq_create_label_args);
         case 100: return (int32_t)sizeof(pq_recover_args);
         case 101: return (int32_t)sizeof(pq_nms_args);
         case 102: return (int32_t)sizeof(pq_decode_bwd_args);

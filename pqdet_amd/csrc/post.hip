@@ -46,6 +46,95 @@ __global__ __launch_bounds__(256) void recover_kernel(pq_recover_args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ label assignment
+// TrainDataset.create_label (dataset/train_dataset.py:109-150) for a whole batch.  One wave per image walks its ground
+// truth boxes IN ORDER (later boxes overwrite earlier ones in a cell, and the per-scale box lists keep insertion order and
+// duplicates), the 64 lanes cooperate on each (6+C)-float label row.  Arithmetic follows NumPy's promotions in the
+// reference expression by expression: box corners / centre / size in float32, everything that meets the int64 strides or
+// the anchor table (cell index, cell centre, anchor IoU, smoothed one-hot) in float64.
+__global__ __launch_bounds__(256) void label_init_kernel(pq_create_label_args a) {
+    const int nv = 6 + a.C;
+    for (int s = 0; s < 3; ++s) {
+        const long n = (long)a.B * a.H[s] * a.W[s] * a.gt_per_grid * nv;
+        float* dst = a.label[s];
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (i % nv == nv - 1) ? 1.f : 0.f;
+        const long m = (long)a.B * a.cap * 4;
+        float* bl = a.boxes[s];
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long)gridDim.x * 256) bl[i] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(64) void label_assign_kernel(pq_create_label_args a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nv = 6 + a.C;
+    const int n = min(a.counts ? a.counts[b] : a.G, a.G);
+    int filled[3] = {0, 0, 0};
+    for (int gi = 0; gi < n; ++gi) {
+        const float* box = a.gt + ((size_t)b * a.G + gi) * 6;
+        const float x1 = box[0], y1 = box[1], x2 = box[2], y2 = box[3];
+        const int cls = (int)box[4];
+        const float mix = box[5];
+        const float cx = (x2 + x1) * 0.5f, cy = (y2 + y1) * 0.5f, bw = x2 - x1, bh = y2 - y1;     // float32, as in NumPy
+        // lanes 0..8: IoU of the box with anchor k centred on its cell of scale k/3 (float64)
+        double iou = -1.0;
+        int cellx[3], celly[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            cellx[s] = (int)floor((double)cx / (double)a.stride[s]);
+            celly[s] = (int)floor((double)cy / (double)a.stride[s]);
+        }
+        if (lane < 9) {
+            const int s = lane / 3;
+            const double acx = (double)((float)cellx[s] + 0.5f) * (double)a.stride[s];
+            const double acy = (double)((float)celly[s] + 0.5f) * (double)a.stride[s];
+            const double aw = (double)a.anchors[lane * 2 + 0], ah = (double)a.anchors[lane * 2 + 1];
+            const float area1 = bw * bh;                                                               // float32 product
+            const double area2 = aw * ah;
+            const float l1 = cx - bw * 0.5f, t1 = cy - bh * 0.5f, r1 = cx + bw * 0.5f, b1 = cy + bh * 0.5f;
+            const double l2 = acx - aw * 0.5, t2 = acy - ah * 0.5, r2 = acx + aw * 0.5, b2 = acy + ah * 0.5;
+            const double iw = fmax(fmin((double)r1, r2) - fmax((double)l1, l2), 0.0);
+            const double ih = fmax(fmin((double)b1, b2) - fmax((double)t1, t2), 0.0);
+            const double inter = iw * ih;
+            iou = inter / ((double)area1 + area2 - inter);
+        }
+        unsigned long long hit = __ballot(lane < 9 && iou > (double)a.iou_threshold) & 0x1ffull;
+        if (hit == 0) {                                           // no anchor passes: the best one is taken (first maximum)
+            double best = iou;
+            int arg = lane;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const double ob = __shfl_down(best, off);
+                const int oa = __shfl_down(arg, off);
+                const bool take = (lane + off < 9) && (lane < 9) && (ob > best || (ob == best && oa < arg));
+                if (take) { best = ob; arg = oa; }
+            }
+            hit = 1ull << __shfl(arg, 0);
+        }
+        for (int k = 0; k < 9; ++k) {
+            if (!((hit >> k) & 1ull)) continue;
+            const int s = k / 3, slot = k % 3;
+            const int gx = cellx[s], gy = celly[s];
+            if (gx >= 0 && gx < a.W[s] && gy >= 0 && gy < a.H[s]) {
+                float* row = a.label[s] + ((((size_t)b * a.H[s] + gy) * a.W[s] + gx) * a.gt_per_grid + slot) * nv;
+                for (int e = lane; e < nv; e += 64) {
+                    float v;
+                    if (e < 4) v = box[e];
+                    else if (e == 4) v = 1.f;
+                    else if (e == nv - 1) v = mix;
+                    else {
+                        const double onehot = (e - 5 == cls) ? 1.0 : 0.0;
+                        v = (float)(onehot * (1.0 - 0.01) + 0.01 * (1.0 / (double)a.C));
+                    }
+                    row[e] = v;
+                }
+            }
+            if (filled[s] < a.cap && lane < 4) a.boxes[s][((size_t)b * a.cap + filled[s]) * 4 + lane] = box[lane];
+            filled[s] += 1;
+        }
+    }
+    if (lane < 3 && a.box_counts) a.box_counts[b * 3 + lane] = min(filled[lane], a.cap);
+}
+
 // ------------------------------------------------------------------------------------------------ NMS
 struct NmsMeta { unsigned count; unsigned maxbits; unsigned kept; unsigned pad; };
 
@@ -236,6 +325,18 @@ extern "C" int pq_recover(const pq_recover_args* a, void* stream) {
     long rows = (long)a->B * a->N;
     long nb = (rows + 255) / 256; if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(recover_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_create_label(const pq_create_label_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->gt && a->anchors, "null pointer");
+    PQ_CHECK_ARG(a->B > 0 && a->G > 0 && a->C > 0 && a->gt_per_grid == 3 && a->cap > 0, "bad shape (3 anchors per scale)");
+    for (int s = 0; s < 3; ++s) PQ_CHECK_ARG(a->label[s] && a->boxes[s] && a->H[s] > 0 && a->W[s] > 0 && a->stride[s] > 0, "bad scale description");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(label_init_kernel, dim3(1024), dim3(256), 0, st, *a);
+    PQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(label_assign_kernel, dim3(a->B), dim3(64), 0, st, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

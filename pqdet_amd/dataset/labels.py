@@ -1,7 +1,8 @@
 """Label assignment on the host (numpy) -- mirrors the reference ``TrainDataset.create_label`` and the box padding of
 ``collate_batch`` (``dataset/train_dataset.py:16-43,109-150``; anchors / strides / IoU threshold defaults from
 ``config.py:56-61``).  This is the producer of the 6-tuple ``DetectionModel.forward(x, target)`` consumes; it runs in
-DataLoader workers in the reference and stays a host function here (a device version is the next scope row).
+DataLoader workers in the reference; :func:`create_label_batch` is the device version for a whole batch (``pq_create_label``),
+bit-identical to the host function.
 """
 from typing import List, Sequence, Tuple
 
@@ -75,3 +76,18 @@ def synthetic_targets(batch: int, size: int, num_classes: int, seed: int = 1, ma
             grids[i].append(out[i])
             lists[i].append(out[3 + i])
     return tuple(torch.from_numpy(np.stack(g, 0)) for g in grids) + tuple(torch.from_numpy(pad_box_lists(l)) for l in lists)
+
+
+def create_label_batch(gt: torch.Tensor, counts, size_hw, num_classes: int, trim: bool = True):
+    """Device label assignment for a batch: ``gt`` (B, G, 6) on the GPU (rows past ``counts[b]`` ignored), input size
+    ``(H, W)`` -> the 6-tuple ``DetectionModel.forward`` takes.  ``trim=True`` cuts the box lists to the batch maximum like
+    the reference's ``collate_batch`` (one host synchronisation); ``trim=False`` keeps the 3*G capacity -- equivalent for the
+    loss, which ignores all-zero rows -- and never synchronises."""
+    from .. import ops
+    h, w = size_hw
+    out_hw = [(h // s, w // s) for s in STRIDES]
+    ls, lm, ll, bs, bm, bl, cnt = ops.create_label(gt, counts, out_hw, num_classes)
+    if trim:
+        m = cnt.max(0).values.clamp(min=1).tolist()
+        bs, bm, bl = bs[:, :m[0]].contiguous(), bm[:, :m[1]].contiguous(), bl[:, :m[2]].contiguous()
+    return ls, lm, ll, bs, bm, bl

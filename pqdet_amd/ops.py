@@ -210,3 +210,36 @@ def sign_l1(grad: torch.Tensor, weight: torch.Tensor, ratio: float):
         raise ValueError('sign_l1 needs contiguous tensors of equal size')
     check(lib().pq_sign_l1(ptr(grad), ptr(weight), grad.numel(), float(ratio), _stream()), 'pq_sign_l1')
     return grad
+
+
+def create_label(gt: torch.Tensor, counts, out_hw, num_classes: int, strides=(8, 16, 32), anchors=None,
+                 iou_threshold: float = 0.3, cap: Optional[int] = None):
+    """Batch label assignment on the device (``pq_create_label``).
+
+    gt (B, G, 6) float32 rows x1,y1,x2,y2,class,mix-up weight; counts (B,) int32 number of real rows per image or None.
+    -> (label_s, label_m, label_l, boxes_s, boxes_m, boxes_l, box_counts[B,3]); box lists are (B, cap, 4)."""
+    _need_cuda(gt)
+    gt = gt.contiguous().float()
+    b, g, six = gt.shape
+    if six != 6:
+        raise ValueError('gt rows must be [x1, y1, x2, y2, class, mixw]')
+    dev = gt.device
+    cap = cap or 3 * g
+    if anchors is None:
+        anchors = torch.tensor([(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119), (116, 90), (156, 198),
+                                (373, 326)], dtype=torch.float32)
+    anchors = anchors.to(dev, torch.float32).contiguous()
+    if counts is not None:
+        counts = counts.to(dev, torch.int32).contiguous()
+    labels = [torch.empty(b, h, w, 3, 6 + num_classes, device=dev) for h, w in out_hw]
+    boxes = [torch.empty(b, cap, 4, device=dev) for _ in range(3)]
+    box_counts = torch.zeros(b, 3, device=dev, dtype=torch.int32)
+    a = abi.CreateLabel()
+    a.gt, a.counts, a.anchors = ptr(gt), ptr(counts), ptr(anchors)
+    for s in range(3):
+        a.label[s], a.boxes[s] = ptr(labels[s]), ptr(boxes[s])
+        a.H[s], a.W[s], a.stride[s] = int(out_hw[s][0]), int(out_hw[s][1]), int(strides[s])
+    a.box_counts = ptr(box_counts)
+    a.B, a.G, a.C, a.gt_per_grid, a.cap, a.iou_threshold = b, g, num_classes, 3, cap, float(iou_threshold)
+    check(lib().pq_create_label(C.byref(a), _stream()), 'pq_create_label')
+    return (*labels, *boxes, box_counts)

@@ -789,3 +789,39 @@ def test_nms_empty_and_ties():
     want = opost.torch_nms(bb.numpy(), 0.1, 0.45)
     got = tools.torch_nms(bb.to(DEV), 0.1, 0.45).cpu().numpy()
     np.testing.assert_array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------------------------- label assignment
+@pytest.mark.parametrize('B,S,ncls,seed', [(4, 256, 20, 1), (16, 512, 20, 2), (3, 128, 5, 3), (2, 960, 10, 4)])
+def test_create_label_matches_host_assignment_bit_exactly(B, S, ncls, seed):
+    from pqdet_amd.dataset import labels
+    rng = np.random.RandomState(seed)
+    per_image, G = [], 0
+    for b in range(B):
+        n = rng.randint(0, 9) if b else 8                     # includes images without boxes
+        boxes = []
+        for _ in range(n):
+            w, h = rng.uniform(4, S * 0.6, 2)
+            x1, y1 = rng.uniform(0, S - w), rng.uniform(0, S - h)
+            boxes.append(np.array([x1, y1, x1 + w, y1 + h, rng.randint(0, ncls), rng.uniform(0.3, 1.0)], dtype=np.float32))
+        if b == 0:
+            boxes[3] = boxes[1].copy(); boxes[3][4] = (boxes[1][4] + 1) % ncls     # same cells: the later box wins
+            boxes[5][:4] = np.array([7, 9, 9.5, 11], np.float32)                   # tiny box: no anchor passes 0.3 -> arg-max
+        per_image.append(boxes)
+        G = max(G, n)
+    hw = np.array([[S // s, S // s] for s in (8, 16, 32)])
+    want = [labels.create_label(bx, hw, ncls) for bx in per_image]
+    gt = np.zeros((B, G, 6), np.float32)
+    for b, bx in enumerate(per_image):
+        if bx:
+            gt[b, :len(bx)] = np.stack(bx)
+    counts = torch.tensor([len(bx) for bx in per_image], dtype=torch.int32)
+    got = labels.create_label_batch(torch.from_numpy(gt).to(DEV), counts, (S, S), ncls)
+    for s in range(3):
+        np.testing.assert_array_equal(got[s].cpu().numpy(), np.stack([w_[s] for w_ in want]))
+        np.testing.assert_array_equal(got[3 + s].cpu().numpy(), labels.pad_box_lists([w_[3 + s] for w_ in want]))
+    # untrimmed lists: same rows, zero tail
+    full = labels.create_label_batch(torch.from_numpy(gt).to(DEV), counts, (S, S), ncls, trim=False)
+    for s in range(3):
+        m = got[3 + s].shape[1]
+        assert torch.equal(full[3 + s][:, :m], got[3 + s]) and float(full[3 + s][:, m:].abs().sum()) == 0.0

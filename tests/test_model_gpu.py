@@ -232,6 +232,42 @@ def test_config4_shape_regnetx_pan_960_batch8():
     assert ev.shape == (2, 3 * (120 * 120 + 60 * 60 + 30 * 30), 25)
 
 
+def test_edge_cases_empty_targets_batch_one_and_untrimmed_box_lists():
+    from pqdet_amd.dataset import labels
+    net, ref = _pair(seed=9)
+    net.train(), ref.train()
+    S, ncls = 96, 20
+    rng = np.random.RandomState(5)
+    per_image = [[], [np.array([10, 12, 70, 80, 3, 1.0], np.float32), np.array([30, 5, 90, 60, 7, 0.6], np.float32)]]
+    hw = np.array([[S // s, S // s] for s in (8, 16, 32)])
+    host = [labels.create_label(bx, hw, ncls) for bx in per_image]
+    tgt = tuple([torch.from_numpy(np.stack([h[i] for h in host])) for i in range(3)]
+                + [torch.from_numpy(labels.pad_box_lists([h[3 + i] for h in host])) for i in range(3)])
+    x = seeded_images(2, S, S, 12)
+    out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    want = ref(x, tgt)
+    for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss'):
+        assert abs(out[k].item() - want[k].item()) <= 1e-3 * abs(want[k].item()) + 1e-5, k
+    # the same targets produced on the device, with the box lists left at their 3*G capacity: identical losses
+    gt = np.zeros((2, 2, 6), np.float32)
+    gt[1] = np.stack(per_image[1])
+    dev_t = labels.create_label_batch(torch.from_numpy(gt).to(DEV), torch.tensor([0, 2], dtype=torch.int32), (S, S), ncls,
+                                      trim=False)
+    out2 = net(x.to(DEV), dev_t)
+    # forward 1 updated the BN running statistics only; batch statistics (train mode) make the two forwards identical
+    for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss'):
+        assert out2[k].item() == out[k].item(), k
+    # a batch that has no ground truth at all, batch size 1
+    empty = labels.create_label([], hw, ncls)
+    tgt1 = tuple([torch.from_numpy(empty[i][None]) for i in range(3)] + [torch.zeros(1, 1, 4) for _ in range(3)])
+    o1 = net(x[:1].to(DEV), tuple(t.to(DEV) for t in tgt1))
+    o1['loss'].mean().backward()
+    w1 = ref(x[:1], tgt1)
+    assert o1['giou_loss'].item() == 0.0 and o1['class_loss'].item() == 0.0
+    assert abs(o1['loss'].item() - w1['loss'].item()) <= 1e-3 * abs(w1['loss'].item()) + 1e-5
+    assert torch.isfinite(net.flat_buffers()[1]).all()
+
+
 def test_no_cpu_fallback():
     from pqdet_amd import abi
     net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
