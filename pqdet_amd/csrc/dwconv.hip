@@ -168,6 +168,136 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwP p) {
     if (part) block_reduce_store_stats<256>(s1, s2, part, p.sink.ldp, c0, p.C, lds, bx);
 }
 
+// ---- dgrad, stride 2, even input sizes: one thread owns a 2x2 block of input pixels, which is fed by exactly the 2x2
+// block of outputs (a..a+1, b..b+1): 4 gradient operands are loaded for 4 results (the per-pixel kernel above loads 4 each).
+//   dx[2a  ][2b  ] = d00*w11
+//   dx[2a  ][2b+1] = d01*w10 + d00*w12
+//   dx[2a+1][2b  ] = d10*w01 + d00*w21
+//   dx[2a+1][2b+1] = d11*w00 + d10*w02 + d01*w20 + d00*w22          (dAB = dy'[a+A][b+B], zero outside the plane)
+__global__ __launch_bounds__(256) void dw_dgrad_s2_quad_kernel(DwP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx;
+    const int c0 = c4 * 4;
+    const bool cok = c4 < p.C4;
+    const int QH = p.IH >> 1, QW = p.IW >> 1;
+    const int items = p.B * QH * QW;
+    float4 wk[9];
+    load_w9(p.w, c0, p.C, wk, false);
+    const GsrcCoef4 gk = gsrc_coef4(p.dy, c0, p.C);
+    const SinkCoef4 sk = sink_coef4(p.sink, c0, p.C);
+    float4 s1 = f4zero(), s2 = f4zero();
+    for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
+        const int qb = (int)(it % QW);
+        const int t2 = it / QW;
+        const int qa = (int)(t2 % QH);
+        const int b = (int)(t2 / QH);
+        const bool y1ok = qa + 1 < p.OH, x1ok = qb + 1 < p.OW;
+        const int oy1 = min(qa + 1, p.OH - 1), ox1 = min(qb + 1, p.OW - 1);
+        const size_t r00 = ((size_t)b * p.OH + qa) * p.OW + qb, r01 = ((size_t)b * p.OH + qa) * p.OW + ox1;
+        const size_t r10 = ((size_t)b * p.OH + oy1) * p.OW + qb, r11 = ((size_t)b * p.OH + oy1) * p.OW + ox1;
+        float4 g00 = ldg4(p.dy.g + r00 * p.dy.ldg + c0), g01 = ldg4(p.dy.g + r01 * p.dy.ldg + c0);
+        float4 g10 = ldg4(p.dy.g + r10 * p.dy.ldg + c0), g11 = ldg4(p.dy.g + r11 * p.dy.ldg + c0);
+        float4 y00 = f4zero(), y01 = f4zero(), y10 = f4zero(), y11 = f4zero();
+        if (gk.two) {
+            y00 = ldg4(p.dy.y + r00 * p.dy.ldy + c0); y01 = ldg4(p.dy.y + r01 * p.dy.ldy + c0);
+            y10 = ldg4(p.dy.y + r10 * p.dy.ldy + c0); y11 = ldg4(p.dy.y + r11 * p.dy.ldy + c0);
+        }
+        const float4 d00 = gsrc_apply4(g00, y00, gk);
+        const float4 d01 = x1ok ? gsrc_apply4(g01, y01, gk) : f4zero();
+        const float4 d10 = y1ok ? gsrc_apply4(g10, y10, gk) : f4zero();
+        const float4 d11 = (x1ok && y1ok) ? gsrc_apply4(g11, y11, gk) : f4zero();
+        const float4 e00 = f4fma(d00, wk[4], f4zero());
+        const float4 e01 = f4fma(d01, wk[3], f4fma(d00, wk[5], f4zero()));
+        const float4 e10 = f4fma(d10, wk[1], f4fma(d00, wk[7], f4zero()));
+        const float4 e11 = f4fma(d11, wk[0], f4fma(d10, wk[2], f4fma(d01, wk[6], f4fma(d00, wk[8], f4zero()))));
+        const size_t i00 = ((size_t)b * p.IH + 2 * qa) * p.IW + 2 * qb;
+        sink_emit4(p.sink, sk, i00, c0, e00, s1, s2);
+        sink_emit4(p.sink, sk, i00 + 1, c0, e01, s1, s2);
+        sink_emit4(p.sink, sk, i00 + p.IW, c0, e10, s1, s2);
+        sink_emit4(p.sink, sk, i00 + p.IW + 1, c0, e11, s1, s2);
+    }
+    float* part = (p.sink.finalize && p.sink.mean) ? p.sink.partial : nullptr;
+    if (part) block_reduce_store_stats<256>(s1, s2, part, p.sink.ldp, c0, p.C, lds, bx);
+}
+
+// ---- dgrad, stride 1, column walk: a thread owns TW columns x RW rows of the (same-size) plane and walks down the rows
+// with a rolling window of three TRANSFORMED gradient rows in registers, so every gradient operand is loaded once per
+// thread instead of three times (vertical reuse no longer goes through L1/L2).
+template <int TW, int RW>
+__global__ __launch_bounds__(256) void dw_dgrad_s1_walk_kernel(DwP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx;
+    const int c0 = c4 * 4;
+    const bool cok = c4 < p.C4;
+    const int H = p.OH, W = p.OW;                       // dy plane == dx plane (stride 1, pad 1)
+    const int WG = (W + TW - 1) / TW, HG = (H + RW - 1) / RW;
+    const int items = p.B * HG * WG;
+    constexpr int NCOL = TW + 2;
+    float4 wk[9];
+    load_w9(p.w, c0, p.C, wk, true);                    // flipped taps: dx = corr(dy', flip(w))
+    const GsrcCoef4 gk = gsrc_coef4(p.dy, c0, p.C);
+    const SinkCoef4 sk = sink_coef4(p.sink, c0, p.C);
+    float4 s1 = f4zero(), s2 = f4zero();
+    for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
+        const int xg = (int)(it % WG);
+        const int t2 = it / WG;
+        const int yg = (int)(t2 % HG);
+        const int b = (int)(t2 / HG);
+        const int x0 = xg * TW, y0 = yg * RW;
+        float4 win[3][NCOL];                            // rows (y-1, y, y+1) of dy', rotated by renaming
+        auto load_row = [&](int y, float4 (&dst)[NCOL]) {
+            const bool yok = y >= 0 && y < H;
+            const int yc = min(max(y, 0), H - 1);
+            const size_t rowbase = ((size_t)b * H + yc) * W;
+            float4 ra[NCOL], rb[NCOL];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int xc = min(max(x0 - 1 + j, 0), W - 1);
+                ra[j] = ldg4(p.dy.g + (rowbase + xc) * p.dy.ldg + c0);
+                rb[j] = gk.two ? ldg4(p.dy.y + (rowbase + xc) * p.dy.ldy + c0) : f4zero();
+            }
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int x = x0 - 1 + j;
+                const float4 v = gsrc_apply4(ra[j], rb[j], gk);
+                dst[j] = (yok && x >= 0 && x < W) ? v : f4zero();
+            }
+        };
+        load_row(y0 - 1, win[0]);
+        load_row(y0, win[1]);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int y = y0 + r;
+            load_row(y + 1, win[(r + 2) % 3]);          // r is a compile-time constant: plain register renaming
+            if (y < H) {
+                float4 acc[TW];
+#pragma unroll
+                for (int t = 0; t < TW; ++t) acc[t] = f4zero();
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float4 (&row)[NCOL] = win[(r + ky) % 3];
+#pragma unroll
+                    for (int t = 0; t < TW; ++t)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc[t] = f4fma(row[t + kx], wk[ky * 3 + kx], acc[t]);
+                }
+                const size_t orow = ((size_t)b * H + y) * W + x0;
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+                    if (x0 + t < W) sink_emit4(p.sink, sk, orow + t, c0, acc[t], s1, s2);
+            }
+        }
+    }
+    float* part = (p.sink.finalize && p.sink.mean) ? p.sink.partial : nullptr;
+    if (part) block_reduce_store_stats<256>(s1, s2, part, p.sink.ldp, c0, p.C, lds, bx);
+}
+
 // ---- wgrad: dw[c][ky][kx] = sum dy'[b,oy,ox,c] * x'[b,oy*S+ky-1,ox*S+kx-1,c]
 template <int S, int TW>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwP p) {
@@ -452,11 +582,17 @@ extern "C" int pq_dw3x3_dgrad(const pq_dw3x3_dgrad_args* a, void* stream) {
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     size_t sh = (size_t)g.cx * g.py * 8 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    static const char* mode = getenv("PQ_DW_DGRAD");                  // "old": the per-pixel / per-row kernels (A/B timing)
+    const bool legacy = mode && mode[0] == 'o';
     if (a->stride == 1) {
-        // stride 1: dgrad is a correlation with the flipped taps on the same grid -> reuse the sliding-window kernel
         DwP q = p;
         q.IH = a->OH; q.IW = a->OW; q.OH = a->IH; q.OW = a->IW;   // "input" = dy plane, "output" = dx plane
-        hipLaunchKernelGGL((dw_fwd_kernel<1, 4, true>), grid, blk, sh, st, q);
+        // the column-walk kernel only pays on the largest planes (256x256: 0.167 -> 0.144 ms); below that the per-row kernel
+        // has more parallelism and is as fast
+        if (!legacy && (long)a->IH * a->IW >= 256L * 256L) hipLaunchKernelGGL((dw_dgrad_s1_walk_kernel<4, 4>), grid, blk, sh, st, q);
+        else hipLaunchKernelGGL((dw_fwd_kernel<1, 4, true>), grid, blk, sh, st, q);
+    } else if (!legacy && (a->IH & 1) == 0 && (a->IW & 1) == 0) {
+        hipLaunchKernelGGL(dw_dgrad_s2_quad_kernel, grid, blk, sh, st, p);
     } else {
         hipLaunchKernelGGL((dw_dgrad_kernel<2>), grid, blk, sh, st, p);
     }
