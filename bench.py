@@ -114,11 +114,12 @@ def profile_kernels(plan, x, tgt, side=None, passes=3):
     return acc
 
 
-# kernel class -> regex over the kernel names of profiles/r1_pmc_summary.csv (gemm_nt template args: BM,BN,WM,WN,AMODE,BKN,EMODE,..)
+# kernel class -> (regex of the class's main kernel, regex of helper kernels launched by the same op) over the kernel
+# names of profiles/r1_pmc_summary.csv (gemm_nt template args: BM,BN,WM,WN,AMODE,BKN,EMODE,..)
 PMC_PATTERN = {
-    'conv1x1_dgrad (gemm_nt, fp32 MFMA)': r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, 2, ',
-    'conv1x1_fwd (gemm_nt, fp32 MFMA)': r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], ',
-    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': r'gemm_tn_kernel<',
+    'conv1x1_dgrad (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, 2, ', None),
+    'conv1x1_fwd (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], ', None),
+    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<', r'slab_reduce_kernel'),
 }
 
 
@@ -128,14 +129,15 @@ def measured_traffic(kernel_class, model_name):
     import csv
     import re
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc_summary.csv')
-    pat = PMC_PATTERN.get(kernel_class)
-    if model_name != 'mobilenetv2-fpn' or pat is None or not os.path.exists(path):
+    main, extra = PMC_PATTERN.get(kernel_class, (None, None))
+    if model_name != 'mobilenetv2-fpn' or main is None or not os.path.exists(path):
         return None
     calls = tot = 0.0
     for r in csv.DictReader(open(path)):
-        if re.search(pat, r['kernel']):
+        is_main = re.search(main, r['kernel']) is not None
+        if is_main or (extra and re.search(extra, r['kernel'])):
             n = float(r['calls'])
-            calls += n
+            calls += n if is_main else 0.0
             tot += n * (float(r['hbm_read_mb_per_launch(2x)']) + float(r['hbm_write_mb_per_launch'])) * 1e6
     return round(tot / calls) if calls else None
 
