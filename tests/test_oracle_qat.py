@@ -1,0 +1,113 @@
+"""The oracle's restatement of PyTorch's observer + fake-quantise op against the library op itself (part of the installed
+torch, so this runs everywhere), and the QAT oracle against the G9 fixtures recorded from the reference."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qat
+
+
+@pytest.mark.parametrize('symmetric,qmin,qmax', [(False, 0, 255), (True, -128, 127)])
+def test_fake_quant_restatement_matches_library_op(symmetric, qmin, qmax):
+    g = torch.Generator().manual_seed(5)
+    cases = [torch.randn(64, 33, generator=g) * s + o for s, o in ((1, 0), (0.01, 0), (5, 3), (1e-4, 0), (2, -7), (0, 0))]
+    cases += [torch.rand(200, generator=g), -torch.rand(200, generator=g), torch.zeros(17)]
+    for x0 in cases:
+        mine = qat.FakeQuant(qmin, qmax, symmetric)
+        mn, mx = torch.tensor(float('inf')), torch.tensor(float('-inf'))
+        sc, zp = torch.tensor([1.0]), torch.tensor([0], dtype=torch.int32)
+        on = torch.tensor([1], dtype=torch.int64)
+        for step in range(3):                      # several steps: exercises the moving average
+            x = (x0 * (1 + 0.5 * step)).clone().requires_grad_(True)
+            x2 = x.detach().clone().requires_grad_(True)
+            want = torch.fused_moving_avg_obs_fake_quant(x, on, on, mn, mx, sc, zp, 0.01, qmin, qmax, -1, False, symmetric)
+            got = mine(x2)
+            assert mine.min_val.item() == mn.item() and mine.max_val.item() == mx.item()
+            assert mine.scale.item() == sc.item() and mine.zero_point.item() == zp.item(), (mine.scale, sc, mine.zero_point, zp)
+            assert torch.equal(got, want)
+            w = torch.randn(x.shape, generator=g)
+            (want * w).sum().backward()
+            (got * w).sum().backward()
+            assert torch.equal(x.grad, x2.grad)
+
+
+def _g9():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    return np.load(os.path.join(here, 'golden_qat.npz')), json.load(open(os.path.join(here, 'g9_names.json')))
+
+
+def qat_batch(step, B=2, S=64, ncls=20):
+    from oracle import postprocess as opost
+    from seedfill import seeded_boxes, seeded_images
+    hw = np.array([[S // s, S // s] for s in (8, 16, 32)])
+    x = seeded_images(B, S, S, step)
+    per = [opost.create_label(bb, hw, ncls) for bb in seeded_boxes(B, S, ncls, 1 + step)]
+    tgt = tuple([torch.from_numpy(np.stack([p[i] for p in per])) for i in range(3)]
+                + [torch.from_numpy(opost.pad_boxes([p[3 + i] for p in per])) for i in range(3)])
+    return x, tgt
+
+
+def qat_observers(net):
+    """(min, max, scale, zero_point) rows in the reference's module order: per layer weight observer then activation
+    observer, the input stub last (named_modules order of the reference model: module_list.*, then qstub)."""
+    rows = []
+    for i, m in enumerate(net.module_list):
+        for fq in (net.w_fq[i], net.a_fq[i]):
+            if isinstance(fq, qat.FakeQuant):
+                rows.append([fq.min_val.item(), fq.max_val.item(), fq.scale.item(), float(fq.zero_point.item())])
+    fq = net.input_fq
+    rows.insert(0, [fq.min_val.item(), fq.max_val.item(), fq.scale.item(), float(fq.zero_point.item())])
+    return np.array(rows)
+
+
+def test_qat_oracle_matches_reference_g9():
+    from pqdet_amd.model import zoo
+    from seedfill import seeded_fill, seeded_images
+    g, names = _g9()
+    net = qat.OracleQATNet(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
+    seeded_fill(net.float_net, 0)
+    net.train()
+    losses = []
+    for step in range(2):
+        x, tgt = qat_batch(step)
+        net.zero_grad()
+        out = net(x, tgt)
+        out['loss'].mean().backward()
+        losses.append([out[k].item() for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss')]
+                      + [v.item() for v in out['loss_per_branch']])
+    np.testing.assert_allclose(np.array(losses), g['g9_loss'], rtol=2e-4)
+    # parameters: the reference's fused modules keep BatchNorm inside `conv` (module_list.i.conv.bn.weight)
+    mine = {k.replace('float_net.', ''): p for k, p in net.named_parameters()}
+    gn = []
+    for k in names['params']:
+        gn.append(mine[k.replace('.conv.bn.', '.bn.')].grad.double().norm().item())
+    gn = np.array(gn)
+    np.testing.assert_allclose(gn, g['g9_gradnorm'], rtol=0.05, atol=1e-5 * gn.max())
+    for key, name in (('g9_grad_last_b', 'module_list.101.conv.bias'), ('g9_grad_last_w', 'module_list.101.conv.weight')):
+        want = g[key]
+        got = mine[name].grad.numpy()
+        assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max(), key
+    obs = qat_observers(net)
+    assert len(obs) == len(names['observers'])
+    # observers are listed by the reference in named_modules order: check the two orders agree on the first few names
+    assert names['observers'][0].startswith('qstub') or names['observers'][-1].startswith('qstub')
+    if names['observers'][-1].startswith('qstub'):
+        obs = np.concatenate([obs[1:], obs[:1]])
+    np.testing.assert_allclose(obs[:, :2], g['g9_observers'][:, :2], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(obs[:, 2], g['g9_observers'][:, 2], rtol=1e-3)
+    assert np.abs(obs[:, 3] - g['g9_observers'][:, 3]).max() <= 1
+    sd = net.float_net.state_dict()
+    rm = [k for k in sd if k.endswith('running_mean')]
+    np.testing.assert_allclose(sd[rm[0]].numpy(), g['g9_rmean_first'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sd[rm[-1].replace('running_mean', 'running_var')].numpy(), g['g9_rvar_last'], rtol=1e-3, atol=1e-5)
+    net.eval()
+    for m in net.modules():
+        if isinstance(m, qat.FakeQuant):
+            m.observer_enabled = True          # the reference leaves observers on in eval() (only the trainer disables them)
+    with torch.no_grad():
+        ev = net(seeded_images(2, 64, 64, 7))
+    np.testing.assert_allclose(ev.numpy(), g['g9_eval'], rtol=2e-3, atol=2e-3)
