@@ -47,6 +47,8 @@ KERNEL_CLASS = {
     abi.OP_COPY_FWD: ('copy_fwd (shortcut/route/upsample)', 'hbm'), abi.OP_ROUTE_BWD: ('route_bwd', 'hbm'),
     abi.OP_LOSS_FWD: ('yolo_loss_fwd', 'hbm'), abi.OP_LOSS_BWD: ('yolo_loss_bwd', 'hbm'), abi.OP_FILL: ('fill', 'hbm'),
     abi.OP_TRANSPOSE: ('weight transposes (one launch)', 'hbm'),
+    abi.OP_QAT_WPREP: ('qat weight scale+observe+quantise (one launch)', 'hbm'),
+    abi.OP_QACT_FWD: ('qat activation observe+quantise', 'hbm'), abi.OP_QACT_BWD: ('qat activation backward', 'hbm'),
 }
 
 
@@ -194,6 +196,7 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--model', default='mobilenetv2-fpn', choices=zoo.available(),
                     help='BASELINE.json configs: mobilenetv2-fpn (the metric), regnetx-600m-fpn / -pan (configs 3, 4)')
+    ap.add_argument('--qat', action='store_true', help='BASELINE config 5: quantisation-aware training step (use --batch 12)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -210,8 +213,11 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(0)
-    model = DetectionModel(io.StringIO(zoo.cfg_text(args.model))).to(dev)
+    model = DetectionModel(io.StringIO(zoo.cfg_text(args.model)), quant=args.qat).to(dev)
     model.train()
+    if args.qat:
+        from pqdet_amd import tools
+        tools.prepare_qat(tools.fuse_model(model), backend='qnnpack')
     model.nan_check = 'deferred'
     runner = model
     if world > 1:
@@ -274,7 +280,8 @@ def main():
                     'device_ms_per_step_all_kernels': round(total_ms, 3),
                     'breakdown_ms': {k: round(v['ms'], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}}
         line = {
-            'metric': 'images/sec train step, %s %dx%d bs%d/GPU' % (args.model, S, S, B), 'value': round(value, 2),
+            'metric': 'images/sec %strain step, %s %dx%d bs%d/GPU' % ('QAT ' if args.qat else '', args.model, S, S, B),
+            'value': round(value, 2),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
@@ -283,7 +290,7 @@ def main():
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.qat:
             line['cpu_baseline'] = cpu_baseline(B, S, model=args.model)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -242,6 +242,7 @@ typedef struct pq_bn_fwd_finalize_args {
     float count, eps, momentum;
     double* scratch;        /* >= pq_bn_finalize_scratch_bytes(C), or NULL: one block per 64 channels walks all rows */
     uint32_t* tickets;      /* pq_bn_finalize_tickets(C) counters, zero before the first use (self re-arming), or NULL */
+    const float* sf;        /* QAT (fused conv-BN): the conv ran with weights scaled by sf[c]; BatchNorm acts on out/sf.  NULL otherwise */
 } pq_bn_fwd_finalize_args;
 int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream);
 
@@ -393,6 +394,52 @@ typedef struct pq_nms_args {
 int pq_nms(const pq_nms_args* a, void* stream);
 int64_t pq_nms_scratch_bytes(int32_t N, int32_t C);
 
+/* ------------------------------------------------------------------ quantisation-aware training (BASELINE config 5)
+ * replaces what the reference gets from torch.ao's QAT modules (tools.py:256-290, model/parser.py:143-183,
+ * model/interpreter.py:27-53): FusedMovingAvgObsFakeQuantize observers + fake-quantise (activations quint8 affine,
+ * weights qint8 symmetric, per tensor) and the fused conv-BN weight scaling.  state = {min, max, scale, zero_point}. */
+typedef struct pq_qat_weight_item {
+    const float* w;             /* [O][K] float weights */
+    const float* gamma;         /* BatchNorm weight or NULL (heads) */
+    const float* running_var;
+    float* wq;                  /* out: fake-quantised (w * sf), what the conv kernels read */
+    float* sf;                  /* out [O]: gamma / sqrt(running_var + eps) (1 without BatchNorm) */
+    float* state;               /* observer state of this weight */
+    const float* dwq;           /* backward: gradient w.r.t. wq (from the wgrad kernels) */
+    float* dw;                  /* backward out: gradient w.r.t. w */
+    float* dgamma;              /* backward: += contribution through sf (after the BatchNorm's own dgamma) */
+    float eps;
+    int32_t O, K;
+} pq_qat_weight_item;
+typedef struct pq_qat_weight_args {
+    const pq_qat_weight_item* items;   /* device table, one entry per conv layer */
+    int32_t n_items, observe, quantise;
+    float avg_const;
+} pq_qat_weight_args;
+int pq_qat_weight_prep(const pq_qat_weight_args* a, void* stream);   /* forward: all layers, one launch */
+int pq_qat_weight_grad(const pq_qat_weight_args* a, void* stream);   /* backward: dw = dwq*mask*sf, dgamma += ..., one launch */
+
+/* out[r][c] = fq(act(scale[c]*x[r][c] + shift[c])) with the observer of `state` updated first (observe != 0) */
+typedef struct pq_qact_args {
+    pq_src in;
+    float* out;              /* [rows][ldo] (flat: [rows]) */
+    float* state;
+    float* partial;          /* >= 2 * pq_qact_blocks(elements) floats */
+    int64_t rows;
+    int32_t C, ldo, flat, observe, quantise;
+    float avg_const;
+} pq_qact_args;
+int pq_qact_fwd(const pq_qact_args* a, void* stream);
+int32_t pq_qact_blocks(int64_t elems);
+/* g = gq * [value inside the quantisation range] * act'(u), written through dx (which also yields the BN-backward sums) */
+typedef struct pq_qact_bwd_args {
+    const float* gq;         /* gradient w.r.t. the quantised tensor, pitch ldgq */
+    pq_gsink dx;             /* g, y, scale, shift, mean, invstd, partial ([pq_ew_blocks(rows, C)][2][ldp]); act */
+    const float* state;
+    int32_t rows, C, ldgq, quantise;
+} pq_qact_bwd_args;
+int pq_qact_bwd(const pq_qact_bwd_args* a, void* stream);
+
 /* ------------------------------------------------------------------ batched 2-D transposes (weights for the dgrad GEMMs)
  * dst[c][r] = src[r][c] for every item, ONE launch for the whole table (the table itself lives in device memory).
  * tile0 = number of 32x32 tiles of all previous items, tiles_c = ceil(cols/32). */
@@ -413,7 +460,8 @@ enum {
     PQ_OP_CONV1X1_FWD = 1, PQ_OP_CONV1X1_DGRAD, PQ_OP_CONV1X1_WGRAD, PQ_OP_DW_FWD, PQ_OP_DW_DGRAD, PQ_OP_DW_WGRAD,
     PQ_OP_STEM_FWD, PQ_OP_STEM_WGRAD, PQ_OP_BN_FWD_FIN, PQ_OP_BN_BWD_FIN, PQ_OP_COPY_FWD, PQ_OP_ROUTE_BWD,
     PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD,
-    PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD, PQ_OP_TRANSPOSE
+    PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD, PQ_OP_TRANSPOSE,
+    PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -428,6 +476,7 @@ typedef struct pq_op {
         pq_bn_fwd_finalize_args bnf; pq_bn_bwd_finalize_args bnb;
         pq_copy_args cp; pq_route_bwd_args rb;
         pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill; pq_transpose_args tr;
+        pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);
@@ -446,7 +495,8 @@ int pq_last_failed_op(void);
 const char* pq_last_error(void);
 const char* pq_version(void);
 /* sizeof() of the argument struct of op `code` (0: pq_op, 100: pq_recover_args, 101: pq_nms_args,
- * 102: pq_decode_bwd_args, 103: pq_transpose_item, 104: pq_create_label_args) -- lets a foreign-language binding verify its struct layout at load time */
+ * 102: pq_decode_bwd_args, 103: pq_transpose_item, 104: pq_create_label_args,
+ * 105: pq_qat_weight_item) -- lets a foreign-language binding verify its struct layout at load time */
 int32_t pq_abi_sizeof(int32_t code);
 
 #ifdef __cplusplus

@@ -104,7 +104,7 @@ class BnFwdFin(C.Structure):
     _fields_ = [('partial', c_fp), ('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp),
                 ('num_batches_tracked', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp), ('shift', c_fp),
                 ('nblk', i32), ('ldp', i32), ('C', i32), ('train', i32), ('count', f32), ('eps', f32), ('momentum', f32),
-                ('scratch', c_fp), ('tickets', c_fp)]
+                ('scratch', c_fp), ('tickets', c_fp), ('sf', c_fp)]
 
 
 class BnBwdFin(C.Structure):
@@ -180,12 +180,31 @@ class Transpose(C.Structure):
     _fields_ = [('items', c_fp), ('n_items', i32), ('total_tiles', i32)]
 
 
+class QatWeightItem(C.Structure):
+    _fields_ = [('w', c_fp), ('gamma', c_fp), ('running_var', c_fp), ('wq', c_fp), ('sf', c_fp), ('state', c_fp),
+                ('dwq', c_fp), ('dw', c_fp), ('dgamma', c_fp), ('eps', f32), ('O', i32), ('K', i32)]
+
+
+class QatWeight(C.Structure):
+    _fields_ = [('items', c_fp), ('n_items', i32), ('observe', i32), ('quantise', i32), ('avg_const', f32)]
+
+
+class Qact(C.Structure):
+    _fields_ = [('inp', Src), ('out', c_fp), ('state', c_fp), ('partial', c_fp), ('rows', i64),
+                ('C', i32), ('ldo', i32), ('flat', i32), ('observe', i32), ('quantise', i32), ('avg_const', f32)]
+
+
+class QactBwd(C.Structure):
+    _fields_ = [('gq', c_fp), ('dx', GSink), ('state', c_fp), ('rows', i32), ('C', i32), ('ldgq', i32), ('quantise', i32)]
+
+
 class _OpU(C.Union):
     _fields_ = [('c1f', Conv1x1Fwd), ('c1d', Conv1x1Dgrad), ('c1w', Conv1x1Wgrad),
                 ('dwf', DwFwd), ('dwd', DwDgrad), ('dww', DwWgrad), ('dwb', DwBwd), ('stf', StemFwd), ('stw', StemWgrad),
                 ('bnf', BnFwdFin), ('bnb', BnBwdFin), ('cp', Copy), ('rb', RouteBwd),
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
-                ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose)]
+                ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose),
+                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd)]
 
 
 OPF_SIDE = 1
@@ -197,14 +216,15 @@ class Op(C.Structure):
 
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
- OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE) = range(1, 23)
+ OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE, OP_QAT_WPREP, OP_QAT_WGRAD, OP_QACT_FWD,
+ OP_QACT_BWD) = range(1, 27)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
     OP_DW_WGRAD: 'dww', OP_STEM_FWD: 'stf', OP_STEM_WGRAD: 'stw', OP_BN_FWD_FIN: 'bnf', OP_BN_BWD_FIN: 'bnb',
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
-    OP_TRANSPOSE: 'tr',
+    OP_TRANSPOSE: 'tr', OP_QAT_WPREP: 'qw', OP_QAT_WGRAD: 'qw', OP_QACT_FWD: 'qa', OP_QACT_BWD: 'qb',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -245,6 +265,11 @@ SIGNATURES = {
     'pq_yolo_loss_bwd': (C.c_int, [C.POINTER(YoloLoss), C.c_void_p]),
     'pq_yolo_loss_blocks': (i32, [i32, i32, i32]),
     'pq_iou_pairs': (C.c_int, [c_fp, c_fp, c_fp, i32, i32, C.c_void_p]),
+    'pq_qat_weight_prep': (C.c_int, [C.POINTER(QatWeight), C.c_void_p]),
+    'pq_qat_weight_grad': (C.c_int, [C.POINTER(QatWeight), C.c_void_p]),
+    'pq_qact_fwd': (C.c_int, [C.POINTER(Qact), C.c_void_p]),
+    'pq_qact_blocks': (i32, [i64]),
+    'pq_qact_bwd': (C.c_int, [C.POINTER(QactBwd), C.c_void_p]),
     'pq_transpose_batch': (C.c_int, [C.POINTER(Transpose), C.c_void_p]),
     'pq_adam_step': (C.c_int, [C.POINTER(Adam), C.c_void_p]),
     'pq_sign_l1': (C.c_int, [c_fp, c_fp, i64, f32, C.c_void_p]),

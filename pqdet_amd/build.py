@@ -19,6 +19,7 @@ SOURCES = {            # file -> extra flags
     'dwconv.hip': [],
     'dwtile.hip': [],
     'gconv.hip': [],
+    'qat.hip': ['-ffp-contract=off'],
     'ew.hip': [],
     'yolo.hip': [],
     'post.hip': ['-ffp-contract=off'],   # NMS comparisons must not see FMA contraction (bit-exact selection)

@@ -41,6 +41,10 @@ static int run_one(const pq_op& op, void* stream) {
         case PQ_OP_GCONV_DGRAD: return pq_gconv3x3_dgrad(&op.u.gcd, stream);
         case PQ_OP_GCONV_WGRAD: return pq_gconv3x3_wgrad(&op.u.gcw, stream);
         case PQ_OP_TRANSPOSE: return pq_transpose_batch(&op.u.tr, stream);
+        case PQ_OP_QAT_WPREP: return pq_qat_weight_prep(&op.u.qw, stream);
+        case PQ_OP_QAT_WGRAD: return pq_qat_weight_grad(&op.u.qw, stream);
+        case PQ_OP_QACT_FWD: return pq_qact_fwd(&op.u.qa, stream);
+        case PQ_OP_QACT_BWD: return pq_qact_bwd(&op.u.qb, stream);
         default:
             pq_set_error("pq_run_ops: unknown op code %d", op.code);
             return PQ_EINVAL;
@@ -193,6 +197,10 @@ extern "C" int32_t pq_abi_sizeof(int32_t code) {
         case PQ_OP_GCONV_DGRAD: return (int32_t)sizeof(pq_gconv3x3_dgrad_args);
         case PQ_OP_GCONV_WGRAD: return (int32_t)sizeof(pq_gconv3x3_wgrad_args);
         case PQ_OP_TRANSPOSE: return (int32_t)sizeof(pq_transpose_args);
+        case PQ_OP_QAT_WPREP: case PQ_OP_QAT_WGRAD: return (int32_t)sizeof(pq_qat_weight_args);
+        case PQ_OP_QACT_FWD: return (int32_t)sizeof(pq_qact_args);
+        case PQ_OP_QACT_BWD: return (int32_t)sizeof(pq_qact_bwd_args);
+        case 105: return (int32_t)sizeof(pq_qat_weight_item);
         case 103: return (int32_t)sizeof(pq_transpose_item);
         case 104: return (int32_t)sizeof(pq_create_label_args);
         case 100: return (int32_t)sizeof(pq_recover_args);

@@ -102,7 +102,10 @@ __global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_fwd_finalize_kernel(pq_bn_
         const double mean = t1 / n;
         double var = t2 / n - mean * mean;
         if (var < 0.0) var = 0.0;
-        const float inv = (float)(1.0 / sqrt(var + (double)a.eps));
+        // QAT: the statistics are those of out = conv_orig * sf.  BatchNorm on conv_orig = out / sf equals BatchNorm on `out`
+        // with eps scaled by sf^2 (and the sign of sf), so everything downstream keeps working on the raw tensor.
+        const double sf = a.sf ? (double)a.sf[c] : 1.0;
+        const float inv = (float)((sf < 0.0 ? -1.0 : 1.0) / sqrt(var + (double)a.eps * sf * sf));
         const float g = a.gamma[c], b = a.beta[c];
         a.mean[c] = (float)mean;
         a.invstd[c] = inv;
@@ -110,18 +113,18 @@ __global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_fwd_finalize_kernel(pq_bn_
         a.scale[c] = sc;
         a.shift[c] = b - (float)mean * sc;
         if (a.running_mean) {
-            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+            const double unb = (n > 1.0 ? var * n / (n - 1.0) : var) / (sf * sf);
+            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)(mean / sf);
             a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
         }
         if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
     } else if (threadIdx.x < BNF_CH && blockIdx.y == 0 && c < a.C) {
         const float inv = 1.f / sqrtf(a.running_var[c] + a.eps);
-        const float sc = a.gamma[c] * inv;
-        a.mean[c] = a.running_mean[c];
-        a.invstd[c] = inv;
-        a.scale[c] = sc;
-        a.shift[c] = a.beta[c] - a.running_mean[c] * sc;
+        const float sf = a.sf ? a.sf[c] : 1.f;              // QAT: the raw tensor is conv_orig * sf
+        a.mean[c] = a.running_mean[c] * sf;
+        a.invstd[c] = inv / sf;
+        a.scale[c] = a.gamma[c] * inv / sf;
+        a.shift[c] = a.beta[c] - a.running_mean[c] * (a.gamma[c] * inv);
     }
 }
 

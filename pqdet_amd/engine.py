@@ -143,6 +143,13 @@ class Plan:
         self.loss_ops_f: List[Tuple[int, int]] = []          # (fwd op index, head slot)
         self.loss_ops_b: List[Tuple[int, int]] = []
         self.segments: List[Tuple[int, int, int]] = []       # backward: (op_end, flat_lo, flat_hi) gradient-ready marks
+        # quantisation-aware training (tools.prepare_qat): observers / fake-quantisation as extra ops around the same kernels
+        self.qat = bool(getattr(model, '_qat', False))
+        self.q_observe = int(bool(getattr(model, 'qat_observer_enabled', True)))
+        self.q_quant = int(bool(getattr(model, 'qat_fake_quant_enabled', True)))
+        self.post_bwd: List[abi.Op] = []
+        self._inner: Dict[int, TensorRef] = {}                # QAT: layer index -> un-quantised producer tensor
+        self._wq: Dict[int, tuple] = {}                       # QAT: layer index -> (wq, sf, dwq) buffers
         self._build()
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -165,6 +172,25 @@ class Plan:
             self.keep += [sc, tk]
             self._bnfin = cur = (sc, tk)
         return cur[0].data_ptr(), cur[1].data_ptr()
+
+    def _qstate(self, key) -> int:
+        """Device address of the observer state {min, max, scale, zero_point} of ('in',) / ('w', i) / ('a', i)."""
+        m = self.model
+        return m._qat_state.data_ptr() + 16 * m._qat_index[key]
+
+    def _qact_fwd(self, src: abi.Src, out_t, rows, C_, ldo, key, flat=0) -> int:
+        elems = rows if flat else rows * C_
+        part = self._new(2 * lib().pq_qact_blocks(elems) + 8)
+        a = abi.Qact(src, ptr(out_t), self._qstate(key), ptr(part), rows, C_, ldo, flat, self.q_observe, self.q_quant, 0.01)
+        return self._op(self.fwd, abi.OP_QACT_FWD, a)
+
+    def _qact_bwd(self, qout: 'TensorRef', inner: 'TensorRef', key):
+        """Gradient of the quantised tensor -> gradient of its producer (straight-through mask x act', BN-backward sums)."""
+        l = lib()
+        Cq = inner.C if inner.C % 4 == 0 else inner.ld          # heads: 75 channels in a pitch of 76 (pad column is zero)
+        sk = self._sink(inner, l.pq_ew_blocks(inner.rows, Cq))
+        a = abi.QactBwd(ptr(qout.grad), sk, self._qstate(key), inner.rows, Cq, qout.ld, self.q_quant)
+        self._op(self.bwd, abi.OP_QACT_BWD, a)
 
     def _op(self, lst, code, args) -> int:
         op = abi.Op()
@@ -281,10 +307,18 @@ class Plan:
                 raw = self._new(rows, ld) if ld == Cout else self._new(rows, ld, fill=0.0)
                 out = TensorRef(raw, B, OH, OW, Cout, ld, bn, act)
                 want_stats = bn is not None and self.bn_train
+                if self.qat:
+                    wq = self._new(conv.weight.numel())
+                    sfv = self._new(_round_up(Cout, ALIGN), fill=1.0)
+                    dwq = self._new(conv.weight.numel()) if train_graph else None
+                    self._wq[i] = (wq, sfv, dwq)
                 if i == 0:
                     if not (k == 3 and groups == 1 and Cin == 3):
                         raise NotImplementedError('first layer must be a dense 3x3 conv on 3 channels')
                     nblk = l.pq_ew_blocks(rows, Cout)
+                    if self.qat:
+                        self.qimg = self._new(B * 3 * self.IH * self.IW)
+                        self._deferred.append(('qimg',))
                     self._deferred.append(('stem_fwd', i, out, nblk))
                 else:
                     src = T[resolve(i - 1, i)]
@@ -307,12 +341,25 @@ class Plan:
                     if want_stats:
                         bn.fwd_partial = self._new(nblk * 2 * bn.ldp)
                     self._deferred.append(('bn_fwd', i, out))
+                if self.qat:
+                    out.n_consumers = 1
+                    self._inner[i] = out
+                    qbuf = self._new(rows, ld) if ld == Cout else self._new(rows, ld, fill=0.0)
+                    qout = TensorRef(qbuf, B, OH, OW, Cout, ld, None, 0)
+                    self._deferred.append(('qact', i, out, qout))
+                    out = qout
                 T.append(out)
             elif t == 'shortcut':
                 a, b_ = T[resolve(i - 1, i)], T[resolve(m._from, i)]
                 raw = self._new(a.rows, a.ld) if a.ld == a.C else self._new(a.rows, a.ld, fill=0.0)
                 out = TensorRef(raw, a.B, a.H, a.W, a.C, a.ld, None, act_code_of(m.act))
                 self._deferred.append(('copy', i, out, a, b_, 0, 1))
+                if self.qat:                                   # reference: act(fq(a + b))
+                    out.act, out.n_consumers = 0, 1
+                    self._inner[i] = out
+                    qout = TensorRef(self._new(a.rows, a.ld), a.B, a.H, a.W, a.C, a.ld, None, act_code_of(m.act))
+                    self._deferred.append(('qact', i, out, qout))
+                    out = qout
                 T.append(out)
             elif t == 'route':
                 srcs = [T[resolve(j, i)] for j in m._layers]
@@ -327,6 +374,12 @@ class Plan:
                     for s_ in srcs:
                         self._deferred.append(('copy', i, out, s_, None, off, 1))
                         off += s_.C
+                    if self.qat:                               # FloatFunctional.cat: the concatenation is re-quantised
+                        out.n_consumers = 1
+                        self._inner[i] = out
+                        qout = TensorRef(self._new(out.rows, ld), out.B, out.H, out.W, Ctot, ld, None, 0)
+                        self._deferred.append(('qact', i, out, qout))
+                        out = qout
                     T.append(out)
             elif t == 'upsample':
                 a = T[resolve(i - 1, i)]
@@ -351,27 +404,40 @@ class Plan:
             self._emit_backward(flat, mods, heads, resolve)
         self.fwd_arr = (abi.Op * len(self.fwd))(*self.fwd)
         self.bwd_arr = (abi.Op * len(self.bwd))(*self.bwd) if self.bwd else None
+        self.post_arr = (abi.Op * len(self.post_bwd))(*self.post_bwd) if self.post_bwd else None
 
     # ------------------------------------------------------------------------------------------ forward emission
     def _emit_forward(self, flat, heads):
         model, l = self.model, lib()
         mods = list(model.module_list)
         B = self.B
+        def wptr(i):
+            return ptr(self._wq[i][0]) if self.qat else ptr(mods[i].conv.weight)
+
+        if self.qat:
+            self._emit_qat_weight_ops(flat, mods)
         for item in self._deferred:
             kind = item[0]
-            if kind == 'stem_fwd':
+            if kind == 'qimg':                                 # QuantStub: observe + fake-quantise the input batch
+                idx = self._qact_fwd(abi.Src(None, None, None, 0, 0), self.qimg, B * 3 * self.IH * self.IW, 1, 1, ('in',), flat=1)
+                self.patch_x.append(('fwd', idx, 'qa'))
+            elif kind == 'qact':
+                _, i, inner, qout = item
+                self._qact_fwd(inner.src(), qout.raw, inner.rows, inner.C, qout.ld, ('a', i))
+            elif kind == 'stem_fwd':
                 _, i, out, nblk = item
                 conv = mods[i].conv
                 part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
-                a = abi.StemFwd(None, ptr(conv.weight), ptr(out.raw), ptr(part), B, 3, self.IH, self.IW, out.H, out.W,
-                                out.C, conv.stride[0], out.ld, out.bn.ldp if out.bn else 0)
+                a = abi.StemFwd(ptr(self.qimg) if self.qat else None, wptr(i), ptr(out.raw), ptr(part), B, 3, self.IH, self.IW,
+                                out.H, out.W, out.C, conv.stride[0], out.ld, out.bn.ldp if out.bn else 0)
                 idx = self._op(self.fwd, abi.OP_STEM_FWD, a)
-                self.patch_x.append(('fwd', idx, 'stf'))
+                if not self.qat:
+                    self.patch_x.append(('fwd', idx, 'stf'))
             elif kind == 'c1_fwd':
                 _, i, out, nblk, src, s = item
                 conv = mods[i].conv
                 part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
-                a = abi.Conv1x1Fwd(src.src(), ptr(conv.weight), ptr(conv.bias) if conv.bias is not None else None,
+                a = abi.Conv1x1Fwd(src.src(), wptr(i), ptr(conv.bias) if conv.bias is not None else None,
                                    ptr(out.raw), ptr(part), out.rows, src.C, out.C, out.ld, out.bn.ldp if out.bn else 0,
                                    s, out.H, out.W, src.H, src.W)
                 self._op(self.fwd, abi.OP_CONV1X1_FWD, a)
@@ -379,14 +445,14 @@ class Plan:
                 _, i, out, nblk, src, s = item
                 conv = mods[i].conv
                 part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
-                a = abi.DwFwd(src.src(), ptr(conv.weight), ptr(out.raw), ptr(part), B, src.H, src.W, out.H, out.W, out.C, s,
+                a = abi.DwFwd(src.src(), wptr(i), ptr(out.raw), ptr(part), B, src.H, src.W, out.H, out.W, out.C, s,
                               out.ld, out.bn.ldp if out.bn else 0)
                 self._op(self.fwd, abi.OP_DW_FWD, a)
             elif kind == 'gc_fwd':
                 _, i, out, nblk, src, s = item
                 conv = mods[i].conv
                 part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
-                a = abi.GconvFwd(src.src(), ptr(conv.weight), ptr(out.raw), ptr(part), B, src.H, src.W, out.H, out.W, out.C,
+                a = abi.GconvFwd(src.src(), wptr(i), ptr(out.raw), ptr(part), B, src.H, src.W, out.H, out.W, out.C,
                                  out.C // conv.groups, s, out.ld, out.bn.ldp if out.bn else 0)
                 self._op(self.fwd, abi.OP_GCONV_FWD, a)
             elif kind == 'bn_fwd':
@@ -398,7 +464,8 @@ class Plan:
                 a = abi.BnFwdFin(ptr(b.fwd_partial) if train else None, ptr(bm.weight), ptr(bm.bias), ptr(bm.running_mean),
                                  ptr(bm.running_var), ptr(bm.num_batches_tracked) if train else None, ptr(b.mean),
                                  ptr(b.invstd), ptr(b.scale), ptr(b.shift), b.fwd_nblk, b.ldp, b.C, int(train), b.count,
-                                 float(bm.eps), float(bm.momentum if bm.momentum is not None else 0.1), sc, tk)
+                                 float(bm.eps), float(bm.momentum if bm.momentum is not None else 0.1), sc, tk,
+                                 ptr(self._wq[i][1]) if self.qat else None)
                 self._op(self.fwd, abi.OP_BN_FWD_FIN, a)
             elif kind == 'copy':
                 _, i, out, a_, b_, coff, up = item
@@ -443,6 +510,30 @@ class Plan:
                 self._op(self.fwd, abi.OP_DECODE, d)
                 row0 += a.H * a.W * A
 
+    def _emit_qat_weight_ops(self, flat, mods):
+        """One table for every conv layer: forward = scale by gamma/sqrt(running_var+eps), observe, fake-quantise (first op
+        of the step); backward = gradient of the float weights (+ the BatchNorm-scale term) from the gradient of the
+        quantised ones (runs after both streams have joined)."""
+        items = []
+        for i in sorted(self._wq):
+            m = mods[i]
+            conv = m.conv
+            wq, sfv, dwq = self._wq[i]
+            bn = getattr(m, 'bn', None)
+            O_ = conv.out_channels
+            items.append(abi.QatWeightItem(
+                ptr(conv.weight), ptr(bn.weight) if bn is not None else None, ptr(bn.running_var) if bn is not None else None,
+                ptr(wq), ptr(sfv), self._qstate(('w', i)), ptr(dwq), flat.grad_ptr(conv.weight),
+                flat.grad_ptr(bn.weight) if bn is not None else None, float(bn.eps) if bn is not None else 0.0,
+                O_, conv.weight.numel() // O_))
+        table = (abi.QatWeightItem * len(items))(*items)
+        dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
+        self.keep.append(dev_table)
+        args = abi.QatWeight(dev_table.data_ptr(), len(items), self.q_observe, self.q_quant, 0.01)
+        self._op(self.fwd, abi.OP_QAT_WPREP, args)
+        if self.with_loss:
+            self._op(self.post_bwd, abi.OP_QAT_WGRAD, abi.QatWeight(dev_table.data_ptr(), len(items), 0, self.q_quant, 0.01))
+
     # ------------------------------------------------------------------------------------------ backward emission
     def _emit_backward(self, flat, mods, heads, resolve):
         l = lib()
@@ -470,7 +561,7 @@ class Plan:
         tr_idx = self._op(self.bwd, abi.OP_TRANSPOSE, abi.Transpose(None, 0, 0))
         tr_items = []
 
-        def transposed(conv):
+        def transposed(conv, wsrc):
             """Device address of the [I][O] copy of a 1x1 weight, refreshed at the start of every backward."""
             O_, I_ = conv.out_channels, conv.in_channels
             if O_ % 4:
@@ -478,7 +569,7 @@ class Plan:
             wt = self._new(I_ * O_)
             tile0 = tr_items[-1][4] + tr_items[-1][6] if tr_items else 0
             tiles_c = (I_ + 31) // 32
-            tr_items.append((ptr(conv.weight), wt.data_ptr(), O_, I_, tile0, tiles_c, ((O_ + 31) // 32) * tiles_c))
+            tr_items.append((wsrc, wt.data_ptr(), O_, I_, tile0, tiles_c, ((O_ + 31) // 32) * tiles_c))
             return wt.data_ptr()
 
         for i in range(len(mods) - 1, -1, -1):
@@ -494,9 +585,17 @@ class Plan:
             elif t == 'convolutional':
                 out = T[i]
                 conv = m.conv
+                wsrc = ptr(self._wq[i][0]) if self.qat else ptr(conv.weight)          # what the forward convolved with
+                wdst = ptr(self._wq[i][2]) if self.qat else flat.grad_ptr(conv.weight)   # where its gradient goes
                 if out.n_consumers == 0 or out.grad is None:
                     zero_params(m)
+                    if self.qat:
+                        self._op(self.bwd, abi.OP_FILL, abi.Fill(wdst, 0.0, conv.weight.numel()))
                 else:
+                    if self.qat:                    # through the activation observer: out <- the un-quantised producer tensor
+                        inner = self._inner[i]
+                        self._qact_bwd(out, inner, ('a', i))
+                        out = inner
                     if out.bn is not None:
                         if self.bn_train and out.bn.bwd_partial is None:
                             raise RuntimeError('internal: BN layer %d never finalised its gradient' % i)
@@ -508,23 +607,24 @@ class Plan:
                     k, s = conv.kernel_size[0], conv.stride[0]
                     if i == 0:
                         need = l.pq_stem3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C, 3)
-                        a = abi.StemWgrad(dy, None, flat.grad_ptr(conv.weight), None, B, 3, self.IH, self.IW, out.H, out.W,
-                                          out.C, s)
+                        a = abi.StemWgrad(dy, ptr(self.qimg) if self.qat else None, wdst, None, B, 3, self.IH, self.IW, out.H,
+                                          out.W, out.C, s)
                         idx = self._op(self.bwd, abi.OP_STEM_WGRAD, a)
-                        self.patch_x.append(('bwd', idx, 'stw'))
+                        if not self.qat:
+                            self.patch_x.append(('bwd', idx, 'stw'))
                         wg_ops.append((idx, 'stw', need))
                     else:
                         src = T[resolve(i - 1, i)]
                         if k == 1:
                             need = l.pq_conv1x1_wgrad_scratch_bytes(out.rows, src.C, out.C)
-                            a = abi.Conv1x1Wgrad(dy, src.src(), flat.grad_ptr(conv.weight),
+                            a = abi.Conv1x1Wgrad(dy, src.src(), wdst,
                                                  flat.grad_ptr(conv.bias) if conv.bias is not None else None, None,
                                                  out.rows, src.C, out.C, s, out.H, out.W, src.H, src.W)
                             idx = self._op(self.bwd, abi.OP_CONV1X1_WGRAD, a)
                             wg_ops.append((idx, 'c1w', need))
                             if src.needs_grad and s == 1:
-                                d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), self._sink(src, l.pq_conv1x1_blocks(src.rows, src.C)), out.rows,
-                                                     src.C, out.C, 1, 0, 0, 0, 0, transposed(conv))
+                                d = abi.Conv1x1Dgrad(dy, wsrc, self._sink(src, l.pq_conv1x1_blocks(src.rows, src.C)), out.rows,
+                                                     src.C, out.C, 1, 0, 0, 0, 0, transposed(conv, wsrc))
                                 self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
                             elif src.needs_grad:
                                 # strided 1x1: dz only lands on every s-th pixel.  The GEMM accumulates into a (zeroed if it
@@ -534,8 +634,8 @@ class Plan:
                                 if not sk.accumulate:
                                     self._op(self.bwd, abi.OP_FILL, abi.Fill(ptr(src.grad), 0.0, src.rows * src.ld))
                                 acc = abi.GSink(sk.g, sk.y, None, None, None, None, None, src.ld, src.ld, 0, 1, 0, 0)
-                                d = abi.Conv1x1Dgrad(dy, ptr(conv.weight), acc, out.rows, src.C, out.C, s, out.H, out.W, src.H,
-                                                     src.W, transposed(conv))
+                                d = abi.Conv1x1Dgrad(dy, wsrc, acc, out.rows, src.C, out.C, s, out.H, out.W, src.H,
+                                                     src.W, transposed(conv, wsrc))
                                 self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
                                 if sk.finalize:
                                     sk.accumulate = 0
@@ -544,12 +644,12 @@ class Plan:
                         elif conv.groups != conv.in_channels or conv.in_channels // conv.groups > 1:
                             gw = conv.in_channels // conv.groups
                             need = l.pq_gconv3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C, gw)
-                            a = abi.GconvWgrad(dy, src.src(), flat.grad_ptr(conv.weight), None, B, src.H, src.W, out.H, out.W,
+                            a = abi.GconvWgrad(dy, src.src(), wdst, None, B, src.H, src.W, out.H, out.W,
                                                out.C, gw, s)
                             idx = self._op(self.bwd, abi.OP_GCONV_WGRAD, a)
                             wg_ops.append((idx, 'gcw', need))
                             if src.needs_grad:
-                                d = abi.GconvDgrad(dy, ptr(conv.weight), self._sink(src, l.pq_gconv3x3_blocks(B, src.H, src.W)),
+                                d = abi.GconvDgrad(dy, wsrc, self._sink(src, l.pq_gconv3x3_blocks(B, src.H, src.W)),
                                                    B, src.H, src.W, out.H, out.W, out.C, gw, s)
                                 self._op(self.bwd, abi.OP_GCONV_DGRAD, d)
                         else:
@@ -557,17 +657,17 @@ class Plan:
                                 # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
                                 need = l.pq_dw3x3_bwd_scratch_bytes(B, src.H, src.W, out.H, out.W, out.C, s)
                                 buf = self._new(max(need, 64) // 4 + 16)
-                                a = abi.DwBwd(dy, src.src(), ptr(conv.weight),
+                                a = abi.DwBwd(dy, src.src(), wsrc,
                                               self._sink(src, l.pq_dw3x3_bwd_blocks(B, src.H, src.W, s)),
-                                              flat.grad_ptr(conv.weight), ptr(buf), B, src.H, src.W, out.H, out.W, out.C, s)
+                                              wdst, ptr(buf), B, src.H, src.W, out.H, out.W, out.C, s)
                                 self._op(self.bwd, abi.OP_DW_BWD, a)
                             else:
                                 need = l.pq_dw3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C)
-                                a = abi.DwWgrad(dy, src.src(), flat.grad_ptr(conv.weight), None, B, src.H, src.W, out.H, out.W,
+                                a = abi.DwWgrad(dy, src.src(), wdst, None, B, src.H, src.W, out.H, out.W,
                                                 out.C, s)
                                 idx = self._op(self.bwd, abi.OP_DW_WGRAD, a)
                                 wg_ops.append((idx, 'dww', need))
-                                d = abi.DwDgrad(dy, ptr(conv.weight), self._sink(src, l.pq_ew_blocks(src.rows, src.C)), B, src.H,
+                                d = abi.DwDgrad(dy, wsrc, self._sink(src, l.pq_ew_blocks(src.rows, src.C)), B, src.H,
                                                 src.W, out.H, out.W, out.C, s)
                                 self._op(self.bwd, abi.OP_DW_DGRAD, d)
                 plist = list(m.parameters())
@@ -576,6 +676,9 @@ class Plan:
                     self.segments.append((len(self.bwd), lo))
             elif t == 'shortcut':
                 out = T[i]
+                if self.qat and out.grad is not None:
+                    self._qact_bwd(out, self._inner[i], ('a', i))
+                    out = self._inner[i]
                 if out.grad is not None:
                     for srcT in (T[resolve(i - 1, i)], T[resolve(m._from, i)]):
                         r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B, srcT.H,
@@ -584,6 +687,9 @@ class Plan:
             elif t == 'route':
                 if not m.single and len(m._layers) > 1:
                     out = T[i]
+                    if self.qat and out.grad is not None:
+                        self._qact_bwd(out, self._inner[i], ('a', i))
+                        out = self._inner[i]
                     off = 0
                     for j in m._layers:
                         srcT = T[resolve(j, i)]
@@ -622,7 +728,10 @@ class Plan:
         xp = x.data_ptr()
         for which, idx, field in self.patch_x:
             arr = self.fwd_arr if which == 'fwd' else self.bwd_arr
-            getattr(arr[idx].u, field).image = xp
+            if field == 'qa':
+                arr[idx].u.qa.inp.x = xp          # QAT: the batch enters through the input observer
+            else:
+                getattr(arr[idx].u, field).image = xp
         if target is not None:
             pick = {8: (0, 3), 16: (1, 4), 32: (2, 5)}       # reference model/interpreter.py:16-20
             for lst, arr in ((self.loss_ops_f, self.fwd_arr), (self.loss_ops_b, self.bwd_arr)):
@@ -645,7 +754,11 @@ class Plan:
         sd = C.c_void_p(side.cuda_stream) if side is not None else None
         if reducer is None:
             check(l.pq_run_ops2(self.bwd_arr, len(self.bwd), st, sd), 'backward step')
+            if self.post_arr is not None:        # QAT: weight gradients through the weight observers (needs every wgrad done)
+                check(l.pq_run_ops(self.post_arr, len(self.post_bwd), st), 'backward step (weight observers)')
             return
+        if self.post_arr is not None:
+            raise NotImplementedError('quantisation-aware training is single-GPU (as in the reference, trainer.py:148)')
         # bucketed replay: launch the ops up to each mark (pq_run_ops2 joins the side stream at the end of every call, so
         # the gradient range is final on the main stream), then hand the finished range to the reducer
         flat = self.model._flat

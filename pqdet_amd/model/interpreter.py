@@ -58,9 +58,10 @@ class AnyModel(nn.Module):
 
     def __init__(self, cfg: Union[str, IO], quant: bool = False, onnx: bool = False):
         super().__init__()
-        if quant:
-            raise NotImplementedError('the QAT model (BASELINE config 5) is not implemented in this build yet')
-        self.quant = quant
+        self.quant = quant            # quant=True: every activation is ReLU (reference parser :408-409); QAT itself is
+        self._qat = False             # switched on by tools.prepare_qat(model), like in the reference
+        self.qat_observer_enabled = True
+        self.qat_fake_quant_enabled = True
         if isinstance(cfg, str):
             cfg = open(cfg, 'r')
         self.module_list = nn.ModuleList(Parser(cfg).torch_layers(quant, onnx))
@@ -105,12 +106,51 @@ class AnyModel(nn.Module):
         for b in self.buffers():
             if b.device != x.device:
                 raise abi.PQError('model buffers live on %s but the input is on %s' % (b.device, x.device))
-        key = (tuple(x.shape), bool(self.training), bool(with_loss))
+        key = (tuple(x.shape), bool(self.training), bool(with_loss), bool(self._qat), bool(self.qat_observer_enabled),
+               bool(self.qat_fake_quant_enabled))
         plan = self._plans.get(key)
         if plan is None:
             plan = Plan(self, tuple(x.shape), bool(self.training), bool(with_loss))
             self._plans[key] = plan
         return plan
+
+    # ---- quantisation-aware training ----------------------------------------------------------------------
+    def prepare_qat(self):
+        """Attach observer state for the input, every conv weight / output, every shortcut sum and every concatenation
+        (what ``torch.quantization.prepare_qat`` adds to the reference model): one row {min, max, scale, zero_point} each,
+        kept in the buffer ``_qat_state`` (part of the state_dict) in the reference's module order."""
+        index, n = {('in',): 0}, 1
+        for i, m in enumerate(self.module_list):
+            if m._type == 'convolutional':
+                index[('w', i)], index[('a', i)] = n, n + 1
+                n += 2
+            elif m._type == 'shortcut' or (m._type == 'route' and not m.single and len(m._layers) > 1):
+                index[('a', i)] = n
+                n += 1
+            elif m._type not in ('route', 'upsample', 'yolo'):
+                raise NotImplementedError("layer type '%s' has no QAT support" % m._type)
+        dev = next(self.parameters()).device
+        state = torch.tensor([float('inf'), float('-inf'), 1.0, 0.0], device=dev).repeat(n, 1).contiguous()
+        self.register_buffer('_qat_state', state)
+        self._qat_index = index
+        self._qat = True
+        self._plans.clear()
+        return self
+
+    def qat_observers(self):
+        """{reference-style module name: (min, max, scale, zero_point)} for checkpoints / inspection."""
+        st = self._qat_state.detach().cpu()
+        out = {}
+        for key, k in self._qat_index.items():
+            if key[0] == 'in':
+                name = 'qstub.activation_post_process'
+            elif key[0] == 'w':
+                name = 'module_list.%d.conv.weight_fake_quant' % key[1]
+            else:
+                m = self.module_list[key[1]]
+                name = 'module_list.%d.%s.activation_post_process' % (key[1], 'conv' if m._type == 'convolutional' else 'ffunc')
+            out[name] = tuple(st[k].tolist())
+        return out
 
     # ---- NaN trap (reference model/loss.py:110-114), polled one step late unless nan_check == 'sync' ----
     def check_nan(self, wait: bool = True):

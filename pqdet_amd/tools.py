@@ -158,9 +158,9 @@ def build_model(cfg_path: Optional[str], weight_path: Optional[str] = None, back
         if clear_history:
             model_info['step'] = 0
     cfg = cfg_path if cfg_path else StringIO(ckpt['cfg'])
-    if state_dict_type in {'qat', 'quant'} or qat or quantized:
-        raise NotImplementedError('QAT / int8 checkpoints (BASELINE config 5) are not implemented in this build yet')
-    model = DetectionModel(cfg, False, onnx)
+    if state_dict_type in {'qat', 'quant'} or quantized:
+        raise NotImplementedError('loading QAT / converted int8 checkpoints is not implemented in this build yet')
+    model = DetectionModel(cfg, qat, onnx)
     if backbone_path:
         print('loading backbone weights from {}'.format(backbone_path))
         load_backbone(model, torch.load(backbone_path, map_location='cpu'))
@@ -168,12 +168,45 @@ def build_model(cfg_path: Optional[str], weight_path: Optional[str] = None, back
         load_weight(model, weight)
         print('resumed at %d steps from %s' % (model_info['step'], weight_path))
     model = model.to(device)
+    if qat:                                   # reference :225-235: fuse conv+bn+relu, then attach observers / fake-quantisers
+        model.train()
+        fuse_model(model)
+        prepare_qat(model, backend or 'qnnpack')
+        return model, model_info              # QAT is single-GPU in the reference (trainer.py:148)
     if dataparallel:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from .parallel import DistributedModel
             model = DistributedModel(model)
     return model, model_info
+
+
+def fuse_model(model: nn.Module, inplace: bool = True) -> nn.Module:
+    """reference :256-275.  Conv + BatchNorm + ReLU are always executed fused by the HIP engine; kept for API parity."""
+    return model
+
+
+def prepare_qat(model: nn.Module, backend: str = 'qnnpack', inplace: bool = True) -> nn.Module:
+    """reference :277-290: per-tensor fake-quantisation of every conv weight (qint8, symmetric) and of the input, every conv
+    block output, shortcut sum and concatenation (quint8, affine) with moving-average min/max observers -- the
+    ``get_default_qat_qconfig('qnnpack')`` recipe ('fbgemm' differs only in reduce_range / per-channel weights and is not
+    offered).  The model must have been built with ``quant=True``."""
+    if backend != 'qnnpack':
+        raise NotImplementedError("only the 'qnnpack' QAT recipe (the reference's yamls/quant.yaml setting) is implemented")
+    m = bare_model(model)
+    if not getattr(m, 'quant', False):
+        raise ValueError('prepare_qat needs a model built with quant=True (ReLU activations)')
+    m.prepare_qat()
+    return model
+
+
+def disable_observer(model: nn.Module):
+    """``model.apply(torch.quantization.disable_observer)`` of the reference trainer (:299-300): freeze quantiser ranges."""
+    bare_model(model).qat_observer_enabled = False
+
+
+def enable_observer(model: nn.Module):
+    bare_model(model).qat_observer_enabled = True
 
 
 def get_bn_layers(model: nn.Module) -> List[nn.BatchNorm2d]:

@@ -43,7 +43,8 @@ def main():
     tools.fuse_model(net)
     tools.prepare_qat(net, backend='qnnpack')
 
-    B, S, ncls = 2, 64, 20
+    B, S, ncls = 2, 256, 20      # 64x64 leaves 8 samples per channel in the stride-32 BatchNorms: with quantised inputs their
+    # batch variance can be a few quantisation steps, and fp32 round-off differences between two CPUs change the loss by 10 %
     hw = np.array([[S // s, S // s] for s in (8, 16, 32)])
     losses = []
     for step in range(2):
@@ -85,6 +86,7 @@ def main():
     net.eval()
     with torch.no_grad():
         ev = net(seeded_images(B, S, S, 7))
+    ev = ev[:, ::37]             # keep the fixture small: every 37th prediction row
     npz['g9_eval'] = mg.t2n(ev)
     np.savez_compressed(os.path.join(HERE, 'golden_qat.npz'), **npz)
     import json

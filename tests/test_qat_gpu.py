@@ -1,0 +1,243 @@
+"""Quantisation-aware training (BASELINE config 5) on the HIP engine.
+
+Fake-quantisation makes the network a step function of its inputs: one value that lands on the other side of a rounding
+boundary moves by a whole quantisation step (0.4 % of the tensor's range), and the box-regression loss of a responsible
+cell sees exp() of it.  The same oracle code run on two different CPUs (this container, the GPU box's host) already
+differs by 0.1-1.8 % in the total loss, 4-12 % in the box term and up to 33 % in single observer ranges at 256x256, and by
+12 % in the total loss at 64x64 (scripts/qat_noise_probe.py).  So parity is established in
+three layers:
+  1. the kernels (weight preparation / gradient, activation observer + quantiser forward / backward) against the oracle's
+     functions on random tensors -- exact;
+  2. the whole QAT step with the rounding switched off (observers on, fake_quant off): a continuous function that
+     exercises every piece of QAT plumbing (weight scaling by gamma/sigma, BatchNorm on conv/sf, observer updates, the
+     extra gradient paths) -- compared tightly with the oracle in the same mode;
+  3. the full QAT step against the G9 fixtures recorded from the reference -- observer ranges and losses within the
+     cross-machine noise band measured above.
+"""
+import ctypes as C
+import io
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import qat as oqat  # noqa: E402
+from pqdet_amd import abi, optim, tools  # noqa: E402
+from pqdet_amd.model import zoo  # noqa: E402
+from pqdet_amd.model.interpreter import DetectionModel  # noqa: E402
+from seedfill import seeded_fill, seeded_images  # noqa: E402
+from test_oracle_qat import _g9, qat_batch  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _product(seed=0):
+    net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')), quant=True)
+    seeded_fill(net, seed)
+    net = net.to(DEV)
+    net.train()
+    tools.fuse_model(net)
+    tools.prepare_qat(net, backend='qnnpack')
+    return net
+
+
+# ------------------------------------------------------------------------------------------------- 1. kernels
+@pytest.mark.parametrize('rows,Cc,act', [(300, 32, 1), (1000, 75, 0), (64, 96, 1)])
+def test_qact_forward_backward_match_oracle_exactly(rows, Cc, act):
+    g = torch.Generator().manual_seed(rows + Cc)
+    l = abi.lib()
+    ld = (Cc + 3) // 4 * 4
+    x = torch.zeros(rows, ld)
+    x[:, :Cc] = torch.randn(rows, Cc, generator=g) * 3
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.5
+    fq = oqat.act_fq()
+    state = torch.tensor([float('inf'), float('-inf'), 1.0, 0.0], device=DEV)
+    xd = x.to(DEV)
+    scd = torch.zeros(ld + 16, device=DEV); scd[:Cc] = sc.to(DEV)
+    shd = torch.zeros(ld + 16, device=DEV); shd[:Cc] = sh.to(DEV)
+    out = torch.zeros(rows, ld, device=DEV)
+    part = torch.empty(2 * l.pq_qact_blocks(rows * Cc) + 8, device=DEV)
+    for step in range(3):                                   # moving average over several "batches"
+        xs = (x * (1 + 0.3 * step))
+        xd.copy_(xs)
+        u = (xs[:, :Cc] * sc + sh).requires_grad_(True)
+        v = torch.relu(u) if act else u
+        want = fq(v)
+        a = abi.Qact(abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), ld, act), out.data_ptr(), state.data_ptr(),
+                     part.data_ptr(), rows, Cc, ld, 0, 1, 1, 0.01)
+        abi.check(l.pq_qact_fwd(C.byref(a), _stream()))
+        torch.cuda.synchronize()
+        st = state.cpu()
+        # u = scale*x + shift is one FMA on the device and two roundings on the host: ranges agree to an ulp
+        np.testing.assert_allclose(st[:3].numpy(), [fq.min_val.item(), fq.max_val.item(), fq.scale.item()], rtol=2e-6, atol=1e-7)
+        assert st[3].item() == float(fq.zero_point.item())
+        # ... and a handful of values may land on the other side of a rounding boundary (one quantisation step)
+        diff = (out[:, :Cc].cpu() - want.detach()).abs()
+        assert (diff > 1e-6).float().mean().item() < 2e-3 and diff.max().item() <= fq.scale.item() * 1.001
+    # backward of the last step: straight-through mask x relu'
+    gq = torch.randn(rows, Cc, generator=g)
+    want.backward(gq)
+    gwant = u.grad * (sc if False else 1.0)                 # gradient w.r.t. u (the pre-activation)
+    gqd = torch.zeros(rows, ld, device=DEV); gqd[:, :Cc] = gq.to(DEV)
+    gout = torch.full((rows, ld), float('nan'), device=DEV)
+    Cq = Cc if Cc % 4 == 0 else ld
+    b = abi.QactBwd(gqd.data_ptr(), abi.GSink(gout.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), None, None, None,
+                                               ld, ld, act, 0, 1, 0), state.data_ptr(), rows, Cq, ld, 1)
+    abi.check(l.pq_qact_bwd(C.byref(b), _stream()))
+    torch.cuda.synchronize()
+    d = (gout[:, :Cc].cpu() - gwant).abs()
+    assert (d > 1e-6).float().mean().item() < 2e-3          # identical except where u sits on a rounding / ReLU boundary
+
+
+def test_weight_prep_and_weight_grad_match_oracle():
+    g = torch.Generator().manual_seed(9)
+    l = abi.lib()
+    shapes = [(32, 27, True), (96, 16, True), (75, 1024, False), (144, 9, True)]
+    items, keep, refs = [], [], []
+    for O_, K_, has_bn in shapes:
+        w = torch.randn(O_, K_, generator=g) * 0.2
+        gamma = torch.rand(O_, generator=g) + 0.5
+        rv = torch.rand(O_, generator=g) + 0.3
+        dwq = torch.randn(O_, K_, generator=g)
+        t = dict(w=w.to(DEV), gamma=gamma.to(DEV), rv=rv.to(DEV), wq=torch.empty(O_, K_, device=DEV), sf=torch.empty(O_ + 16, device=DEV),
+                 state=torch.tensor([float('inf'), float('-inf'), 1.0, 0.0], device=DEV), dwq=dwq.to(DEV),
+                 dw=torch.full((O_, K_), float('nan'), device=DEV), dgamma=torch.ones(O_, device=DEV))
+        keep.append(t)
+        items.append(abi.QatWeightItem(t['w'].data_ptr(), t['gamma'].data_ptr() if has_bn else None, t['rv'].data_ptr() if has_bn else None,
+                                       t['wq'].data_ptr(), t['sf'].data_ptr(), t['state'].data_ptr(), t['dwq'].data_ptr(),
+                                       t['dw'].data_ptr(), t['dgamma'].data_ptr() if has_bn else None, 1e-5, O_, K_))
+        refs.append((w, gamma, rv, dwq, has_bn))
+    table = (abi.QatWeightItem * len(items))(*items)
+    dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(DEV)
+    args = abi.QatWeight(dev_table.data_ptr(), len(items), 1, 1, 0.01)
+    abi.check(l.pq_qat_weight_prep(C.byref(args), _stream()))
+    abi.check(l.pq_qat_weight_grad(C.byref(args), _stream()))
+    torch.cuda.synchronize()
+    for t, (w, gamma, rv, dwq, has_bn) in zip(keep, refs):
+        wr = w.clone().requires_grad_(True)
+        gr = gamma.clone().requires_grad_(True)
+        fq = oqat.weight_fq()
+        sf = gr / torch.sqrt(rv + 1e-5) if has_bn else torch.ones_like(gr)
+        wq = fq(wr * sf.reshape(-1, 1))
+        # the conv output is divided by sf again: d/dsf of that division is -sum(dwq * wq)/sf per channel
+        loss = (wq * dwq).sum() - ((wq.detach() * dwq).sum(1) / sf.detach() * sf).sum() if has_bn else (wq * dwq).sum()
+        loss.backward()
+        st = t['state'].cpu()
+        assert st[2].item() == fq.scale.item() and st[0].item() == fq.min_val.item()
+        assert torch.equal(t['wq'].cpu(), wq.detach())
+        assert torch.allclose(t['dw'].cpu(), wr.grad, rtol=1e-6, atol=1e-7)
+        if has_bn:
+            assert torch.allclose(t['dgamma'].cpu() - 1.0, gr.grad, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------- 2. rounding off
+def test_qat_plumbing_with_rounding_switched_off_matches_oracle():
+    text = zoo.cfg_text('mobilenetv2-fpn')
+    net = _product(seed=4)
+    net.qat_fake_quant_enabled = False
+    ref = oqat.OracleQATNet(io.StringIO(text))
+    seeded_fill(ref.float_net, 4)
+    ref.train()
+    for m in ref.modules():
+        if isinstance(m, oqat.FakeQuant):
+            m.fake_quant_enabled = False
+    for step in range(2):
+        x, tgt = qat_batch(step, B=3, S=160)
+        net.zero_grad()
+        out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+        out['loss'].mean().backward()
+        ref.zero_grad()
+        want = ref(x, tgt)
+        want['loss'].mean().backward()
+        for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss'):
+            assert abs(out[k].item() - want[k].item()) <= 1e-3 * abs(want[k].item()) + 1e-5, (step, k)
+    mine = dict(net.named_parameters())
+    bad = []
+    top = max(p.grad.double().norm().item() for p in ref.float_net.parameters())
+    for k, p in ref.float_net.named_parameters():
+        gw = p.grad.double()
+        if gw.norm().item() < 1e-6 * top:      # e.g. the BatchNorm shift of a linear layer that feeds only conv+BN: exactly 0
+            continue                           # in exact arithmetic, pure round-off in any fp32 evaluation
+        e = ((mine[k].grad.cpu().double() - gw).norm() / gw.norm()).item()
+        if e > 0.08:                       # fp32 conditioning of deep train-mode BN stacks, see test_model_gpu.py
+            bad.append((k, e))
+    assert len(bad) <= 3, bad
+    # observers saw the same ranges, running statistics moved the same way
+    from test_oracle_qat import qat_observers
+    want_obs = qat_observers(ref)
+    got_obs = net._qat_state.cpu().numpy()
+    np.testing.assert_allclose(got_obs[:, :3], want_obs[:, :3], rtol=2e-3, atol=1e-5)
+    sd, rd = net.state_dict(), ref.float_net.state_dict()
+    for k in rd:
+        if 'running' in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), rd[k].numpy(), rtol=2e-3, atol=1e-5, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------- 3. full QAT vs G9
+def test_qat_two_steps_against_reference_g9_within_quantisation_noise():
+    g, names = _g9()
+    net = _product()
+    losses = []
+    for step in range(2):
+        x, tgt = qat_batch(step)
+        net.zero_grad()
+        out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+        out['loss'].mean().backward()
+        losses.append([out[k].item() for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss')]
+                      + [v.item() for v in out['loss_per_branch']])
+    net.check_nan()
+    losses = np.array(losses)
+    print('losses', losses, 'reference', g['g9_loss'])
+    np.testing.assert_allclose(losses[:, 0], g['g9_loss'][:, 0], rtol=0.03)           # total
+    np.testing.assert_allclose(losses[:, 2], g['g9_loss'][:, 2], rtol=0.03)           # objectness (dominant, smooth)
+    np.testing.assert_allclose(losses[:, 3], g['g9_loss'][:, 3], rtol=0.10)           # class
+    assert np.all(np.abs(losses[:, 1] - g['g9_loss'][:, 1]) <= 0.5 * g['g9_loss'][:, 1])   # box term: exp() of 1-LSB flips
+    obs = net.qat_observers()
+    got = np.array([obs[k] for k in names['observers']])
+    want = g['g9_observers']
+    rng_w = np.maximum(np.abs(want[:, 0]), np.abs(want[:, 1]))
+    dev = np.abs(got[:, :2] - want[:, :2]).max(1) / (rng_w + 1e-6)
+    off = [(names['observers'][i], got[i, :2].tolist(), want[i, :2].tolist()) for i in np.argsort(-dev)[:6] if dev[i] > 0.05]
+    print('largest observer deviations', off)
+    # noise band measured with the CPU oracle on two machines (scripts/qat_noise_probe.py): 38 of 181 ranges differ by more
+    # than 5 %, 11 by more than 15 %, the worst by 33 % (single-element extremes behind 128-sample BatchNorms)
+    assert np.median(dev) < 0.02 and np.mean(dev > 0.15) < 0.2 and dev.max() < 1.0, off
+    w_rows = [i for i, k in enumerate(names['observers']) if k.endswith('weight_fake_quant')]
+    np.testing.assert_allclose(got[w_rows][:, 2], want[w_rows][:, 2], rtol=2e-2)      # weight scales: nearly noise free
+    gn_names = names['params']
+    mine = dict(net.named_parameters())
+    gn = np.array([mine[k.replace('.conv.bn.', '.bn.')].grad.double().norm().item() for k in gn_names])
+    ratio = gn / np.maximum(g['g9_gradnorm'], 1e-12)
+    big = g['g9_gradnorm'] > 1e-4 * g['g9_gradnorm'].max()
+    assert np.median(np.abs(np.log(ratio[big]))) < 0.1 and np.all(np.abs(np.log(ratio[big])) < 1.0)
+    net.eval()
+    with torch.no_grad():
+        ev = net(seeded_images(2, 256, 256, 7).to(DEV))[:, ::37]
+    conf_err = np.abs(ev.cpu().numpy()[..., 4:] - g['g9_eval'][..., 4:])
+    assert np.median(conf_err) < 5e-3 and np.mean(conf_err > 0.1) < 0.02
+
+
+def test_qat_small_shape_first_step_reproduces_reference_and_observer_switch():
+    """At 64x64 the first forward happens to meet no rounding-boundary disagreement with the reference run: every loss term
+    agrees to 1e-5 (recorded when the fixtures were made; kept as a canary with a fallback to the noise band)."""
+    net = _product()
+    x, tgt = qat_batch(0, S=64)
+    out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    got = np.array([out[k].item() for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss')])
+    want = np.array([88.1607894897461, 4.020943641662598, 33.55781936645508, 50.58203125])      # reference, this container
+    assert np.allclose(got, want, rtol=1e-4) or abs(got[0] - want[0]) <= 0.15 * want[0]
+    out['loss'].mean().backward()
+    before = net._qat_state.clone()
+    tools.disable_observer(net)                              # trainer.py:299-300: ranges stay frozen from here on
+    x, tgt = qat_batch(3, S=64)
+    net(x.to(DEV), tuple(t.to(DEV) for t in tgt))['loss'].mean().backward()
+    assert torch.equal(net._qat_state, before)
+    opt = optim.Adam(net.parameters(), lr=1e-4)
+    opt.step()
+    assert all(torch.isfinite(p).all() for p in net.parameters())
