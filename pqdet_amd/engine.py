@@ -205,7 +205,7 @@ class Plan:
         accumulate = t.received > 0
         finalize = (t.received + 1 == t.n_consumers)
         t.received += 1
-        stats = finalize and t.bn is not None and self.bn_train
+        stats = finalize and t.bn is not None           # frozen statistics still need the sums: they ARE dgamma / dbeta
         if stats:
             b = t.bn
             b.bwd_nblk = nblk
@@ -597,11 +597,9 @@ class Plan:
                         self._qact_bwd(out, inner, ('a', i))
                         out = inner
                     if out.bn is not None:
-                        if self.bn_train and out.bn.bwd_partial is None:
+                        if out.bn.bwd_partial is None:
                             raise RuntimeError('internal: BN layer %d never finalised its gradient' % i)
-                        if not self.bn_train:
-                            # frozen statistics: no sums were collected; p = gamma*invstd, q = r = 0; dgamma/dbeta need sums
-                            raise NotImplementedError('training with BatchNorm in eval mode is not supported yet')
+                        # frozen statistics (model.eval() or tools.freeze_bn_stats): p = gamma*invstd, q = r = 0
                         bn_bwd(out)
                     dy = out.gsrc(self.bn_train)
                     k, s = conv.kernel_size[0], conv.stride[0]

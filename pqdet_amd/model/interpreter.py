@@ -62,6 +62,7 @@ class AnyModel(nn.Module):
         self._qat = False             # switched on by tools.prepare_qat(model), like in the reference
         self.qat_observer_enabled = True
         self.qat_fake_quant_enabled = True
+        self.bn_frozen = False        # tools.freeze_bn_stats: BatchNorm uses (and keeps) its running statistics while training
         if isinstance(cfg, str):
             cfg = open(cfg, 'r')
         self.module_list = nn.ModuleList(Parser(cfg).torch_layers(quant, onnx))
@@ -106,11 +107,12 @@ class AnyModel(nn.Module):
         for b in self.buffers():
             if b.device != x.device:
                 raise abi.PQError('model buffers live on %s but the input is on %s' % (b.device, x.device))
-        key = (tuple(x.shape), bool(self.training), bool(with_loss), bool(self._qat), bool(self.qat_observer_enabled),
+        bn_train = bool(self.training) and not self.bn_frozen
+        key = (tuple(x.shape), bn_train, bool(with_loss), bool(self._qat), bool(self.qat_observer_enabled),
                bool(self.qat_fake_quant_enabled))
         plan = self._plans.get(key)
         if plan is None:
-            plan = Plan(self, tuple(x.shape), bool(self.training), bool(with_loss))
+            plan = Plan(self, tuple(x.shape), bn_train, bool(with_loss))
             self._plans[key] = plan
         return plan
 

@@ -205,6 +205,16 @@ def disable_observer(model: nn.Module):
     bare_model(model).qat_observer_enabled = False
 
 
+def freeze_bn_stats(model: nn.Module):
+    """``model.apply(torch.nn.intrinsic.qat.freeze_bn_stats)`` of the reference trainer (:302-303): from here on BatchNorm
+    normalises with its running statistics and stops updating them, while the weights keep training."""
+    bare_model(model).bn_frozen = True
+
+
+def update_bn_stats(model: nn.Module):
+    bare_model(model).bn_frozen = False
+
+
 def enable_observer(model: nn.Module):
     bare_model(model).qat_observer_enabled = True
 

@@ -268,6 +268,34 @@ def test_edge_cases_empty_targets_batch_one_and_untrimmed_box_lists():
     assert torch.isfinite(net.flat_buffers()[1]).all()
 
 
+def test_training_with_frozen_batchnorm_statistics():
+    """model.eval() + loss (validation loss) and tools.freeze_bn_stats (trainer.py:302-303): BatchNorm normalises with its
+    running statistics, the backward is p = gamma*invstd, q = r = 0.  Without batch statistics the whole net is well
+    conditioned, so gradients are compared directly."""
+    from pqdet_amd import tools
+    net, ref = _pair(seed=11)
+    x = seeded_images(2, 128, 160, 3)
+    tgt = _targets(2, 128, 160, 20, seed=2)
+    net.train(), ref.eval()
+    tools.freeze_bn_stats(net)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}
+    out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    out['loss'].mean().backward()
+    want = ref(x, tgt)
+    want['loss'].mean().backward()
+    for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss'):
+        assert abs(out[k].item() - want[k].item()) <= 1e-3 * abs(want[k].item()) + 1e-5, k
+    for (n1, p1), (_, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        if p2.grad.norm().item() > 1e-6:
+            assert _relerr(p1.grad, p2.grad) < 5e-3, n1
+    for k, v in sd0.items():
+        assert torch.equal(net.state_dict()[k], v), k        # statistics untouched
+    tools.update_bn_stats(net)
+    net.eval()                                                # the same through model.eval()
+    out2 = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    assert out2['loss'].item() == out['loss'].item()
+
+
 def test_no_cpu_fallback():
     from pqdet_amd import abi
     net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
