@@ -158,8 +158,9 @@ def build_model(cfg_path: Optional[str], weight_path: Optional[str] = None, back
         if clear_history:
             model_info['step'] = 0
     cfg = cfg_path if cfg_path else StringIO(ckpt['cfg'])
-    if state_dict_type in {'qat', 'quant'} or quantized:
-        raise NotImplementedError('loading QAT / converted int8 checkpoints is not implemented in this build yet')
+    if state_dict_type == 'quant' or quantized:
+        raise NotImplementedError('converted int8 models (torch.quantization.convert, CPU-only in the reference) are not built')
+    qat = qat or state_dict_type == 'qat'
     model = DetectionModel(cfg, qat, onnx)
     if backbone_path:
         print('loading backbone weights from {}'.format(backbone_path))
@@ -172,6 +173,8 @@ def build_model(cfg_path: Optional[str], weight_path: Optional[str] = None, back
         model.train()
         fuse_model(model)
         prepare_qat(model, backend or 'qnnpack')
+        if state_dict_type == 'qat':          # reference :236-238: a QAT checkpoint is loaded into the prepared model
+            load_qat_state_dict(model, weight)
         return model, model_info              # QAT is single-GPU in the reference (trainer.py:148)
     if dataparallel:
         import torch.distributed as dist
@@ -203,6 +206,85 @@ def prepare_qat(model: nn.Module, backend: str = 'qnnpack', inplace: bool = True
 def disable_observer(model: nn.Module):
     """``model.apply(torch.quantization.disable_observer)`` of the reference trainer (:299-300): freeze quantiser ranges."""
     bare_model(model).qat_observer_enabled = False
+
+
+_FQ_EPS = 1.1920928955078125e-07          # torch.finfo(torch.float32).eps, the observers' `eps` buffer
+
+
+def qat_state_dict(model: nn.Module) -> Dict[str, torch.Tensor]:
+    """State of a prepared QAT model under the reference's key names (what ``trainer.py:194-201`` stores with
+    ``'type': 'qat'``): fused modules keep BatchNorm inside ``conv`` (``module_list.i.conv.bn.weight``), every observer
+    contributes ``fake_quant_enabled, observer_enabled, scale, zero_point, activation_post_process.{eps,min_val,max_val}``."""
+    m = bare_model(model)
+    if not getattr(m, '_qat', False):
+        raise ValueError('not a prepared QAT model')
+    st = m._qat_state.detach().cpu()
+    on = torch.tensor([1 if m.qat_observer_enabled else 0], dtype=torch.int64)
+    fq = torch.tensor([1 if m.qat_fake_quant_enabled else 0], dtype=torch.int64)
+
+    def observer(prefix, row):
+        mn, mx, sc, zp = st[row].tolist()
+        return {prefix + '.fake_quant_enabled': fq.clone(), prefix + '.observer_enabled': on.clone(),
+                prefix + '.scale': torch.tensor([sc], dtype=torch.float32),
+                prefix + '.zero_point': torch.tensor([int(zp)], dtype=torch.int32),
+                prefix + '.activation_post_process.eps': torch.tensor([_FQ_EPS], dtype=torch.float32),
+                prefix + '.activation_post_process.min_val': torch.tensor(mn, dtype=torch.float32),
+                prefix + '.activation_post_process.max_val': torch.tensor(mx, dtype=torch.float32)}
+
+    out = dict(observer('qstub.activation_post_process', m._qat_index[('in',)]))
+    for i, layer in enumerate(m.module_list):
+        base = 'module_list.%d.' % i
+        if layer._type == 'convolutional':
+            out[base + 'conv.weight'] = layer.conv.weight.detach().cpu().clone()
+            if layer.conv.bias is not None:
+                out[base + 'conv.bias'] = layer.conv.bias.detach().cpu().clone()
+            if hasattr(layer, 'bn'):
+                for k, v in layer.bn.state_dict().items():
+                    out[base + 'conv.bn.' + k] = v.detach().cpu().clone()
+            out.update(observer(base + 'conv.weight_fake_quant', m._qat_index[('w', i)]))
+            out.update(observer(base + 'conv.activation_post_process', m._qat_index[('a', i)]))
+        elif ('a', i) in m._qat_index:
+            out.update(observer(base + 'ffunc.activation_post_process', m._qat_index[('a', i)]))
+    return out
+
+
+def load_qat_state_dict(model: nn.Module, state_dict: Dict[str, torch.Tensor]):
+    """Inverse of :func:`qat_state_dict`: accepts a reference QAT checkpoint's ``'model'`` entry (optional ``module.`` prefix)."""
+    m = bare_model(model)
+    if not getattr(m, '_qat', False):
+        raise ValueError('call tools.prepare_qat(model) before loading a QAT checkpoint')
+    sd = _strip(state_dict) if _state_dict_is_dp(state_dict) else state_dict
+    plain = {}
+    for k, v in sd.items():
+        if '.conv.bn.' in k:
+            plain[k.replace('.conv.bn.', '.bn.')] = v
+        elif k.endswith('conv.weight') or k.endswith('conv.bias'):
+            plain[k] = v
+    missing = [k for k in m.state_dict() if k != '_qat_state' and k not in plain]
+    if missing:
+        raise KeyError('QAT checkpoint lacks %d tensors, e.g. %s' % (len(missing), missing[:3]))
+    with torch.no_grad():
+        own = m.state_dict()
+        for k, v in plain.items():
+            own[k].copy_(v)
+        st = m._qat_state
+
+        def take(prefix, row):
+            st[row, 0] = float(sd[prefix + '.activation_post_process.min_val'])
+            st[row, 1] = float(sd[prefix + '.activation_post_process.max_val'])
+            st[row, 2] = float(sd[prefix + '.scale'])
+            st[row, 3] = float(sd[prefix + '.zero_point'])
+        take('qstub.activation_post_process', m._qat_index[('in',)])
+        for key, row in m._qat_index.items():
+            if key[0] == 'w':
+                take('module_list.%d.conv.weight_fake_quant' % key[1], row)
+            elif key[0] == 'a':
+                kind = 'conv' if m.module_list[key[1]]._type == 'convolutional' else 'ffunc'
+                take('module_list.%d.%s.activation_post_process' % (key[1], kind), row)
+        first = 'qstub.activation_post_process'
+        m.qat_observer_enabled = bool(int(sd[first + '.observer_enabled']))
+        m.qat_fake_quant_enabled = bool(int(sd[first + '.fake_quant_enabled']))
+    m._plans.clear()
 
 
 def freeze_bn_stats(model: nn.Module):

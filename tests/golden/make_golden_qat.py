@@ -91,7 +91,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'golden_qat.npz'), **npz)
     import json
     with open(os.path.join(HERE, 'g9_names.json'), 'w') as f:
-        json.dump({'params': names, 'observers': obs_names}, f)
+        json.dump({'params': names, 'observers': obs_names,
+                   'state_dict': [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()]}, f)
     print('wrote', len(npz), 'arrays;', len(names), 'params,', len(obs_names), 'observers; losses', losses)
 
 

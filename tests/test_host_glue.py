@@ -56,3 +56,33 @@ def test_numpy_nms_matches_reference(golden):
         np.testing.assert_array_equal(out, golden[key])
     one = np.array([[0, 0, 10, 10, 0.05, 2]], dtype=np.float32)
     np.testing.assert_array_equal(tools.nms(one, 0.1, 0.45), one)             # a class's best box is reported regardless
+
+
+def test_qat_checkpoint_layout_matches_reference_and_round_trips():
+    """qat_state_dict() emits exactly the reference QAT model's state_dict (names, shapes, dtypes recorded in G9) and
+    load_qat_state_dict() takes it back (CPU only: no kernel is involved)."""
+    import io
+    import json
+    import os
+
+    import torch
+    from pqdet_amd.model import zoo
+    from pqdet_amd.model.interpreter import DetectionModel
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    want = json.load(open(os.path.join(here, 'g9_names.json')))['state_dict']
+    net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')), quant=True)
+    tools.prepare_qat(tools.fuse_model(net))
+    net._qat_state[:, 0] = torch.arange(181.) * -0.01
+    net._qat_state[:, 1] = torch.arange(181.) * 0.02 + 1
+    net._qat_state[:, 2] = 0.05
+    net._qat_state[:, 3] = 7
+    sd = tools.qat_state_dict(net)
+    assert sorted(sd) == sorted(k for k, _, _ in want)
+    for k, shape, dtype in want:
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == dtype, k
+    other = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')), quant=True)
+    tools.prepare_qat(other)
+    tools.load_qat_state_dict(other, {'module.' + k: v for k, v in sd.items()})
+    assert torch.equal(other._qat_state, net._qat_state)
+    for (k1, v1), (_, v2) in zip(net.state_dict().items(), other.state_dict().items()):
+        assert torch.equal(v1, v2), k1
