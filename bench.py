@@ -204,11 +204,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    rehearsal = os.environ.get('PQ_BENCH_REHEARSAL') == '1'     # all ranks on cuda:0 over gloo: exercises this file's
+    if rehearsal:                                               # multi-rank flow on a one-GPU box (never a measurement)
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
