@@ -652,7 +652,9 @@ static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, 
     big = (O >= 96 && I >= 96);
     const int b = big ? 128 : 64;
     tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
-    int want = (512 + tiles - 1) / tiles;
+    static const char* tgt_env = getenv("PQ_WG_TARGET");
+    const int target = tgt_env ? atoi(tgt_env) : 768;
+    int want = (target + tiles - 1) / tiles;
     int maxs = (M + 255) / 256;
     splits = want < 1 ? 1 : (want > maxs ? maxs : want);
     if (splits < 1) splits = 1;
