@@ -649,7 +649,11 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
 }
 
 static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, int& rows) {
-    big = (O >= 96 && I >= 96);
+    // 64x64 output tiles everywhere: four times more tiles than 128x128 means four times fewer row splits for the same
+    // number of workgroups, i.e. longer contraction loops per workgroup and a quarter of the slab traffic; measured equal
+    // or faster on every layer shape of the nets (PQ_WG_BIG=1 restores the 128x128 rule for A/B timing)
+    static const char* big_env = getenv("PQ_WG_BIG");
+    big = (O >= 96 && I >= 96) && (big_env && big_env[0] == '1');
     const int b = big ? 128 : 64;
     tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
     static const char* tgt_env = getenv("PQ_WG_TARGET");
