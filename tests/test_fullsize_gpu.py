@@ -1,0 +1,114 @@
+"""BASELINE config-2 sizes (mobilenetv2-fpn, 512x512, batch 16; NMS over 16128 x 20 scores) checked through properties that
+do not need the CPU oracle to finish: determinism, linearity of the backward in the upstream gradient, score order and
+the suppression invariants of NMS at the largest candidate count the evaluator can produce."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pqdet_amd import tools  # noqa: E402
+from pqdet_amd.dataset import RECOVER_BBOXES_REGISTER, labels  # noqa: E402
+from pqdet_amd.model import zoo  # noqa: E402
+from pqdet_amd.model.interpreter import DetectionModel  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _iou_matrix(a, b):
+    lt = torch.maximum(a[:, None, :2], b[None, :, :2])
+    rb = torch.minimum(a[:, None, 2:4], b[None, :, 2:4])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa[:, None] + ab[None, :] - inter)
+
+
+def test_train_step_512_batch16_is_deterministic_and_linear_in_the_upstream_gradient():
+    torch.manual_seed(0)
+    net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn'))).to(DEV)
+    net.train()
+    x = torch.randn(16, 3, 512, 512, generator=torch.Generator().manual_seed(0)).to(DEV)
+    tgt = tuple(t.to(DEV) for t in labels.synthetic_targets(16, 512, 20, seed=1))
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    runs = []
+    for scale in (1.0, 1.0, 3.0):
+        net.load_state_dict(sd0)                      # same running statistics going in
+        out = net(x, tgt)
+        (out['loss'].mean() * scale).backward()
+        net.check_nan()
+        runs.append((torch.stack([out[k] for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss')]).clone(),
+                     net.flat_buffers()[1].clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])      # bit-identical replays
+    assert torch.equal(runs[0][0], runs[2][0])
+    g1, g3 = runs[0][1], runs[2][1]
+    assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    err = (g3 - 3.0 * g1).abs().max().item()
+    assert err <= 1e-5 * g3.abs().max().item()                                                 # backward is linear in dL
+    # loss_per_branch sums to the total, the three parts sum to the total
+    out = net(x, tgt)
+    assert abs(sum(v.item() for v in out['loss_per_branch']) - out['loss'].item()) <= 1e-4 * out['loss'].item()
+    parts = out['giou_loss'].item() + out['conf_loss'].item() + out['class_loss'].item()
+    assert abs(parts - out['loss'].item()) <= 1e-4 * out['loss'].item()
+
+
+def test_nms_invariants_at_the_largest_candidate_count():
+    """16128 boxes x 20 classes, every score above the threshold (what a random-init model produces):
+    322,560 candidates through pq_nms."""
+    g = torch.Generator().manual_seed(3)
+    n, ncls, thr = 16128, 20, 0.45
+    xy = torch.rand(n, 2, generator=g) * 480
+    wh = torch.rand(n, 2, generator=g) * 100 + 4
+    sc = torch.rand(n, ncls, generator=g) * 0.89 + 0.11
+    boxes = torch.cat([xy, xy + wh, sc], 1).to(DEV)
+    dets = tools.torch_nms(boxes, 0.1, thr)
+    k = dets.shape[0]
+    assert dets.shape[1] == 6 and 0 < k < n * ncls
+    score, cls = dets[:, 4], dets[:, 5].long()
+    assert bool((score[:-1] >= score[1:]).all())                                   # score-descending
+    assert bool((score > 0.1).all()) and int(cls.min()) >= 0 and int(cls.max()) < ncls
+    # every kept row is one of the inputs with its own class score
+    src = boxes[:, :4]
+    for c in (0, 7, 19):
+        mine = dets[cls == c]
+        # no two kept boxes of a class overlap by more than the threshold
+        iou = _iou_matrix(mine[:, :4], mine[:, :4])
+        iou.fill_diagonal_(0)
+        # (batched_nms compares IoUs of class-offset coordinates, x + cls*(max+1): float32 rounding of the shifted corners
+        # moves an IoU by ~1e-5, so both invariants are checked with that slack)
+        assert float(iou.max()) <= thr + 1e-4
+        # every suppressed candidate of the class overlaps a kept box of higher (or equal) score by more than the threshold
+        cand_scores = boxes[:, 4 + c]
+        kept_mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+        match = (mine[:, None, :4] == src[None, :, :]).all(-1) & (mine[:, 4:5] == cand_scores[None, :])
+        kept_idx = match.float().argmax(1)
+        assert bool(match.any(1).all())
+        kept_mask[kept_idx] = True
+        sup = (~kept_mask).nonzero()[:, 0]
+        sub = sup[torch.randperm(len(sup), generator=torch.Generator().manual_seed(c))[:2000].to(DEV)]
+        iou2 = _iou_matrix(src[sub], mine[:, :4])
+        ok = ((iou2 > thr - 1e-4) & (mine[None, :, 4] >= cand_scores[sub][:, None])).any(1)
+        assert bool(ok.all())
+    assert len(mine) > 0
+
+
+def test_eval_pipeline_512_batch16_shapes_and_ranges():
+    torch.manual_seed(1)
+    net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn'))).to(DEV)
+    net.eval()
+    x = torch.randn(16, 3, 512, 512, generator=torch.Generator().manual_seed(2)).to(DEV)
+    with torch.no_grad():
+        pred = net(x)
+    assert pred.shape == (16, 16128, 25)
+    assert bool(((pred[..., 4:] >= 0) & (pred[..., 4:] <= 1)).all())               # sigmoid outputs
+    assert bool((pred[..., 2] > pred[..., 0]).all()) and bool((pred[..., 3] > pred[..., 1]).all())   # xmax > xmin (exp > 0)
+    shapes = torch.tensor([[375., 500.]] * 16)
+    rec = RECOVER_BBOXES_REGISTER['voc'](pred.clone(), torch.FloatTensor([512, 512]).to(DEV), shapes.to(DEV))
+    assert rec.shape == (16, 16128, 24)
+    # base_sample.py:98-139: only the top-left corner is clamped at 0 and only the bottom-right one at (orig - 1)
+    assert float(rec[..., :2].min()) >= 0 and float(rec[..., 2].max()) <= 499 and float(rec[..., 3].max()) <= 374
+    again = RECOVER_BBOXES_REGISTER['voc'](pred.clone(), torch.FloatTensor([512, 512]).to(DEV), shapes.to(DEV))
+    assert torch.equal(rec, again)
