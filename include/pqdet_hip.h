@@ -274,6 +274,8 @@ typedef struct pq_copy_args {
     pq_src b;            /* b.x == NULL: no second addend */
     float* out;
     int32_t B, H, W, C, ldo, coff, up;   /* H,W = OUTPUT size */
+    const float* gate;   /* scale_channels (model/parser.py:158-168): out *= sigmoid(gate[b][c]); raw gate [B][ldgate] or NULL */
+    int32_t ldgate;
 } pq_copy_args;
 int pq_copy_fwd(const pq_copy_args* a, void* stream);
 
@@ -281,9 +283,26 @@ typedef struct pq_route_bwd_args {
     const float* gout;
     pq_gsink dx;
     int32_t B, H, W, C, ldgo, coff, up;  /* H,W = SOURCE (dx) size */
+    const float* gate;   /* scale_channels backward: dz = gout * sigmoid(gate[b][c]) (up == 1) */
+    int32_t ldgate;
+    int32_t bcast;       /* global average pool backward: gout is [B][ldgo], dz[b,p,c] = gout[b][c] * mul */
+    float mul;
 } pq_route_bwd_args;
 int pq_route_bwd(const pq_route_bwd_args* a, void* stream);
 int32_t pq_ew_blocks(int32_t rows, int32_t C);   /* row-blocks used by elementwise sinks (partial rows) */
+
+/* reductions over the pixels of each image (squeeze-and-excitation blocks of regnety-400m-fpn.cfg):
+ *   gout == NULL: out[b][c] = mul * sum_p a'[b,p,c]                (avgpool with height = width = 1)
+ *   gout != NULL: out[b][c] = s(1-s) * mul * sum_p gout[b,p,c] * a'[b,p,c], s = sigmoid(gate[b][c])   (scale_channels gate gradient) */
+typedef struct pq_pool_reduce_args {
+    pq_src a;
+    const float* gout; int32_t ldgo;
+    const float* gate; int32_t ldgate;
+    float* out; int32_t ldo;
+    int32_t B, HW, C;
+    float mul;
+} pq_pool_reduce_args;
+int pq_pool_reduce(const pq_pool_reduce_args* a, void* stream);
 
 /* ------------------------------------------------------------------ YOLO head: decode + loss
  * decode: model/parser.py:206-235; loss: model/loss.py:22-115 (+ tools.py:357-477 IoU family).
@@ -461,7 +480,7 @@ enum {
     PQ_OP_STEM_FWD, PQ_OP_STEM_WGRAD, PQ_OP_BN_FWD_FIN, PQ_OP_BN_BWD_FIN, PQ_OP_COPY_FWD, PQ_OP_ROUTE_BWD,
     PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD,
     PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD, PQ_OP_TRANSPOSE,
-    PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD
+    PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -476,7 +495,7 @@ typedef struct pq_op {
         pq_bn_fwd_finalize_args bnf; pq_bn_bwd_finalize_args bnb;
         pq_copy_args cp; pq_route_bwd_args rb;
         pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill; pq_transpose_args tr;
-        pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb;
+        pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);

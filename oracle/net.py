@@ -73,7 +73,8 @@ class OracleNet(nn.Module):
                     m.add_module('act', nn.ReLU() if quant_relu else _ACTS[s['activation']]())
                 m.kind = kind
                 chans = s['filters']
-                stride *= s['stride']
+                if stride is not None:                        # LayerInfo.update_stride: no-op after an avgpool (:26-29)
+                    stride *= s['stride']
             elif kind == 'shortcut':                          # :415-424
                 assert out_ch[-1] == out_ch[s['from']]
                 m = _Holder(kind, s)
@@ -89,10 +90,12 @@ class OracleNet(nn.Module):
                 stride = strides[idx[0]]
             elif kind == 'upsample':                          # :450-452
                 m = _Holder(kind, s)
-                stride //= s['stride']
+                if stride is not None:
+                    stride //= s['stride']
             elif kind == 'maxpool':
                 m = _Holder(kind, s)
-                stride *= s['stride']
+                if stride is not None:
+                    stride *= s['stride']
             elif kind == 'avgpool':
                 m = _Holder(kind, s)
                 stride = None

@@ -115,12 +115,19 @@ class BnBwdFin(C.Structure):
 
 class Copy(C.Structure):
     _fields_ = [('a', Src), ('b', Src), ('out', c_fp),
-                ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('ldo', i32), ('coff', i32), ('up', i32)]
+                ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('ldo', i32), ('coff', i32), ('up', i32),
+                ('gate', c_fp), ('ldgate', i32)]
+
+
+class PoolReduce(C.Structure):
+    _fields_ = [('a', Src), ('gout', c_fp), ('ldgo', i32), ('gate', c_fp), ('ldgate', i32), ('out', c_fp), ('ldo', i32),
+                ('B', i32), ('HW', i32), ('C', i32), ('mul', f32)]
 
 
 class RouteBwd(C.Structure):
     _fields_ = [('gout', c_fp), ('dx', GSink),
-                ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('ldgo', i32), ('coff', i32), ('up', i32)]
+                ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('ldgo', i32), ('coff', i32), ('up', i32),
+                ('gate', c_fp), ('ldgate', i32), ('bcast', i32), ('mul', f32)]
 
 
 class HeadView(C.Structure):
@@ -204,7 +211,7 @@ class _OpU(C.Union):
                 ('bnf', BnFwdFin), ('bnb', BnBwdFin), ('cp', Copy), ('rb', RouteBwd),
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
                 ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose),
-                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd)]
+                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce)]
 
 
 OPF_SIDE = 1
@@ -217,7 +224,7 @@ class Op(C.Structure):
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
  OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE, OP_QAT_WPREP, OP_QAT_WGRAD, OP_QACT_FWD,
- OP_QACT_BWD) = range(1, 27)
+ OP_QACT_BWD, OP_POOL_REDUCE) = range(1, 28)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
@@ -225,6 +232,7 @@ OP_FIELD = {
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
     OP_TRANSPOSE: 'tr', OP_QAT_WPREP: 'qw', OP_QAT_WGRAD: 'qw', OP_QACT_FWD: 'qa', OP_QACT_BWD: 'qb',
+    OP_POOL_REDUCE: 'pr',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -259,6 +267,7 @@ SIGNATURES = {
     'pq_copy_fwd': (C.c_int, [C.POINTER(Copy), C.c_void_p]),
     'pq_route_bwd': (C.c_int, [C.POINTER(RouteBwd), C.c_void_p]),
     'pq_ew_blocks': (i32, [i32, i32]),
+    'pq_pool_reduce': (C.c_int, [C.POINTER(PoolReduce), C.c_void_p]),
     'pq_decode': (C.c_int, [C.POINTER(Decode), C.c_void_p]),
     'pq_decode_bwd': (C.c_int, [C.POINTER(DecodeBwd), C.c_void_p]),
     'pq_yolo_loss_fwd': (C.c_int, [C.POINTER(YoloLoss), C.c_void_p]),

@@ -147,6 +147,8 @@ __global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_bwd_finalize_kernel(pq_bn_
 }
 
 // ------------------------------------------------------------------------------------------------ copy / route
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
 struct CopyP { pq_copy_args a; int C4; };
 
 __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
@@ -171,6 +173,10 @@ __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
         }
         float4 v = src_apply4(ldg4(a.a.x + sr * a.a.ld + c0), ka);
         if (two) v = f4add(v, src_apply4(ldg4(a.b.x + (size_t)r * a.b.ld + c0), kb));
+        if (a.gate) {                                   // scale_channels: multiply by the per-image channel gate sigmoid(z)
+            const float4 z = ldg4(a.gate + (size_t)(r / (a.H * a.W)) * a.ldgate + c0);
+            v = make_float4(v.x * sigmoidf_(z.x), v.y * sigmoidf_(z.y), v.z * sigmoidf_(z.z), v.w * sigmoidf_(z.w));
+        }
         stg4(a.out + (size_t)r * a.ldo + a.coff + c0, v);
     }
 }
@@ -190,8 +196,15 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     float4 s1 = f4zero(), s2 = f4zero();
     for (int r = bx * blockDim.y + threadIdx.y; r < rows && cok; r += gridDim.x * blockDim.y) {
         float4 dz = f4zero();
-        if (a.up == 1) {
+        if (a.bcast) {                                  // global average pool: every pixel of image b receives gout[b] * mul
+            const float4 gb = ldg4(a.gout + (size_t)(r / (a.H * a.W)) * a.ldgo + a.coff + c0);
+            dz = make_float4(gb.x * a.mul, gb.y * a.mul, gb.z * a.mul, gb.w * a.mul);
+        } else if (a.up == 1) {
             dz = ldg4(a.gout + (size_t)r * a.ldgo + a.coff + c0);
+            if (a.gate) {                               // scale_channels: d(feature) = gout * sigmoid(z)
+                const float4 z = ldg4(a.gate + (size_t)(r / (a.H * a.W)) * a.ldgate + c0);
+                dz = make_float4(dz.x * sigmoidf_(z.x), dz.y * sigmoidf_(z.y), dz.z * sigmoidf_(z.z), dz.w * sigmoidf_(z.w));
+            }
         } else {
             const int x = (int)(r % a.W);
             const int t2 = r / a.W;
@@ -207,6 +220,49 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     }
     float* part = (a.dx.finalize && a.dx.mean) ? a.dx.partial : nullptr;
     if (part) block_reduce_store_stats<256>(s1, s2, part, a.dx.ldp, c0, a.C, lds, bx);
+}
+
+// ------------------------------------------------------------------------------------------------ pooled reductions
+// out[b][c] = mul * sum_p a'[b,p,c]                                   (global average pool, model/parser.py avgpool)
+// out[b][c] = s(1-s) * sum_p gout[b,p,c] * a'[b,p,c],  s = sigmoid(gate[b][c])   (gradient of a scale_channels gate)
+struct PoolP { pq_pool_reduce_args a; int C4; };
+
+__global__ __launch_bounds__(256) void pool_reduce_kernel(PoolP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pq_pool_reduce_args& a = p.a;
+    const int b = blockIdx.x;
+    const int c4 = blockIdx.y * blockDim.x + threadIdx.x, c0 = c4 * 4;
+    const bool cok = c4 < p.C4;
+    const SrcCoef4 ka = src_coef4(a.a, c0, a.C);
+    float4 acc = f4zero();
+    if (cok)
+        for (int q = threadIdx.y; q < a.HW; q += blockDim.y) {
+            const size_t r = (size_t)b * a.HW + q;
+            float4 v = src_apply4(ldg4(a.a.x + r * a.a.ld + c0), ka);
+            if (a.gout) {
+                const float4 g = ldg4(a.gout + r * a.ldgo + c0);
+                v = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+            }
+            acc = f4add(acc, v);
+        }
+    float* slot = lds + (size_t)(threadIdx.y * blockDim.x + threadIdx.x) * 4;
+    slot[0] = acc.x; slot[1] = acc.y; slot[2] = acc.z; slot[3] = acc.w;
+    __syncthreads();
+    if (threadIdx.y == 0 && cok) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int y = 0; y < (int)blockDim.y; ++y) {
+            const float* o = lds + (size_t)(y * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] += o[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c0 + j >= a.C) break;
+            float v = t[j] * a.mul;
+            if (a.gate) { const float s = sigmoidf_(a.gate[(size_t)b * a.ldgate + c0 + j]); v *= s * (1.f - s); }
+            a.out[(size_t)b * a.ldo + c0 + j] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ batched transpose
@@ -336,6 +392,17 @@ extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
     hipLaunchKernelGGL(route_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float),
                        (hipStream_t)stream, p);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_pool_reduce(const pq_pool_reduce_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->a.x && a->out, "null pointer");
+    PQ_CHECK_ARG(a->B > 0 && a->HW > 0 && a->C > 0 && a->C % 4 == 0 && a->a.ld % 4 == 0 && (!a->gout || a->ldgo % 4 == 0), "bad shape");
+    if (act_is_special(a->a.act)) { pq_set_error("pq_pool_reduce: logistic/tanh operands are not supported"); return PQ_EUNSUPPORTED; }
+    PoolP p{*a, a->C / 4};
+    const int cx = pick_cx(p.C4), py = 256 / cx, gy = (p.C4 + cx - 1) / cx;
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3(a->B, gy), dim3(cx, py), (size_t)cx * py * 4 * sizeof(float), (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

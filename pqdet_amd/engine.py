@@ -268,6 +268,15 @@ class Plan:
                 h, w = h * f, w * f
             elif t == 'yolo':
                 use(resolve(i - 1, i))
+            elif t == 'avgpool':                               # squeeze of an SE block: global average per image
+                if tuple(m.output_size) != (1, 1):
+                    raise NotImplementedError('only global average pooling (height = width = 1) is supported')
+                use(resolve(i - 1, i))
+                h, w = 1, 1
+            elif t == 'scale_channels':                        # excitation: feature map x sigmoid(gate)
+                use(resolve(i - 1, i))
+                use(resolve(m._from, i))
+                h, w, c = shapes[resolve(m._from, i)]
             else:
                 raise NotImplementedError("layer type '%s' is not supported by the HIP engine yet" % t)
             shapes.append((h, w, c))
@@ -301,11 +310,15 @@ class Plan:
                 ld = _round_up(Cout, 4)
                 bn = conv_bn(m, Cout, rows)
                 act = act_code_of(getattr(m, 'act', None))
+                is_gate = False
+                if act == abi.ACT_LOGISTIC and i + 1 < len(mods) and mods[i + 1]._type == 'scale_channels' \
+                        and consumers.get(i, 0) == 1 and not hasattr(m, 'bn'):
+                    act, is_gate = 0, True          # the sigmoid of an SE gate is applied inside the scale_channels kernels
                 if act in (abi.ACT_LOGISTIC, abi.ACT_TANH):
-                    raise NotImplementedError('logistic / tanh between layers are not supported by the HIP engine yet '
-                                              '(no shipped detector cfg uses them)')
+                    raise NotImplementedError('logistic / tanh are only supported as the gate of a scale_channels layer')
                 raw = self._new(rows, ld) if ld == Cout else self._new(rows, ld, fill=0.0)
                 out = TensorRef(raw, B, OH, OW, Cout, ld, bn, act)
+                out.is_gate = is_gate
                 want_stats = bn is not None and self.bn_train
                 if self.qat:
                     wq = self._new(conv.weight.numel())
@@ -388,6 +401,22 @@ class Plan:
                 out = TensorRef(raw, a.B, a.H * f, a.W * f, a.C, a.ld, None, 0)
                 self._deferred.append(('copy', i, out, a, None, 0, f))
                 T.append(out)
+            elif t == 'avgpool':
+                if self.qat:
+                    raise NotImplementedError('avgpool has no QAT support')
+                a = T[resolve(i - 1, i)]
+                if a.C % 4:
+                    raise NotImplementedError('avgpool needs a channel count that is a multiple of 4')
+                out = TensorRef(self._new(a.B, a.ld), a.B, 1, 1, a.C, a.ld, None, 0)
+                self._deferred.append(('pool', i, out, a))
+                T.append(out)
+            elif t == 'scale_channels':
+                gate, feat = T[resolve(i - 1, i)], T[resolve(m._from, i)]
+                if not getattr(gate, 'is_gate', False) or gate.C != feat.C or gate.H != 1 or gate.W != 1 or feat.C % 4:
+                    raise NotImplementedError('scale_channels needs a (B, C, 1, 1) logistic conv as its gate and C % 4 == 0')
+                out = TensorRef(self._new(feat.rows, feat.ld), feat.B, feat.H, feat.W, feat.C, feat.ld, None, 0)
+                self._deferred.append(('scale', i, out, feat, gate))
+                T.append(out)
             elif t == 'yolo':
                 a = T[resolve(i - 1, i)]
                 if a.bn is not None or a.act != 0:
@@ -467,6 +496,15 @@ class Plan:
                                  float(bm.eps), float(bm.momentum if bm.momentum is not None else 0.1), sc, tk,
                                  ptr(self._wq[i][1]) if self.qat else None)
                 self._op(self.fwd, abi.OP_BN_FWD_FIN, a)
+            elif kind == 'pool':
+                _, i, out, a_ = item
+                pr = abi.PoolReduce(a_.src(), None, 0, None, 0, ptr(out.raw), out.ld, a_.B, a_.H * a_.W, a_.C, 1.0 / (a_.H * a_.W))
+                self._op(self.fwd, abi.OP_POOL_REDUCE, pr)
+            elif kind == 'scale':
+                _, i, out, feat, gate = item
+                none = abi.Src(None, None, None, 0, 0)
+                a = abi.Copy(feat.src(), none, ptr(out.raw), out.B, out.H, out.W, feat.C, out.ld, 0, 1, ptr(gate.raw), gate.ld)
+                self._op(self.fwd, abi.OP_COPY_FWD, a)
             elif kind == 'copy':
                 _, i, out, a_, b_, coff, up = item
                 none = abi.Src(None, None, None, 0, 0)
@@ -696,6 +734,27 @@ class Plan:
                                              srcT.H, srcT.W, srcT.C, out.ld, off, 1)
                             self._op(self.bwd, abi.OP_ROUTE_BWD, r)
                         off += srcT.C
+            elif t == 'avgpool':
+                out = T[i]
+                srcT = T[resolve(i - 1, i)]
+                if out.grad is not None:
+                    r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B, srcT.H, srcT.W,
+                                     srcT.C, out.ld, 0, 1, None, 0, 1, 1.0 / (srcT.H * srcT.W))
+                    self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+            elif t == 'scale_channels':
+                out = T[i]
+                gate, feat = T[resolve(i - 1, i)], T[resolve(m._from, i)]
+                if out.grad is not None:
+                    # gradient of the gate's pre-sigmoid value: s(1-s) * sum_p gout * feature
+                    if gate.grad is None:
+                        gate.grad = self._new(gate.rows, gate.ld, fill=0.0)
+                    gate.received += 1
+                    pr = abi.PoolReduce(feat.src(), ptr(out.grad), out.ld, ptr(gate.raw), gate.ld, ptr(gate.grad), gate.ld,
+                                        feat.B, feat.H * feat.W, feat.C, 1.0)
+                    self._op(self.bwd, abi.OP_POOL_REDUCE, pr)
+                    r = abi.RouteBwd(ptr(out.grad), self._sink(feat, l.pq_ew_blocks(feat.rows, feat.C)), feat.B, feat.H, feat.W,
+                                     feat.C, out.ld, 0, 1, ptr(gate.raw), gate.ld, 0, 1.0)
+                    self._op(self.bwd, abi.OP_ROUTE_BWD, r)
             elif t == 'upsample':
                 out = T[i]
                 srcT = T[resolve(i - 1, i)]

@@ -26,8 +26,18 @@ def _targets(batch, h, w, ncls, seed=1):
     return tuple(labels + boxes)
 
 
+def _cfg_text(name):
+    if name in zoo.available():
+        return zoo.cfg_text(name)
+    import json
+    import os
+    from test_cfg_zoo_gpu import cfg_text_from_specs
+    g1 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g1_parser.json')))['cfgs']
+    return cfg_text_from_specs(g1[name]['specs'])
+
+
 def _pair(seed=0, name='mobilenetv2-fpn'):
-    text = zoo.cfg_text(name)
+    text = _cfg_text(name)
     net = DetectionModel(io.StringIO(text))
     seeded_fill(net, seed)
     ref = OracleNet(io.StringIO(text))
@@ -72,7 +82,8 @@ def test_golden_g5_64(golden, g5_names, name, tag):
 
 
 @pytest.mark.parametrize('name,B,H,W', [('mobilenetv2-fpn', 3, 96, 160), ('mobilenetv2-fpn', 2, 256, 256),
-                                        ('regnetx-600m-fpn', 2, 128, 160), ('regnetx-600m-pan', 4, 160, 192)])
+                                        ('regnetx-600m-fpn', 2, 128, 160), ('regnetx-600m-pan', 4, 160, 192),
+                                        ('regnety-400m-fpn.cfg', 4, 160, 192)])
 def test_train_step_gradients_within_fp32_noise_of_fp64_oracle(name, B, H, W):
     """Every parameter gradient of the HIP step is as close to an fp64 evaluation of the reference algorithm as the
     reference's own fp32 CPU evaluation is (x5 slack, floor 2e-3): train-mode BN on small feature maps plus the
