@@ -187,11 +187,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int lrow = lane & 31, lh = lane >> 5;
-    auto compute = [&](int buf) {
+    // half = -1: the whole k-tile; 0 / 1: its first / second half (the LDS writes of the next tile are issued in between,
+    // so that they execute in the shadow of the first half's MFMAs instead of after the last one)
+    auto compute = [&](int buf, int half = -1) {
         const float* As = As2 + buf * (BM * LDT);
         const float* Bs = Bs2 + buf * (BN * LDT);
+        const int ks0 = half == 1 ? BK / 16 : 0, ks1 = half == 0 ? BK / 16 : BK / 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
+            if (ks < ks0 || ks >= ks1) continue;
             float4 af[TI], bf[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -233,15 +237,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #ifndef PQ_ABLATE_LOADS
             if (kt + 2 < nk) load_tiles((kt + 2) * BK, r0);
 #endif
-            compute(0);
+            compute(0, 0);
             if (kt + 1 < nk) store_tiles((kt + 1) * BK, r1, 1);
+            compute(0, 1);
             __syncthreads();
             if (kt + 1 < nk) {
 #ifndef PQ_ABLATE_LOADS
                 if (kt + 3 < nk) load_tiles((kt + 3) * BK, r1);
 #endif
-                compute(1);
+                compute(1, 0);
                 if (kt + 2 < nk) store_tiles((kt + 2) * BK, r0, 0);
+                compute(1, 1);
                 __syncthreads();
             }
         }
@@ -255,8 +261,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #ifndef PQ_ABLATE_LOADS
             if (more) load_tiles((kt + 1) * BK, r0);
 #endif
-            compute(kt & 1);
+            compute(kt & 1, 0);
             if (more) store_tiles((kt + 1) * BK, r0, (kt + 1) & 1);
+            compute(kt & 1, 1);
             __syncthreads();
         }
     } else {
