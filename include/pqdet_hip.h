@@ -409,6 +409,9 @@ typedef struct pq_nms_args {
     int64_t scratch_bytes;
     int32_t N, C, cap;
     float score_thr, iou_thr;
+    int32_t cand_cap;    /* > 0: compact the (box, class) pairs above score_thr first and sort only cand_cap of them
+                            (ordered compaction, same tie order); *count = -1 if there were more -- call again with a
+                            larger value or 0.  0: sort all N*C pairs (any candidate count) */
 } pq_nms_args;
 int pq_nms(const pq_nms_args* a, void* stream);
 int64_t pq_nms_scratch_bytes(int32_t N, int32_t C);

@@ -166,7 +166,7 @@ class Recover(C.Structure):
 
 class Nms(C.Structure):
     _fields_ = [('bboxes', c_fp), ('dets', c_fp), ('count', c_fp), ('scratch', c_fp), ('scratch_bytes', i64),
-                ('N', i32), ('C', i32), ('cap', i32), ('score_thr', f32), ('iou_thr', f32)]
+                ('N', i32), ('C', i32), ('cap', i32), ('score_thr', f32), ('iou_thr', f32), ('cand_cap', i32)]
 
 
 class CreateLabel(C.Structure):

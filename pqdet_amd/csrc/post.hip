@@ -170,6 +170,81 @@ __global__ __launch_bounds__(256) void nms_mark_kernel(const float* bboxes, int 
     }
 }
 
+// ---- candidate compaction (cand_cap > 0): only the (box, class) pairs above the threshold enter the sorts.  Ordered: block b
+// owns entries [b*4096, (b+1)*4096), thread t 16 consecutive ones, so the compacted list is in ascending pair index like the
+// reference's nonzero() and the stable score sort breaks ties the same way as on the full list.
+constexpr int NMS_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void nms_fill_kernel(float* keys, unsigned* vals, int S) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) { keys[i] = -INFINITY; vals[i] = 0u; }
+}
+
+__global__ __launch_bounds__(256) void nms_count_kernel(const float* bboxes, int N, int C, float thr, unsigned* bcnt, NmsMeta* meta) {
+    __shared__ unsigned sc[4], sm[4];
+    const long E = (long)N * C;
+    const long base = (long)blockIdx.x * NMS_CHUNK + (long)threadIdx.x * 16;
+    unsigned cnt = 0, mx = 0;
+    for (int j = 0; j < 16; ++j) {
+        const long e = base + j;
+        if (e >= E) break;
+        const int i = (int)(e / C), c = (int)(e % C);
+        const float* row = bboxes + (size_t)i * (4 + C);
+        if (row[4 + c] > thr) {
+            ++cnt;
+            const unsigned o = f2ord(fmaxf(fmaxf(row[0], row[1]), fmaxf(row[2], row[3])));
+            mx = o > mx ? o : mx;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_xor(cnt, off);
+        const unsigned o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = cnt; sm[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bcnt[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+        const unsigned m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+        if (m) atomicMax(&meta->maxbits, m);
+    }
+}
+
+__global__ void nms_scan_kernel(unsigned* bcnt, int G, NmsMeta* meta, unsigned S) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned s = 0;
+        for (int b = 0; b < G; ++b) { const unsigned o = bcnt[b]; bcnt[b] = s; s += o; }
+        meta->pad = s > S ? 1u : 0u;              // more candidates than the caller's capacity: the result is discarded
+        meta->count = s > S ? S : s;
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_write_kernel(const float* bboxes, int N, int C, float thr, const unsigned* boff, float* keys,
+                                                         unsigned* vals, unsigned S) {
+    __shared__ unsigned pre[256];
+    const long E = (long)N * C;
+    const long base = (long)blockIdx.x * NMS_CHUNK + (long)threadIdx.x * 16;
+    unsigned cnt = 0;
+    for (int j = 0; j < 16; ++j) {
+        const long e = base + j;
+        if (e >= E) break;
+        if (bboxes[(size_t)(e / C) * (4 + C) + 4 + (e % C)] > thr) ++cnt;
+    }
+    pre[threadIdx.x] = cnt;
+    __syncthreads();
+    unsigned pos = boff[blockIdx.x];
+    for (int q = 0; q < (int)threadIdx.x; ++q) pos += pre[q];          // 256 short adds: this kernel is not on any hot path
+    if (cnt == 0) return;
+    for (int j = 0; j < 16; ++j) {
+        const long e = base + j;
+        if (e >= E) break;
+        const float sc = bboxes[(size_t)(e / C) * (4 + C) + 4 + (e % C)];
+        if (sc > thr) {
+            if (pos < S) { keys[pos] = sc; vals[pos] = (unsigned)e; }
+            ++pos;
+        }
+    }
+}
+
 // class key per rank (0xFFFF for non-candidates) + histogram
 __global__ __launch_bounds__(256) void nms_classkey_kernel(const unsigned* sorted_vals, long E, int C, const NmsMeta* meta,
                                                             unsigned* ckeys, unsigned* ranks, unsigned* hist) {
@@ -311,7 +386,7 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const float* bboxes, 
     }
     if (threadIdx.x == 0) {
         meta->kept = running;
-        *count = (int32_t)running;
+        *count = meta->pad ? -1 : (int32_t)running;          // -1: cand_cap was too small, call again with a larger one / 0
     }
 }
 
@@ -344,7 +419,7 @@ extern "C" int pq_create_label(const pq_create_label_args* a, void* stream) {
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct NmsLayout {
-    size_t keys0, keys1, vals0, vals1, ckeys0, ckeys1, rk0, rk1, keep, kept, hist, offs, meta, tmp, total;
+    size_t keys0, keys1, vals0, vals1, ckeys0, ckeys1, rk0, rk1, keep, kept, hist, offs, bcnt, meta, tmp, total;
 };
 static NmsLayout nms_layout(long E, int C) {
     NmsLayout L;
@@ -353,6 +428,7 @@ static NmsLayout nms_layout(long E, int C) {
     L.meta = take(sizeof(NmsMeta));
     L.hist = take((size_t)(C + 1) * 4);
     L.offs = take((size_t)(C + 2) * 4);
+    L.bcnt = take((size_t)((E + NMS_CHUNK - 1) / NMS_CHUNK + 2) * 4);
     L.keep = take((size_t)E * 4);
     L.keys0 = take((size_t)E * 4); L.keys1 = take((size_t)E * 4);
     L.vals0 = take((size_t)E * 4); L.vals1 = take((size_t)E * 4);
@@ -394,22 +470,36 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
 
     // zero meta + hist + offs + keep (contiguous prefix of the layout)
     if (hipMemsetAsync(base, 0, L.keys0, st) != hipSuccess) { pq_set_error("pq_nms: memset failed"); return PQ_ELAUNCH; }
-    long nb = (E + 255) / 256; if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(nms_mark_kernel, dim3((unsigned)nb), dim3(256), 0, st, a->bboxes, a->N, a->C, a->score_thr, keys0, vals0, meta);
-    PQ_CHECK_LAUNCH();
+    // S = how many entries go through the two sorts: everything, or the caller's candidate capacity after compaction
+    const long S = (a->cand_cap > 0 && a->cand_cap < E) ? a->cand_cap : E;
+    long nb = (S + 255) / 256; if (nb > 2048) nb = 2048;
+    if (S == E) {
+        long nbe = (E + 255) / 256; if (nbe > 2048) nbe = 2048;
+        hipLaunchKernelGGL(nms_mark_kernel, dim3((unsigned)nbe), dim3(256), 0, st, a->bboxes, a->N, a->C, a->score_thr, keys0, vals0, meta);
+        PQ_CHECK_LAUNCH();
+    } else {
+        unsigned* bcnt = (unsigned*)(base + L.bcnt);
+        const int G = (int)((E + NMS_CHUNK - 1) / NMS_CHUNK);
+        hipLaunchKernelGGL(nms_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, keys0, vals0, (int)S);
+        hipLaunchKernelGGL(nms_count_kernel, dim3(G), dim3(256), 0, st, a->bboxes, a->N, a->C, a->score_thr, bcnt, meta);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, bcnt, G, meta, (unsigned)S);
+        hipLaunchKernelGGL(nms_write_kernel, dim3(G), dim3(256), 0, st, a->bboxes, a->N, a->C, a->score_thr, (const unsigned*)bcnt, keys0, vals0,
+                           (unsigned)S);
+        PQ_CHECK_LAUNCH();
+    }
     size_t need = 0;
-    hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, need, keys0, keys1, vals0, vals1, (size_t)E, 0, 32, st);
+    hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, need, keys0, keys1, vals0, vals1, (size_t)S, 0, 32, st);
     if (e != hipSuccess || need > tmp_avail) { pq_set_error("pq_nms: sort scratch (%zu needed, %zu available)", need, tmp_avail); return PQ_EINVAL; }
-    e = rocprim::radix_sort_pairs_desc(tmp, need, keys0, keys1, vals0, vals1, (size_t)E, 0, 32, st);
+    e = rocprim::radix_sort_pairs_desc(tmp, need, keys0, keys1, vals0, vals1, (size_t)S, 0, 32, st);
     if (e != hipSuccess) { pq_set_error("pq_nms: radix sort failed: %s", hipGetErrorString(e)); return PQ_ELAUNCH; }
-    hipLaunchKernelGGL(nms_classkey_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const unsigned*)vals1, E, a->C, (const NmsMeta*)meta, ck0, rk0, hist);
+    hipLaunchKernelGGL(nms_classkey_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const unsigned*)vals1, S, a->C, (const NmsMeta*)meta, ck0, rk0, hist);
     PQ_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)hist, a->C, offs);
     PQ_CHECK_LAUNCH();
     size_t need2 = 0;
-    e = rocprim::radix_sort_pairs(nullptr, need2, ck0, ck1, rk0, rk1, (size_t)E, 0, 16, st);
+    e = rocprim::radix_sort_pairs(nullptr, need2, ck0, ck1, rk0, rk1, (size_t)S, 0, 16, st);
     if (e != hipSuccess || need2 > tmp_avail) { pq_set_error("pq_nms: class-sort scratch (%zu needed, %zu available)", need2, tmp_avail); return PQ_EINVAL; }
-    e = rocprim::radix_sort_pairs(tmp, need2, ck0, ck1, rk0, rk1, (size_t)E, 0, 16, st);
+    e = rocprim::radix_sort_pairs(tmp, need2, ck0, ck1, rk0, rk1, (size_t)S, 0, 16, st);
     if (e != hipSuccess) { pq_set_error("pq_nms: class sort failed: %s", hipGetErrorString(e)); return PQ_ELAUNCH; }
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(a->C), dim3(256), 0, st, a->bboxes, a->C, (const unsigned*)vals1, (const unsigned*)rk1,
                        (const unsigned*)offs, (const NmsMeta*)meta, a->iou_thr, kept, keep);

@@ -80,6 +80,12 @@ class Evaluator:
         cap = n * (w - 4)
         outs = [ops.nms(boxes[i], self._score_threshold, self._iou_threshold, cap=cap) for i in range(b)]
         counts = torch.cat([c for _, c in outs]).cpu().tolist()                     # the one synchronisation per batch
+        if any(k < 0 for k in counts):          # candidate capacity exceeded somewhere: redo those images over all pairs
+            ops.nms_grow(n, w - 4)
+            for i, k in enumerate(counts):
+                if k < 0:
+                    outs[i] = ops.nms(boxes[i], self._score_threshold, self._iou_threshold, cap=cap, cand_cap=0)
+                    counts[i] = int(outs[i][1].item())
         res = []
         for (dets, _), k in zip(outs, counts):
             res.append(dets[:k].cpu().numpy() if k else np.zeros((0,), dtype=np.float32))

@@ -171,13 +171,33 @@ def recover(pred: torch.Tensor, delta: torch.Tensor, ratio: torch.Tensor, orig: 
 _nms_scratch = {}
 
 
-def nms(bboxes: torch.Tensor, score_thr: float, iou_thr: float, cap: Optional[int] = None):
-    """-> (dets[cap,6], count int32[1]) on device; rows beyond count are undefined."""
+_nms_hint = {}     # (N, C) -> candidate capacity that was enough last time
+
+
+def nms_capacity(n: int, ncls: int) -> int:
+    """Candidate capacity for the compacting fast path of ``pq_nms`` (a trained detector passes 10^2..10^4 of the N*C pairs)."""
+    return _nms_hint.get((n, ncls), 8192)
+
+
+def nms_grow(n: int, ncls: int, seen: Optional[int] = None):
+    """Called after a ``count == -1`` (capacity exceeded) or with an observed candidate count: adapts the next capacity."""
+    cur = nms_capacity(n, ncls)
+    want = cur * 4 if seen is None else max(8192, 1 << (int(seen) * 2 - 1).bit_length())
+    _nms_hint[(n, ncls)] = min(max(want, 8192), n * ncls)
+
+
+def nms(bboxes: torch.Tensor, score_thr: float, iou_thr: float, cap: Optional[int] = None, cand_cap: Optional[int] = None):
+    """-> (dets[cap,6], count int32[1]) on device; rows beyond count are undefined.  ``cand_cap`` = number of (box, class)
+    pairs the sorts are sized for (None: adaptive, 0: all N*C); ``count == -1`` means it was too small (see tools.torch_nms)."""
     _need_cuda(bboxes)
     bboxes = bboxes.contiguous().float()
     n, w = bboxes.shape
     ncls = w - 4
     cap = cap or n * ncls
+    if cand_cap is None:
+        cand_cap = nms_capacity(n, ncls)
+    if cand_cap >= n * ncls:
+        cand_cap = 0
     l = lib()
     need = l.pq_nms_scratch_bytes(n, ncls)
     key = (bboxes.device, need)
@@ -188,7 +208,7 @@ def nms(bboxes: torch.Tensor, score_thr: float, iou_thr: float, cap: Optional[in
         _nms_scratch[key] = scratch
     dets = torch.empty(cap, 6, device=bboxes.device, dtype=torch.float32)
     count = torch.zeros(1, device=bboxes.device, dtype=torch.int32)
-    args = abi.Nms(ptr(bboxes), ptr(dets), ptr(count), ptr(scratch), need, n, ncls, cap, score_thr, iou_thr)
+    args = abi.Nms(ptr(bboxes), ptr(dets), ptr(count), ptr(scratch), need, n, ncls, cap, score_thr, iou_thr, cand_cap)
     check(l.pq_nms(C.byref(args), _stream()), 'pq_nms')
     return dets, count
 

@@ -68,6 +68,10 @@ def torch_nms(bboxes: torch.Tensor, score_threshold: float, iou_threshold: float
         return torch.tensor([]).to(bboxes)
     dets, count = ops.nms(bboxes, float(score_threshold), float(iou_threshold))
     k = int(count.item())
+    if k < 0:          # more candidates than the compacting fast path was sized for: sort all N*C pairs instead
+        ops.nms_grow(bboxes.shape[0], bboxes.shape[1] - 4)
+        dets, count = ops.nms(bboxes, float(score_threshold), float(iou_threshold), cand_cap=0)
+        k = int(count.item())
     if k == 0:
         return torch.tensor([]).to(bboxes)
     return dets[:k]

@@ -777,6 +777,25 @@ def test_nms_selection_bit_exact(n, ncls, seed):
     np.testing.assert_array_equal(got, want)
 
 
+def test_nms_candidate_compaction_paths_agree():
+    """Fast path (ordered compaction of the pairs above the threshold, sorts sized by cand_cap), its overflow signal and the
+    all-pairs path give the same detections, including score ties."""
+    from pqdet_amd import ops, tools
+    bb = _random_dets(3000, 20, 11, hot=0.05)
+    bb[100, 4:] = bb[101, 4:]                                  # equal scores across boxes: order by pair index
+    d = bb.to(DEV)
+    full, cf = ops.nms(d, 0.1, 0.45, cand_cap=0)
+    fast, cq = ops.nms(d, 0.1, 0.45, cand_cap=8192)
+    k = int(cf.item())
+    assert int(cq.item()) == k > 0 and torch.equal(full[:k], fast[:k])
+    tiny, ct = ops.nms(d, 0.1, 0.45, cand_cap=256)
+    assert int(ct.item()) == -1                                # fewer slots than candidates: flagged, never silently wrong
+    ops._nms_hint[(3000, 20)] = 256                            # torch_nms falls back to all pairs and raises the hint
+    got = tools.torch_nms(d, 0.1, 0.45)
+    assert torch.equal(got, full[:k]) and ops.nms_capacity(3000, 20) > 256
+    ops._nms_hint.pop((3000, 20))
+
+
 def test_nms_empty_and_ties():
     from oracle import postprocess as opost
     from pqdet_amd import tools
