@@ -156,6 +156,53 @@ __global__ __launch_bounds__(256) void qact_minmax_kernel(pq_qact_args a, float*
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = lo; partial[2 * blockIdx.x + 1] = hi; }
 }
 
+// float4 variants (C % 4 == 0, 16-byte aligned pitches): a thread owns 4 consecutive channels, no per-element division
+__global__ __launch_bounds__(256) void qact_minmax4_kernel(pq_qact_args a, float* partial) {
+    __shared__ float sh[64];
+    float lo = INFINITY, hi = -INFINITY;
+    const ActParam act = act_param(a.in.act);
+    const int C4 = a.C >> 2;
+    const long n4 = (long)a.rows * C4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const long r = e / C4;
+        const int c = (int)(e - r * C4) * 4;
+        const float4 x = ldg4(a.in.x + r * a.in.ld + c);
+        float u[4] = {x.x, x.y, x.z, x.w};
+        if (a.in.scale) {
+            const float4 sc = ldg4(a.in.scale + c), sf = ldg4(a.in.shift + c);
+            u[0] = fmaf(sc.x, u[0], sf.x); u[1] = fmaf(sc.y, u[1], sf.y); u[2] = fmaf(sc.z, u[2], sf.z); u[3] = fmaf(sc.w, u[3], sf.w);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float v = act_fwd(u[j], act); lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    }
+    block_minmax(lo, hi, sh);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = lo; partial[2 * blockIdx.x + 1] = hi; }
+}
+
+__global__ __launch_bounds__(256) void qact_apply4_kernel(pq_qact_args a) {
+    const float scale = a.state[2], zp = a.state[3], inv = 1.f / scale;
+    const ActParam act = act_param(a.in.act);
+    const int C4 = a.C >> 2;
+    const long n4 = (long)a.rows * C4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const long r = e / C4;
+        const int c = (int)(e - r * C4) * 4;
+        const float4 x = ldg4(a.in.x + r * a.in.ld + c);
+        float u[4] = {x.x, x.y, x.z, x.w};
+        if (a.in.scale) {
+            const float4 sc = ldg4(a.in.scale + c), sf = ldg4(a.in.shift + c);
+            u[0] = fmaf(sc.x, u[0], sf.x); u[1] = fmaf(sc.y, u[1], sf.y); u[2] = fmaf(sc.z, u[2], sf.z); u[3] = fmaf(sc.w, u[3], sf.w);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = act_fwd(u[j], act);
+            bool inside;
+            u[j] = a.quantise ? fq_value(v, scale, inv, zp, 0.f, 255.f, inside) : v;
+        }
+        stg4(a.out + r * a.ldo + c, make_float4(u[0], u[1], u[2], u[3]));
+    }
+}
+
 __global__ __launch_bounds__(256) void qact_observe_kernel(const float* partial, int n, float* state, float avg_const) {
     __shared__ float sh[64];
     float lo = INFINITY, hi = -INFINITY;
@@ -259,13 +306,17 @@ extern "C" int pq_qact_fwd(const pq_qact_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t elems = a->flat ? a->rows : a->rows * (int64_t)a->C;
     const int nb = pq_qact_blocks(elems);
+    const bool vec = !a->flat && (a->C & 3) == 0 && (a->in.ld & 3) == 0 && (a->ldo & 3) == 0 &&
+                     (((uintptr_t)a->in.x | (uintptr_t)a->out) & 15) == 0;
     if (a->observe) {
-        hipLaunchKernelGGL(qact_minmax_kernel, dim3(nb), dim3(256), 0, st, *a, a->partial);
+        if (vec) hipLaunchKernelGGL(qact_minmax4_kernel, dim3(nb), dim3(256), 0, st, *a, a->partial);
+        else hipLaunchKernelGGL(qact_minmax_kernel, dim3(nb), dim3(256), 0, st, *a, a->partial);
         PQ_CHECK_LAUNCH();
         hipLaunchKernelGGL(qact_observe_kernel, dim3(1), dim3(256), 0, st, (const float*)a->partial, nb, a->state, a->avg_const);
         PQ_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(qact_apply_kernel, dim3(nb), dim3(256), 0, st, *a);
+    if (vec) hipLaunchKernelGGL(qact_apply4_kernel, dim3(nb), dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL(qact_apply_kernel, dim3(nb), dim3(256), 0, st, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
