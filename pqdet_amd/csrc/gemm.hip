@@ -209,15 +209,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                     bf[j] = make_float4(bp[0], bp[LDBK], bp[2 * LDBK], bp[3 * LDBK]);
                 }
             }
+            // k-major order: consecutive MFMAs write different accumulators, so none waits for the previous one's result
+            {
+                float ak[TI][4], bk[TJ][4];
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i) { ak[i][0] = af[i].x; ak[i][1] = af[i].y; ak[i][2] = af[i].z; ak[i][3] = af[i].w; }
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    acc[i][j] = mfma32(af[i].x, bf[j].x, acc[i][j]);
-                    acc[i][j] = mfma32(af[i].y, bf[j].y, acc[i][j]);
-                    acc[i][j] = mfma32(af[i].z, bf[j].z, acc[i][j]);
-                    acc[i][j] = mfma32(af[i].w, bf[j].w, acc[i][j]);
-                }
+                for (int j = 0; j < TJ; ++j) { bk[j][0] = bf[j].x; bk[j][1] = bf[j].y; bk[j][2] = bf[j].z; bk[j][3] = bf[j].w; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(ak[i][q], bk[j][q], acc[i][j]);
+            }
         }
     };
 
@@ -261,8 +266,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #ifndef PQ_ABLATE_LOADS
             if (more) load_tiles((kt + 1) * BK, r0);
 #endif
+            // pinned phase order (the scheduler otherwise sinks the loads behind half of the MFMAs and the LDS writes behind all
+            // of them, which drains the MFMA pipe before every barrier): loads -> MFMA half -> LDS writes -> MFMA half -> barrier
+            __builtin_amdgcn_sched_barrier(0);
             compute(kt & 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (more) store_tiles((kt + 1) * BK, r0, (kt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
             compute(kt & 1, 1);
             __syncthreads();
         }
@@ -556,20 +566,25 @@ using namespace pq;
 //  * streaming tiles 128 x (32*TJ), TJ = ceil(N/32) <= 6, one block per 128 rows covering ALL N columns: the A tile is
 //    read once and the block writes one contiguous slab of the output -- used whenever that still fills the chip;
 //  * otherwise the best of 128x128 / 128x64 / 64x64 / 128x32 by padding waste and block count (double-buffered LDS).
-struct TileCand { int bm, bn; float bonus; };
-static const TileCand kTiles[4] = {{128, 128, 141.f}, {128, 64, 132.f}, {64, 64, 114.f}, {128, 32, 105.f}};
+struct TileCand { int bm, bn; int occ; float eff; };
+// occ = workgroups of that tile shape that fit on a CU together (registers / LDS), eff = relative efficiency of its inner loop
+static const TileCand kTiles[4] = {{128, 128, 2, 1.00f}, {128, 64, 2, 0.98f}, {64, 64, 3, 0.95f}, {128, 32, 4, 0.85f}};
 struct TilePick { int kind; int idx; int bm, bn; };     // kind 0: kTiles[idx]; kind 1: streaming with TJ = idx
 static TilePick pick_tile(int M, int N) {
     const int tj = (N + 31) / 32;
     if (tj <= 6 && (long)(M + 127) / 128 >= 384) return {1, tj, 128, 32 * tj};
-    // cost model: the busiest CU runs ceil(blocks / 256) tiles back to back (MFMA bound), each tile at the on-chip
-    // rate measured for its shape (scripts/probes/mfma_probe.hip: 141 / 132 / 114 / 105 TF/s)
+    // cost model: the chip holds 256*occ workgroups at once; co-resident workgroups share their CU, so one "wave" of
+    // workgroups costs occ * tile area, and a partially filled last wave costs as much as a full one.  Reproduces the
+    // measured ranking of the three big tiles on every mid / low resolution layer shape (PQ_GEMM_TILE=0..3 forces one).
     int best = 0;
     float best_cost = 3.4e38f;
+    static const char* force = getenv("PQ_GEMM_TILE");          // A/B timing only: force one of the four tile shapes
+    if (force && force[0] >= '0' && force[0] <= '3') { const int c = force[0] - '0'; return {0, c, kTiles[c].bm, kTiles[c].bn}; }
     for (int c = 0; c < 4; ++c) {
         const long gm = (M + kTiles[c].bm - 1) / kTiles[c].bm, gn = (N + kTiles[c].bn - 1) / kTiles[c].bn;
-        const long rounds = (gm * gn + 255) / 256;
-        const float cost = (float)rounds * kTiles[c].bm * kTiles[c].bn / kTiles[c].bonus;
+        const long slots = 256L * kTiles[c].occ;
+        const long rounds = (gm * gn + slots - 1) / slots;
+        const float cost = (float)rounds * kTiles[c].occ * kTiles[c].bm * kTiles[c].bn / kTiles[c].eff;
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
     return {0, best, kTiles[best].bm, kTiles[best].bn};
