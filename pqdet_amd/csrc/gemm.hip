@@ -226,6 +226,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         }
     };
 
+    // Scheduling hint for the region (MFMA half, LDS writes of the next tile, MFMA half): spread the VALU transform and the
+    // ds_write_b128 of the next tile between the MFMAs instead of one block in the middle -- with one or two waves per SIMD the
+    // matrix pipe otherwise idles while that block issues.
+    auto interleave = [&]() {
+#ifdef PQ_SCHED_GROUPS
+        constexpr int NW = AI + BI;                       // ds_write_b128 per thread per k-tile
+        constexpr int MF = TI * TJ * 4 * (BK / 8);        // MFMAs per wave per k-tile
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MF / NW, 0);     // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);          // VALU (operand transform, masks, addresses)
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);           // DS write
+        }
+#endif
+    };
+
     // AMODE 2 with y == NULL never reaches this kernel (host dispatches AMODE 0 instead).
     const int nk = (K + BK - 1) / BK;
     RegSet r0, r1;
@@ -245,6 +261,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             compute(0, 0);
             if (kt + 1 < nk) store_tiles((kt + 1) * BK, r1, 1);
             compute(0, 1);
+            interleave();
             __syncthreads();
             if (kt + 1 < nk) {
 #ifndef PQ_ABLATE_LOADS
@@ -253,6 +270,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                 compute(1, 0);
                 if (kt + 2 < nk) store_tiles((kt + 2) * BK, r0, 0);
                 compute(1, 1);
+                interleave();
                 __syncthreads();
             }
         }
