@@ -72,6 +72,8 @@ typedef struct pq_gsink {
     int32_t accumulate;
     int32_t finalize;
     int32_t ldp;
+    const float* qstate; /* QAT: T is consumed as fake_quant(act(...)) with this observer state {min,max,scale,zp}: finalize also
+                            applies the straight-through mask (0 where the value falls outside [0,255] steps).  NULL otherwise */
 } pq_gsink;
 
 /* ------------------------------------------------------------------ 1x1 convolution = fp32 MFMA GEMM

@@ -105,7 +105,8 @@ __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
 // ---- per-channel sink coefficients for 4 consecutive channels ------------------------------------------------
 struct SinkCoef4 {
     float a[4], b[4], mean[4], inv[4];
-    bool affine, stats;
+    bool affine, stats, q;
+    float qinv, qzp;          // QAT: 1/scale and zero point of the tensor's activation observer
     ActParam act;
 };
 __device__ __forceinline__ SinkCoef4 sink_coef4(const pq_gsink& s, int c0, int C) {
@@ -113,6 +114,9 @@ __device__ __forceinline__ SinkCoef4 sink_coef4(const pq_gsink& s, int c0, int C
     k.affine = s.scale != nullptr;
     k.stats = s.mean != nullptr && s.partial != nullptr;
     k.act = act_param(s.act);
+    k.q = s.qstate != nullptr;
+    k.qinv = k.q ? 1.f / s.qstate[2] : 0.f;
+    k.qzp = k.q ? s.qstate[3] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int c = c0 + j;
@@ -129,7 +133,7 @@ __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k
                                            float4& s1, float4& s2) {
     float* gp = s.g + row * (size_t)s.ldg + c0;
     if (s.accumulate) dz = f4add(dz, ldg4(gp));
-    if (s.finalize && (k.act.code != PQ_ACT_LINEAR || k.stats)) {
+    if (s.finalize && (k.act.code != PQ_ACT_LINEAR || k.stats || k.q)) {
         float4 y4 = ldg4(s.y + row * (size_t)s.ldy + c0);
         float d[4] = {dz.x, dz.y, dz.z, dz.w}, y[4] = {y4.x, y4.y, y4.z, y4.w};
         float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t2[4] = {s2.x, s2.y, s2.z, s2.w};
@@ -137,6 +141,10 @@ __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k
         for (int j = 0; j < 4; ++j) {
             float u = k.affine ? fmaf(k.a[j], y[j], k.b[j]) : y[j];
             float g = d[j] * act_bwd(u, k.act);
+            if (k.q) {            // straight-through estimator of the activation fake-quantiser (same arithmetic as qat.hip)
+                const float qv = rintf(act_fwd(u, k.act) * k.qinv) + k.qzp;
+                g = (qv >= 0.f && qv <= 255.f) ? g : 0.f;
+            }
             d[j] = g;
             if (k.stats) {
                 t1[j] += g;

@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
         const pq_gsink& sk = p.sink;
         const bool affine = sk.scale != nullptr;
         const bool stats = sk.mean != nullptr && sk.partial != nullptr;
-        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
+        const bool qmask = sk.finalize && sk.qstate != nullptr;
+        const float qinv = qmask ? 1.f / sk.qstate[2] : 0.f, qzp = qmask ? sk.qstate[3] : 0.f;
+        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats || qmask);
         want_stats = sk.finalize && stats;
         const ActParam sact = act_param(sk.act);
         const float ca = affine ? sk.scale[ch] : 1.f, cb = affine ? sk.shift[ch] : 0.f;
@@ -185,7 +187,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
             const int q = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
             float dz = acc[r] + gv[r];
-            if (need_y) dz *= act_bwd(fmaf(ca, yv[r], cb), sact);
+            if (need_y) {
+                const float uu = fmaf(ca, yv[r], cb);
+                dz *= act_bwd(uu, sact);
+                if (qmask) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz = (qv >= 0.f && qv <= 255.f) ? dz : 0.f; }
+            }
             if (nok && oy < p.OH && ox < p.OW) {
                 sk.g[(((size_t)b * p.OH + oy) * p.OW + ox) * sk.ldg + ch] = dz;
                 if (stats) { s1 += dz; s2 = fmaf(dz, (yv[r] - cm) * ci, s2); }

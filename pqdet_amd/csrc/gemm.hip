@@ -325,7 +325,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         const bool affine = sk.scale != nullptr;
         const bool stats = sk.mean != nullptr && sk.partial != nullptr;
         const ActParam sact = act_param(sk.act);
-        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
+        const bool qmask = sk.finalize && sk.qstate != nullptr;        // QAT: straight-through mask of the activation quantiser
+        const float qinv = qmask ? 1.f / sk.qstate[2] : 0.f, qzp = qmask ? sk.qstate[3] : 0.f;
+        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats || qmask);
         want_stats = sk.finalize && stats;
         // Row-major sink through LDS (same patch trick as the forward store): every lane then handles 4 consecutive columns of
         // 4 rows, so the forward values y, the accumulated gradient and the result move as 16-byte accesses; the per-column
@@ -369,7 +371,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                         const float yy[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w};
                         if (need_y) {
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) dz[u] *= act_bwd(fmaf(ca[u], yy[u], cb[u]), sact);
+                            for (int u = 0; u < 4; ++u) {
+                                const float uu = fmaf(ca[u], yy[u], cb[u]);
+                                dz[u] *= act_bwd(uu, sact);
+                                if (qmask) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz[u] = (qv >= 0.f && qv <= 255.f) ? dz[u] : 0.f; }
+                            }
                         }
                         if (m < M && nok) {
                             stg4(sk.g + (size_t)m * sk.ldg + nn, make_float4(dz[0], dz[1], dz[2], dz[3]));
@@ -423,6 +429,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                     if (need_y) {
                         const float u = fmaf(ca, yv[r], cb);
                         dz *= act_bwd(u, sact);
+                        if (qmask) { const float qv = rintf(act_fwd(u, sact) * qinv) + qzp; dz = (qv >= 0.f && qv <= 255.f) ? dz : 0.f; }
                     }
                     if (m < M && nok) {
                         sk.g[srow[r] * sk.ldg + n] = dz;

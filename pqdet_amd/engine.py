@@ -14,6 +14,7 @@ MI355X-first design notes (see DESIGN.md for the long form)
 * the step never synchronises with the host: loss scalars stay on the device, the NaN trap is polled one step late.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -200,6 +201,27 @@ class Plan:
         return len(lst) - 1
 
     def _sink(self, t: TensorRef, nblk: int) -> abi.GSink:
+        inner = getattr(t, 'fuse_inner', None)
+        if inner is not None:
+            # QAT, conv output consumed only through gradient sinks: the consumers write straight into the producer's
+            # gradient; the last one applies act' x the quantiser's straight-through mask and emits the BN-backward sums
+            if inner.grad is None:
+                inner.grad = self._new(inner.rows, inner.ld, fill=0.0) if inner.ld != inner.C else self._new(inner.rows, inner.ld)
+                t.grad = inner.grad
+            accumulate = t.received > 0
+            finalize = (t.received + 1 == t.n_consumers)
+            t.received += 1
+            bn = inner.bn
+            stats = finalize and bn is not None
+            if stats:
+                bn.bwd_nblk = nblk
+                bn.bwd_partial = self._new(nblk * 2 * bn.ldp)
+            if finalize:
+                inner.received = inner.n_consumers
+            return abi.GSink(ptr(inner.grad), ptr(inner.raw), ptr(bn.scale) if bn else None, ptr(bn.shift) if bn else None,
+                             ptr(bn.mean) if stats else None, ptr(bn.invstd) if stats else None,
+                             ptr(bn.bwd_partial) if stats else None, inner.ld, inner.ld, inner.act, int(accumulate),
+                             int(finalize), bn.ldp if bn else 0, self._qstate(t.fuse_key) if self.q_quant else None)
         if t.grad is None:
             t.grad = self._new(t.rows, t.ld, fill=0.0) if t.ld != t.C else self._new(t.rows, t.ld)
         accumulate = t.received > 0
@@ -425,6 +447,13 @@ class Plan:
                 T.append(a)
         for i_, n_ in consumers.items():
             T[i_].n_consumers = n_
+        if self.qat and train_graph:
+            head_inputs = {id(a) for _, _, a in heads}
+            for i_, inner in self._inner.items():
+                qout = T[i_]
+                if mods[i_]._type == 'convolutional' and id(qout) not in head_inputs and qout.act == 0 \
+                        and inner.C % 4 == 0 and os.environ.get('PQ_QAT_FUSE', '1') != '0':
+                    qout.fuse_inner, qout.fuse_key = inner, ('a', i_)
 
         coef.commit()
         self.keep.append(coef.buf)
@@ -632,8 +661,9 @@ class Plan:
                 else:
                     if self.qat:                    # through the activation observer: out <- the un-quantised producer tensor
                         inner = self._inner[i]
-                        self._qact_bwd(out, inner, ('a', i))
-                        out = inner
+                        if getattr(out, 'fuse_inner', None) is None:
+                            self._qact_bwd(out, inner, ('a', i))
+                        out = inner                 # (fused: the consumers' sinks already finalised inner.grad)
                     if out.bn is not None:
                         if out.bn.bwd_partial is None:
                             raise RuntimeError('internal: BN layer %d never finalised its gradient' % i)

@@ -95,6 +95,48 @@ def test_qact_forward_backward_match_oracle_exactly(rows, Cc, act):
     assert (d > 1e-6).float().mean().item() < 2e-3          # identical except where u sits on a rounding / ReLU boundary
 
 
+def test_gradient_sinks_apply_the_straight_through_mask():
+    """Fused backward: a consumer's sink with qstate set finalises g = dz * act'(u) * [fq(act(u)) inside the range], both in the
+    element-wise sinks (pq_route_bwd) and in the GEMM's row-major sink epilogue (pq_conv1x1_dgrad)."""
+    g = torch.Generator().manual_seed(21)
+    l = abi.lib()
+    rows, Cc = 512, 64
+    y = torch.randn(rows, Cc, generator=g) * 2
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    # observer state with a range that clips the top of the distribution
+    state = torch.tensor([0.0, 2.0, 2.0 / 255, 0.0])
+    u = (y * sc + sh).requires_grad_(True)
+    v = torch.relu(u)
+    q = oqat._FakeQuantSTE.apply(v, float(state[2]), int(state[3]), 0, 255)
+    up = torch.randn(rows, Cc, generator=g)
+    q.backward(up)
+    want = u.grad
+    assert (want == 0).float().mean() > 0.3 and ((v > 2.01) & (up != 0)).any()       # both ReLU and range clipping occur
+    yd, upd, st = y.to(DEV), up.to(DEV), state.to(DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    gout = torch.full((rows, Cc), float('nan'), device=DEV)
+    sink = abi.GSink(gout.data_ptr(), yd.data_ptr(), scd.data_ptr(), shd.data_ptr(), None, None, None, Cc, Cc, 1, 0, 1, 0, st.data_ptr())
+    r = abi.RouteBwd(upd.data_ptr(), sink, 1, rows, 1, Cc, Cc, 0, 1, None, 0, 0, 1.0)
+    abi.check(l.pq_route_bwd(C.byref(r), _stream()))
+    torch.cuda.synchronize()
+    d = (gout.cpu() - want).abs()
+    assert (d > 1e-6).float().mean().item() < 2e-3
+    # GEMM sink: dz = dy @ w (identity-like weights so that dz == dy), same finalisation
+    O_ = Cc
+    w = torch.eye(O_, Cc)
+    gout2 = torch.full((rows, Cc), float('nan'), device=DEV)
+    a = abi.Conv1x1Dgrad()
+    a.dy = abi.GSrc(upd.data_ptr(), None, None, None, None, None, O_, O_)
+    wd = w.to(DEV)
+    a.w = wd.data_ptr()
+    a.dx = abi.GSink(gout2.data_ptr(), yd.data_ptr(), scd.data_ptr(), shd.data_ptr(), None, None, None, Cc, Cc, 1, 0, 1, 0, st.data_ptr())
+    a.M, a.I, a.O = rows, Cc, O_
+    abi.check(l.pq_conv1x1_dgrad(C.byref(a), _stream()))
+    torch.cuda.synchronize()
+    d2 = (gout2.cpu() - want).abs()
+    assert (d2 > 1e-5).float().mean().item() < 2e-3
+
+
 def test_weight_prep_and_weight_grad_match_oracle():
     g = torch.Generator().manual_seed(9)
     l = abi.lib()
