@@ -33,13 +33,15 @@ enum { PQ_ACT_LINEAR = 0, PQ_ACT_RELU = 1, PQ_ACT_RELU6 = 2, PQ_ACT_LEAKY = 3, P
 /* box loss kinds -- reference model/loss.py:62-81 */
 enum { PQ_BOX_L1 = 0, PQ_BOX_GIOU = 1, PQ_BOX_DIOU = 2, PQ_BOX_CIOU = 3, PQ_BOX_IOU = 4 };
 
-/* forward-value operand:  v[row][c] = act(scale[c] * x[row*ld + c] + shift[c]);  scale==NULL => identity affine */
+/* forward-value operand:  v[row][c] = act(scale[c] * x[row*ld + c] + shift[c]);  scale==NULL => identity affine;
+ * with qstate the value is then fake-quantised (quint8 [0,255], per tensor): (clamp(rint(v/s)+zp) - zp) * s */
 typedef struct pq_src {
     const float* x;
     const float* scale;
     const float* shift;
     int32_t ld;
     int32_t act;
+    const float* qstate; /* QAT: the consumer sees fake_quant(v) with this activation observer {min,max,scale,zp}; NULL otherwise */
 } pq_src;
 
 /* gradient operand: v[row][c] = p[c]*g[row*ldg+c] + q[c]*(y[row*ldy+c] - mu[c]) + r[c];  y==NULL => v = g */
@@ -446,7 +448,7 @@ int pq_qat_weight_grad(const pq_qat_weight_args* a, void* stream);   /* backward
 /* out[r][c] = fq(act(scale[c]*x[r][c] + shift[c])) with the observer of `state` updated first (observe != 0) */
 typedef struct pq_qact_args {
     pq_src in;
-    float* out;              /* [rows][ldo] (flat: [rows]) */
+    float* out;              /* [rows][ldo] (flat: [rows]); NULL: only update the observer (consumers quantise on load) */
     float* state;
     float* partial;          /* >= 2 * pq_qact_blocks(elements) floats */
     int64_t rows;

@@ -22,7 +22,7 @@ BOX_KIND = {'l1': BOX_L1, 'giou': BOX_GIOU, 'diou': BOX_DIOU, 'ciou': BOX_CIOU, 
 
 
 class Src(C.Structure):
-    _fields_ = [('x', c_fp), ('scale', c_fp), ('shift', c_fp), ('ld', i32), ('act', i32)]
+    _fields_ = [('x', c_fp), ('scale', c_fp), ('shift', c_fp), ('ld', i32), ('act', i32), ('qstate', c_fp)]
 
 
 class GSrc(C.Structure):

@@ -46,12 +46,21 @@ inline bool act_is_special(int act) { return act == PQ_ACT_LOGISTIC || act == PQ
 struct SrcCoef4 {
     float a[4], b[4];
     ActParam act;
-    bool affine;
+    bool affine, q;
+    float qs, qinv, qzp;      // QAT activation quantiser of the tensor: scale, 1/scale, zero point
 };
+// the activation fake-quantiser (quint8 [0, 255]); same expression order as qat.hip's fq_value
+__device__ __forceinline__ float fq_act(float v, float qs, float qinv, float qzp) {
+    return (fminf(fmaxf(rintf(v * qinv) + qzp, 0.f), 255.f) - qzp) * qs;
+}
 __device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C) {
     SrcCoef4 k;
     k.act = act_param(s.act);
     k.affine = s.scale != nullptr;
+    k.q = s.qstate != nullptr;
+    k.qs = k.q ? s.qstate[2] : 1.f;
+    k.qinv = k.q ? 1.f / k.qs : 1.f;
+    k.qzp = k.q ? s.qstate[3] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int c = c0 + j;
@@ -65,6 +74,10 @@ __device__ __forceinline__ float4 src_apply4(float4 v, const SrcCoef4& k) {
     float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = act_fwd(fmaf(k.a[j], r[j], k.b[j]), k.act);     // (a, b) default to (1, 0)
+    if (k.q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = fq_act(r[j], k.qs, k.qinv, k.qzp);
+    }
     return make_float4(r[0], r[1], r[2], r[3]);
 }
 
@@ -137,14 +150,18 @@ __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k
         float4 y4 = ldg4(s.y + row * (size_t)s.ldy + c0);
         float d[4] = {dz.x, dz.y, dz.z, dz.w}, y[4] = {y4.x, y4.y, y4.z, y4.w};
         float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t2[4] = {s2.x, s2.y, s2.z, s2.w};
+        if (k.q) {                // QAT only: straight-through mask of the activation fake-quantiser (arithmetic of qat.hip)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = k.affine ? fmaf(k.a[j], y[j], k.b[j]) : y[j];
+                const float qv = rintf(act_fwd(u, k.act) * k.qinv) + k.qzp;
+                d[j] = (qv >= 0.f && qv <= 255.f) ? d[j] : 0.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float u = k.affine ? fmaf(k.a[j], y[j], k.b[j]) : y[j];
             float g = d[j] * act_bwd(u, k.act);
-            if (k.q) {            // straight-through estimator of the activation fake-quantiser (same arithmetic as qat.hip)
-                const float qv = rintf(act_fwd(u, k.act) * k.qinv) + k.qzp;
-                g = (qv >= 0.f && qv <= 255.f) ? g : 0.f;
-            }
             d[j] = g;
             if (k.stats) {
                 t1[j] += g;

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
                 for (int j = 0; j < 4; ++j) {
                     const float sc = p.in.scale ? p.in.scale[c + j] : 1.f, sh = p.in.scale ? p.in.shift[c + j] : 0.f;
                     e4[j] = act_fwd(fmaf(sc, e4[j], sh), aact);
+                    if (p.in.qstate) e4[j] = fq_act(e4[j], p.in.qstate[2], 1.f / p.in.qstate[2], p.in.qstate[3]);
                 }
                 v = make_float4(e4[0], e4[1], e4[2], e4[3]);
             }
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GcWP p) {
                 for (int j = 0; j < 4; ++j) {
                     const float sc = p.in.scale ? p.in.scale[c + j] : 1.f, sh = p.in.scale ? p.in.shift[c + j] : 0.f;
                     e4[j] = act_fwd(fmaf(sc, e4[j], sh), aact);
+                    if (p.in.qstate) e4[j] = fq_act(e4[j], p.in.qstate[2], 1.f / p.in.qstate[2], p.in.qstate[3]);
                 }
                 v = make_float4(e4[0], e4[1], e4[2], e4[3]);
             }

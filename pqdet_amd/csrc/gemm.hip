@@ -20,6 +20,7 @@ struct GemmP {
     // A operand
     const float* a0; const float* a1;          // x | g , y
     const float* c0; const float* c1; const float* c2; const float* c3;   // scale,shift | p,q,mu,r
+    const float* qstate;                       // AMODE 1, QAT: fake-quantise the transformed operand
     int lda0, lda1, act;
     int sub, OH, OW, IH, IW;                    // strided 1x1 conv: forward gathers A rows, the sink epilogue scatters rows
     // B operand
@@ -57,6 +58,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     const int m0 = bmy * BM, n0 = bnx * BN;
     const int M = p.M, N = p.N, K = p.K;
     const ActParam aact = act_param(p.act);
+    const bool aq = AMODE == 1 && p.qstate != nullptr;          // uniform
+    const float aqs = aq ? p.qstate[2] : 1.f, aqinv = aq ? 1.f / aqs : 1.f, aqzp = aq ? p.qstate[3] : 0.f;
 
     // ---- A load plan
     const int ac4 = t & 7, ar0 = t >> 3;
@@ -145,6 +148,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                 for (int j = 0; j < 4; ++j) {
                     const float u = fmaf(c0[j], v[j], c1[j]);
                     v[j] = fminf(fmaf(aact.slope, fminf(u, 0.f), fmaxf(u, 0.f)), aact.hi);
+                }
+                if (aq) {        // QAT only: one uniform branch per quad, nothing on the float path
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fq_act(v[j], aqs, aqinv, aqzp);
                 }
             } else if (AMODE == 2) {
                 const float y[4] = {r.a1[i].x, r.a1[i].y, r.a1[i].z, r.a1[i].w};
@@ -371,10 +378,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                         const float yy[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w};
                         if (need_y) {
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const float uu = fmaf(ca[u], yy[u], cb[u]);
-                                dz[u] *= act_bwd(uu, sact);
-                                if (qmask) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz[u] = (qv >= 0.f && qv <= 255.f) ? dz[u] : 0.f; }
+                            for (int u = 0; u < 4; ++u) dz[u] *= act_bwd(fmaf(ca[u], yy[u], cb[u]), sact);
+                            if (qmask) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const float qv = rintf(act_fwd(fmaf(ca[u], yy[u], cb[u]), sact) * qinv) + qzp;
+                                    dz[u] = (qv >= 0.f && qv <= 255.f) ? dz[u] : 0.f;
+                                }
                             }
                         }
                         if (m < M && nok) {
@@ -742,12 +752,12 @@ extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a->sub >= 1, "sub must be >= 1");
     if (act_is_special(a->in.act)) { pq_set_error("pq_conv1x1_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     GemmP p{};
-    p.a0 = a->in.x; p.lda0 = a->in.ld; p.c0 = a->in.scale; p.c1 = a->in.shift; p.act = a->in.act;
+    p.a0 = a->in.x; p.lda0 = a->in.ld; p.c0 = a->in.scale; p.c1 = a->in.shift; p.act = a->in.act; p.qstate = a->in.qstate;
     p.sub = a->sub; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->O; p.K = a->I;
     p.out = a->out; p.bias = a->bias; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     hipStream_t st = (hipStream_t)stream;
-    const bool xform = a->in.scale != nullptr || a->in.act != PQ_ACT_LINEAR;
+    const bool xform = a->in.scale != nullptr || a->in.act != PQ_ACT_LINEAR || a->in.qstate != nullptr;
     if (xform) {
         if (a->partial) launch_nt<1, false, 1>(p, st); else launch_nt<1, false, 0>(p, st);
     } else {

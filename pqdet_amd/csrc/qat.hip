@@ -300,13 +300,14 @@ extern "C" int32_t pq_qact_blocks(int64_t elems) {
 }
 
 extern "C" int pq_qact_fwd(const pq_qact_args* a, void* stream) {
-    PQ_CHECK_ARG(a && a->in.x && a->out && a->state && a->partial, "null pointer");
+    PQ_CHECK_ARG(a && a->in.x && a->state && a->partial, "null pointer");
+    PQ_CHECK_ARG(a->out || a->observe, "nothing to do: no output and no observer update");
     PQ_CHECK_ARG(a->rows > 0 && (a->flat || a->C > 0), "empty");
     if (act_is_special(a->in.act)) { pq_set_error("pq_qact_fwd: logistic/tanh are not part of the QAT model (every activation is ReLU)"); return PQ_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     const int64_t elems = a->flat ? a->rows : a->rows * (int64_t)a->C;
     const int nb = pq_qact_blocks(elems);
-    const bool vec = !a->flat && (a->C & 3) == 0 && (a->in.ld & 3) == 0 && (a->ldo & 3) == 0 &&
+    const bool vec = !a->flat && (a->C & 3) == 0 && (a->in.ld & 3) == 0 && (!a->out || (a->ldo & 3) == 0) &&
                      (((uintptr_t)a->in.x | (uintptr_t)a->out) & 15) == 0;
     if (a->observe) {
         if (vec) hipLaunchKernelGGL(qact_minmax4_kernel, dim3(nb), dim3(256), 0, st, *a, a->partial);
@@ -315,6 +316,7 @@ extern "C" int pq_qact_fwd(const pq_qact_args* a, void* stream) {
         hipLaunchKernelGGL(qact_observe_kernel, dim3(1), dim3(256), 0, st, (const float*)a->partial, nb, a->state, a->avg_const);
         PQ_CHECK_LAUNCH();
     }
+    if (!a->out) return PQ_OK;                 // observer only: the consumers fake-quantise while loading (pq_src.qstate)
     if (vec) hipLaunchKernelGGL(qact_apply4_kernel, dim3(nb), dim3(256), 0, st, *a);
     else hipLaunchKernelGGL(qact_apply_kernel, dim3(nb), dim3(256), 0, st, *a);
     PQ_CHECK_LAUNCH();

@@ -117,6 +117,11 @@ class TensorRef:
         return self.B * self.H * self.W
 
     def src(self) -> abi.Src:
+        fused = getattr(self, 'fuse_inner', None)
+        if fused is not None:          # QAT: read the producer's raw tensor, fake-quantise while loading
+            s = fused.src()
+            s.qstate = self.fuse_qptr
+            return s
         if self.bn is not None:
             return abi.Src(ptr(self.raw), ptr(self.bn.scale), ptr(self.bn.shift), self.ld, self.act)
         return abi.Src(ptr(self.raw), None, None, self.ld, self.act)
@@ -447,13 +452,16 @@ class Plan:
                 T.append(a)
         for i_, n_ in consumers.items():
             T[i_].n_consumers = n_
-        if self.qat and train_graph:
+        if self.qat:
+            # conv outputs that only feed other layers are never materialised in quantised form: consumers fake-quantise while
+            # loading (pq_src.qstate) and their gradient sinks apply the straight-through mask (pq_gsink.qstate)
             head_inputs = {id(a) for _, _, a in heads}
             for i_, inner in self._inner.items():
                 qout = T[i_]
                 if mods[i_]._type == 'convolutional' and id(qout) not in head_inputs and qout.act == 0 \
                         and inner.C % 4 == 0 and os.environ.get('PQ_QAT_FUSE', '1') != '0':
                     qout.fuse_inner, qout.fuse_key = inner, ('a', i_)
+                    qout.fuse_qptr = self._qstate(('a', i_)) if self.q_quant else None
 
         coef.commit()
         self.keep.append(coef.buf)
@@ -481,7 +489,11 @@ class Plan:
                 self.patch_x.append(('fwd', idx, 'qa'))
             elif kind == 'qact':
                 _, i, inner, qout = item
-                self._qact_fwd(inner.src(), qout.raw, inner.rows, inner.C, qout.ld, ('a', i))
+                if getattr(qout, 'fuse_inner', None) is not None:
+                    if self.q_observe:                     # observer only; nobody reads a materialised copy
+                        self._qact_fwd(inner.src(), None, inner.rows, inner.C, qout.ld, ('a', i))
+                else:
+                    self._qact_fwd(inner.src(), qout.raw, inner.rows, inner.C, qout.ld, ('a', i))
             elif kind == 'stem_fwd':
                 _, i, out, nblk = item
                 conv = mods[i].conv
