@@ -37,6 +37,7 @@ KERNEL_CLASS = {
     abi.OP_CONV1X1_FWD: ('conv1x1_fwd (gemm_nt, fp32 MFMA)', 'mfma'),
     abi.OP_CONV1X1_DGRAD: ('conv1x1_dgrad (gemm_nt, fp32 MFMA)', 'mfma'),
     abi.OP_CONV1X1_WGRAD: ('conv1x1_wgrad (gemm_tn, fp32 MFMA)', 'mfma'),
+    abi.OP_CONV1X1_BWD: ('conv1x1_bwd narrow layers (fused dgrad+wgrad, one pass over dy)', 'hbm'),
     abi.OP_DW_FWD: ('dw3x3_fwd', 'hbm'), abi.OP_DW_DGRAD: ('dw3x3_dgrad', 'hbm'), abi.OP_DW_WGRAD: ('dw3x3_wgrad', 'hbm'),
     abi.OP_DW_BWD: ('dw3x3_bwd (fused dgrad+wgrad, LDS tiles)', 'hbm'),
     abi.OP_GCONV_FWD: ('gconv3x3_fwd (implicit GEMM, fp32 MFMA)', 'mfma'),
@@ -61,6 +62,9 @@ def op_work(op):
     if c in (abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_WGRAD):
         a = op.u.c1d if c == abi.OP_CONV1X1_DGRAD else op.u.c1w
         return 2.0 * a.M * a.I * a.O, 4.0 * (a.M * a.I + a.M * a.O + a.I * a.O)
+    if c == abi.OP_CONV1X1_BWD:      # both GEMMs; dy and the layer input are counted once each, plus the input gradient
+        a = op.u.c1b
+        return 2.0 * 2.0 * a.M * a.I * a.O, 4.0 * (2 * a.M * a.I + a.M * a.O + 2 * a.I * a.O)
     if c in (abi.OP_DW_FWD, abi.OP_DW_DGRAD, abi.OP_DW_WGRAD):
         a = {abi.OP_DW_FWD: op.u.dwf, abi.OP_DW_DGRAD: op.u.dwd, abi.OP_DW_WGRAD: op.u.dww}[c]
         n_in, n_out = a.B * a.IH * a.IW * a.C, a.B * a.OH * a.OW * a.C
@@ -121,7 +125,8 @@ def profile_kernels(plan, x, tgt, side=None, passes=3):
 PMC_PATTERN = {
     'conv1x1_dgrad (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, 2, ', None),
     'conv1x1_fwd (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], ', None),
-    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<', r'slab_reduce_kernel'),
+    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<', r'pq::slab_reduce_kernel'),
+    'conv1x1_bwd narrow layers (fused dgrad+wgrad, one pass over dy)': (r'pw_bwd_kernel<', r'pw_slab_reduce_kernel'),
 }
 
 

@@ -120,6 +120,26 @@ typedef struct pq_conv1x1_wgrad_args {
     int32_t sub, OH, OW, IH, IW;   /* sub>1: in' rows are gathered at (b,oy*sub,ox*sub) as in the forward */
 } pq_conv1x1_wgrad_args;
 int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream);
+
+/* Fused backward of a NARROW 1x1 convolution (min(I,O) <= 32, max <= 192, many rows): dgrad + wgrad of the two entries
+ * above from ONE pass over dy' (both GEMMs are HBM-bound there and dy' is the widest operand).  Same operand meaning as
+ * pq_conv1x1_dgrad (dy, w, dx) and pq_conv1x1_wgrad (in, dw); stride 1 only, no bias gradient.
+ * pq_conv1x1_bwd_blocks(M,I,O): number of workgroups = partial-sum rows the sink emits; 0 => shape outside the fused
+ * kernel's range (use the two separate entries; pq_conv1x1_bwd then returns PQ_EUNSUPPORTED).
+ * pq_conv1x1_bwd_pays(M,I,O): 1 when the fused kernel is supported AND faster on a whole step than the two entries. */
+typedef struct pq_conv1x1_bwd_args {
+    pq_gsrc dy;
+    const float* w;      /* [O][I] */
+    pq_src in;
+    pq_gsink dx;
+    float* dw;           /* [O][I] */
+    float* scratch;      /* >= pq_conv1x1_bwd_scratch_bytes(M,I,O) */
+    int32_t M, I, O;
+} pq_conv1x1_bwd_args;
+int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream);
+int32_t pq_conv1x1_bwd_blocks(int32_t M, int32_t I, int32_t O);
+int32_t pq_conv1x1_bwd_pays(int32_t M, int32_t I, int32_t O);
+int64_t pq_conv1x1_bwd_scratch_bytes(int32_t M, int32_t I, int32_t O);
 int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t O);
 
 /* ------------------------------------------------------------------ depthwise 3x3 (groups == channels), pad 1
@@ -487,7 +507,7 @@ enum {
     PQ_OP_STEM_FWD, PQ_OP_STEM_WGRAD, PQ_OP_BN_FWD_FIN, PQ_OP_BN_BWD_FIN, PQ_OP_COPY_FWD, PQ_OP_ROUTE_BWD,
     PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD,
     PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD, PQ_OP_TRANSPOSE,
-    PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE
+    PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE, PQ_OP_CONV1X1_BWD
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -502,7 +522,7 @@ typedef struct pq_op {
         pq_bn_fwd_finalize_args bnf; pq_bn_bwd_finalize_args bnb;
         pq_copy_args cp; pq_route_bwd_args rb;
         pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill; pq_transpose_args tr;
-        pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr;
+        pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr; pq_conv1x1_bwd_args c1b;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);

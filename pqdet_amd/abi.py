@@ -52,6 +52,11 @@ class Conv1x1Wgrad(C.Structure):
                 ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32)]
 
 
+class Conv1x1Bwd(C.Structure):
+    _fields_ = [('dy', GSrc), ('w', c_fp), ('inp', Src), ('dx', GSink), ('dw', c_fp), ('scratch', c_fp),
+                ('M', i32), ('I', i32), ('O', i32)]
+
+
 class GconvFwd(C.Structure):
     _fields_ = [('inp', Src), ('w', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('gw', i32), ('stride', i32),
@@ -211,7 +216,7 @@ class _OpU(C.Union):
                 ('bnf', BnFwdFin), ('bnb', BnBwdFin), ('cp', Copy), ('rb', RouteBwd),
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
                 ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose),
-                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce)]
+                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce), ('c1b', Conv1x1Bwd)]
 
 
 OPF_SIDE = 1
@@ -224,7 +229,7 @@ class Op(C.Structure):
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
  OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE, OP_QAT_WPREP, OP_QAT_WGRAD, OP_QACT_FWD,
- OP_QACT_BWD, OP_POOL_REDUCE) = range(1, 28)
+ OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD) = range(1, 29)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
@@ -232,7 +237,7 @@ OP_FIELD = {
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
     OP_TRANSPOSE: 'tr', OP_QAT_WPREP: 'qw', OP_QAT_WGRAD: 'qw', OP_QACT_FWD: 'qa', OP_QACT_BWD: 'qb',
-    OP_POOL_REDUCE: 'pr',
+    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -268,6 +273,10 @@ SIGNATURES = {
     'pq_route_bwd': (C.c_int, [C.POINTER(RouteBwd), C.c_void_p]),
     'pq_ew_blocks': (i32, [i32, i32]),
     'pq_pool_reduce': (C.c_int, [C.POINTER(PoolReduce), C.c_void_p]),
+    'pq_conv1x1_bwd': (C.c_int, [C.POINTER(Conv1x1Bwd), C.c_void_p]),
+    'pq_conv1x1_bwd_blocks': (i32, [i32, i32, i32]),
+    'pq_conv1x1_bwd_pays': (i32, [i32, i32, i32]),
+    'pq_conv1x1_bwd_scratch_bytes': (C.c_int64, [i32, i32, i32]),
     'pq_decode': (C.c_int, [C.POINTER(Decode), C.c_void_p]),
     'pq_decode_bwd': (C.c_int, [C.POINTER(DecodeBwd), C.c_void_p]),
     'pq_yolo_loss_fwd': (C.c_int, [C.POINTER(YoloLoss), C.c_void_p]),

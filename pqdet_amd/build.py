@@ -19,6 +19,7 @@ SOURCES = {            # file -> extra flags
     'dwconv.hip': [],
     'dwtile.hip': [],
     'gconv.hip': [],
+    'pwbwd.hip': [],
     'qat.hip': ['-ffp-contract=off'],
     'ew.hip': [],
     'yolo.hip': [],

@@ -141,13 +141,13 @@ __device__ __forceinline__ SinkCoef4 sink_coef4(const pq_gsink& s, int c0, int C
     }
     return k;
 }
-// Emit 4 channels of one row into the sink; returns g and accumulates the two statistics.
-__device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k, size_t row, int c0, float4 dz,
-                                           float4& s1, float4& s2) {
-    float* gp = s.g + row * (size_t)s.ldg + c0;
-    if (s.accumulate) dz = f4add(dz, ldg4(gp));
-    if (s.finalize && (k.act.code != PQ_ACT_LINEAR || k.stats || k.q)) {
-        float4 y4 = ldg4(s.y + row * (size_t)s.ldy + c0);
+// does the sink read y when it finalises?
+__device__ __forceinline__ bool sink_needs_y(const pq_gsink& s, const SinkCoef4& k) {
+    return s.finalize && (k.act.code != PQ_ACT_LINEAR || k.stats || k.q);
+}
+// dz (accumulated already) -> gradient wrt y for 4 channels of one row; y4 is only used when sink_needs_y()
+__device__ __forceinline__ float4 sink_apply4(const pq_gsink& s, const SinkCoef4& k, float4 dz, float4 y4, float4& s1, float4& s2) {
+    if (sink_needs_y(s, k)) {
         float d[4] = {dz.x, dz.y, dz.z, dz.w}, y[4] = {y4.x, y4.y, y4.z, y4.w};
         float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t2[4] = {s2.x, s2.y, s2.z, s2.w};
         if (k.q) {                // QAT only: straight-through mask of the activation fake-quantiser (arithmetic of qat.hip)
@@ -172,7 +172,16 @@ __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k
         s1 = make_float4(t1[0], t1[1], t1[2], t1[3]);
         s2 = make_float4(t2[0], t2[1], t2[2], t2[3]);
     }
-    stg4(gp, dz);
+    return dz;
+}
+// Emit 4 channels of one row into the sink; accumulates the two statistics.
+__device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k, size_t row, int c0, float4 dz,
+                                           float4& s1, float4& s2) {
+    float* gp = s.g + row * (size_t)s.ldg + c0;
+    if (s.accumulate) dz = f4add(dz, ldg4(gp));
+    float4 y4 = f4zero();
+    if (sink_needs_y(s, k)) y4 = ldg4(s.y + row * (size_t)s.ldy + c0);
+    stg4(gp, sink_apply4(s, k, dz, y4, s1, s2));
 }
 
 // ---- XCD-aware block numbering ---------------------------------------------------------------------------------

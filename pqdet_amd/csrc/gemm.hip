@@ -664,20 +664,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTP p) {
     }
 }
 
-// out[j] = sum_s slab[s*stride + j]; block = 64 columns x 16 split lanes
+// out[j] = sum_s slab[s*stride + j]; block = 32 columns x 32 split lanes, 8 loads in flight per thread
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* slab, size_t stride, int splits, float* out0, int n0, float* out1, int n1) {
-    __shared__ float red[16][65];
+    __shared__ float red[32][33];
     const int n = n0 + n1;
-    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.x * 32 + threadIdx.x;
     float s = 0.f;
-    if (j < n)
-        for (int k = threadIdx.y; k < splits; k += 16) s += slab[(size_t)k * stride + j];
+    if (j < n) {
+        int k = threadIdx.y;
+        for (; k + 7 * 32 < splits; k += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(k + 32 * u) * stride + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < splits; k += 32) s += slab[(size_t)k * stride + j];
+    }
     red[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && j < n) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
         if (j < n0) out0[j] = t; else out1[j - n0] = t;
     }
 }
@@ -841,8 +850,8 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
     else hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
     const int n0 = a->O * a->I, n1 = a->dbias ? a->O : 0;
-    const int rb = (n0 + n1 + 63) / 64;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(64, 16), 0, st, (const float*)a->scratch, p.slab_stride, splits,
+    const int rb = (n0 + n1 + 31) / 32;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(32, 32), 0, st, (const float*)a->scratch, p.slab_stride, splits,
                        a->dw, n0, a->dbias, n1);
     PQ_CHECK_LAUNCH();
     return PQ_OK;

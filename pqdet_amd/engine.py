@@ -693,7 +693,18 @@ class Plan:
                         wg_ops.append((idx, 'stw', need))
                     else:
                         src = T[resolve(i - 1, i)]
-                        if k == 1:
+                        fused_blocks = 0
+                        if k == 1 and s == 1 and src.needs_grad and conv.bias is None:
+                            # narrow layer over many rows: input and weight gradient from one pass over dy (pwbwd.hip)
+                            if l.pq_conv1x1_bwd_pays(out.rows, src.C, out.C):
+                                fused_blocks = l.pq_conv1x1_bwd_blocks(out.rows, src.C, out.C)
+                        if fused_blocks:
+                            need = l.pq_conv1x1_bwd_scratch_bytes(out.rows, src.C, out.C)
+                            buf = self._new(max(need, 64) // 4 + 16)
+                            a = abi.Conv1x1Bwd(dy, wsrc, src.src(), self._sink(src, fused_blocks), wdst, ptr(buf),
+                                               out.rows, src.C, out.C)
+                            self._op(self.bwd, abi.OP_CONV1X1_BWD, a)
+                        elif k == 1:
                             need = l.pq_conv1x1_wgrad_scratch_bytes(out.rows, src.C, out.C)
                             a = abi.Conv1x1Wgrad(dy, src.src(), wdst,
                                                  flat.grad_ptr(conv.bias) if conv.bias is not None else None, None,

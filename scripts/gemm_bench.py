@@ -9,6 +9,9 @@ SHAPES = [(1048576, 16, 96), (1048576, 32, 16), (262144, 24, 144), (262144, 144,
           (65536, 128, 256), (65536, 256, 128), (16384, 64, 384), (16384, 384, 64), (16384, 96, 576), (16384, 576, 96),
           (16384, 256, 512), (16384, 512, 256), (4096, 160, 960), (4096, 960, 160), (4096, 320, 1280), (4096, 1280, 512),
           (4096, 512, 1024), (4096, 1024, 512)]
+if os.environ.get('NARROW'):
+    SHAPES = [(1048576, 16, 96), (1048576, 32, 16), (262144, 24, 144), (262144, 144, 24), (262144, 96, 24), (65536, 32, 192),
+              (65536, 192, 32), (65536, 144, 32)]
 if os.environ.get('SWEEP'):
     SHAPES = [(m, k, n) for (m, n) in ((4096, 512), (4096, 1024), (16384, 256), (65536, 128), (262144, 128)) for k in (32, 64, 128, 256, 512, 1024, 2048)]
 which = sys.argv[1] if len(sys.argv) > 1 else 'fwd,dgrad,wgrad'
@@ -69,5 +72,18 @@ for (M, I, O) in SHAPES:
         ms = timeit(lambda: abi.check(l.pq_conv1x1_wgrad(C.byref(a), st)))
         tot['wgrad'] = tot.get('wgrad', 0) + ms
         line += '| wgrad %.3f ms %5.1f TF %6.0f GB/s' % (ms, flops / ms / 1e9, byts / ms / 1e6)
+    if 'bwd' in which and l.pq_conv1x1_bwd_blocks(M, I, O) > 0:
+        nb = l.pq_conv1x1_bwd_blocks(M, I, O); ldp = (I + 15) // 16 * 16
+        part = torch.empty(nb * 2 * ldp, device=dev)
+        scratch = torch.empty(l.pq_conv1x1_bwd_scratch_bytes(M, I, O) // 4 + 16, device=dev)
+        dw = torch.empty(O, I, device=dev)
+        a = abi.Conv1x1Bwd(abi.GSrc(g.data_ptr(), y.data_ptr(), p.data_ptr(), q.data_ptr(), mu.data_ptr(), r.data_ptr(), ldo, ldo),
+                           w.data_ptr(), abi.Src(x.data_ptr(), a2.data_ptr(), b2.data_ptr(), I, 2),
+                           abi.GSink(gin.data_ptr(), x.data_ptr(), a2.data_ptr(), b2.data_ptr(), mn.data_ptr(), iv.data_ptr(), part.data_ptr(), I, I, 2, 0, 1, ldp),
+                           dw.data_ptr(), scratch.data_ptr(), M, I, O)
+        ms = timeit(lambda: abi.check(l.pq_conv1x1_bwd(C.byref(a), st)))
+        tot['bwd'] = tot.get('bwd', 0) + ms
+        tb = 4.0 * M * (2 * O + 3 * I)
+        line += '| fused bwd %.3f ms %6.0f GB/s(real) grid %d' % (ms, tb / ms / 1e6, nb)
     print(line, flush=True)
 print('sum', {k: round(v, 3) for k, v in tot.items()})

@@ -37,6 +37,7 @@ for tag, arr, n in (('fwd', plan.fwd_arr, len(plan.fwd)), ('bwd', plan.bwd_arr, 
         if op.code == abi.OP_CONV1X1_FWD: a = op.u.c1f; desc = 'M=%d I=%d O=%d' % (a.M, a.I, a.O)
         elif op.code == abi.OP_CONV1X1_DGRAD: a = op.u.c1d; desc = 'M=%d I=%d O=%d' % (a.M, a.I, a.O)
         elif op.code == abi.OP_CONV1X1_WGRAD: a = op.u.c1w; desc = 'M=%d I=%d O=%d' % (a.M, a.I, a.O)
+        elif op.code == abi.OP_CONV1X1_BWD: a = op.u.c1b; desc = 'M=%d I=%d O=%d' % (a.M, a.I, a.O)
         elif op.code in (abi.OP_DW_FWD, abi.OP_DW_DGRAD, abi.OP_DW_WGRAD):
             a = {abi.OP_DW_FWD: op.u.dwf, abi.OP_DW_DGRAD: op.u.dwd, abi.OP_DW_WGRAD: op.u.dww}[op.code]
             desc = 'B=%d %dx%d->%dx%d C=%d s=%d' % (a.B, a.IH, a.IW, a.OH, a.OW, a.C, a.stride)

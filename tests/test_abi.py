@@ -37,7 +37,8 @@ def test_struct_layouts_match_the_compiler(lib):
              abi.OP_ADAM: abi.Adam, abi.OP_FILL: abi.Fill, abi.OP_DW_BWD: abi.DwBwd, abi.OP_GCONV_FWD: abi.GconvFwd,
              abi.OP_GCONV_DGRAD: abi.GconvDgrad, abi.OP_GCONV_WGRAD: abi.GconvWgrad, abi.OP_TRANSPOSE: abi.Transpose,
              103: abi.TransposeItem, 104: abi.CreateLabel, 105: abi.QatWeightItem, abi.OP_QAT_WPREP: abi.QatWeight,
-             abi.OP_QACT_FWD: abi.Qact, abi.OP_QACT_BWD: abi.QactBwd, abi.OP_POOL_REDUCE: abi.PoolReduce, 100: abi.Recover, 101: abi.Nms, 102: abi.DecodeBwd}
+             abi.OP_QACT_FWD: abi.Qact, abi.OP_QACT_BWD: abi.QactBwd, abi.OP_POOL_REDUCE: abi.PoolReduce,
+             abi.OP_CONV1X1_BWD: abi.Conv1x1Bwd, 100: abi.Recover, 101: abi.Nms, 102: abi.DecodeBwd}
     for code, st in pairs.items():
         assert lib.pq_abi_sizeof(code) == C.sizeof(st), (code, st.__name__)
 
@@ -49,4 +50,6 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.pq_version().startswith(b'pqdet_hip')
     assert lib.pq_yolo_loss_blocks(64, 64, 3) == 48
     assert lib.pq_conv1x1_wgrad_scratch_bytes(4096, 160, 960) > 0
+    assert lib.pq_conv1x1_bwd_blocks(1 << 20, 16, 96) > 0 and lib.pq_conv1x1_bwd_blocks(4096, 160, 960) == 0
+    assert lib.pq_conv1x1_bwd_pays(1 << 20, 16, 96) == 1 and lib.pq_conv1x1_bwd_pays(4096, 16, 96) == 0
     assert lib.pq_nms_scratch_bytes(16128, 20) > 16128 * 20 * 56

@@ -254,6 +254,94 @@ def test_conv1x1_wgrad(M, I, O, two, bias):
         close(db, dy.double().sum(0).float(), rt=1e-3, at=1e-3, what='bias grad')
 
 
+@pytest.mark.parametrize('M,I,O,two,act,accum,stats', [
+    (40000, 16, 96, True, 2, False, True),       # expand layer, ReLU6 + BN sink
+    (33000, 32, 16, True, 0, True, True),        # both sides narrow, linear sink, accumulate
+    (36001, 144, 24, True, 2, False, True),      # project layer (wide input side), ragged last tile
+    (32768, 24, 144, True, 0, False, False),     # linear sink without statistics
+    (35000, 192, 32, False, 1, True, True),      # dy' = g (no BatchNorm after the conv), 12 column tiles
+    (34000, 96, 24, True, 3, False, True),       # leaky
+])
+def test_conv1x1_bwd_fused_matches_the_two_kernel_backward(M, I, O, two, act, accum, stats):
+    """pq_conv1x1_bwd (one pass) against the fp64 statement AND against pq_conv1x1_dgrad + pq_conv1x1_wgrad."""
+    l = abi.lib()
+    nblk = l.pq_conv1x1_bwd_blocks(M, I, O)
+    assert nblk > 0
+    g = torch.Generator().manual_seed(M + I + O + 7)
+    gy = rnd(M, O, g=g)
+    yout = rnd(M, O, g=g) + 0.3
+    gamma = torch.rand(O, generator=g) + 0.5
+    w = rnd(O, I, g=g, scale=1 / math.sqrt(O))
+    if two:
+        p, q, mu, r, _ = _bn_bwd_coeffs(gy, yout, gamma)
+        dy = p * gy + q * (yout - mu) + r
+    else:
+        dy = gy
+    yin = rnd(M, I, g=g) * 2 + 1
+    a_in = torch.rand(I, generator=g) + 0.5
+    b_in = rnd(I, g=g, scale=0.5)
+    mean_in = yin.mean(0)
+    inv_in = 1 / torch.sqrt(yin.var(0, unbiased=False) + 1e-5)
+    old = rnd(M, I, g=g)
+    u_in = yin * a_in + b_in
+    xin = act_ref(u_in, act)
+    want_dw = dy.double().t() @ xin.double()
+    gout = ((dy.double() @ w.double()).float() + (old if accum else 0)) * act_grad_ref(u_in, act)
+    gyd, youtd, wd, yind = gy.to(DEV), yout.to(DEV), w.to(DEV), yin.to(DEV)
+    vecs = [chan_vec(v) for v in ((p, q, mu, r) if two else ())]
+    sv = [chan_vec(v) for v in (a_in, b_in, mean_in, inv_in)]
+    ldp = (I + 15) // 16 * 16
+    dyarg = abi.GSrc(gyd.data_ptr(), youtd.data_ptr() if two else None, *([v.data_ptr() for v in vecs] if two else [None] * 4), O, O)
+    inarg = abi.Src(yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(), I, act)
+
+    def sink(gdst, partial):
+        return abi.GSink(gdst.data_ptr(), yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
+                         sv[2].data_ptr() if stats else None, sv[3].data_ptr() if stats else None,
+                         partial.data_ptr() if stats else None, I, I, act, int(accum), 1, ldp)
+
+    gdst = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
+    partial = torch.full((nblk * 2 * ldp,), float('nan'), device=DEV)
+    dw = torch.full((O, I), float('nan'), device=DEV)
+    scratch = torch.empty(l.pq_conv1x1_bwd_scratch_bytes(M, I, O) // 4, device=DEV)
+    a = abi.Conv1x1Bwd(dyarg, wd.data_ptr(), inarg, sink(gdst, partial), dw.data_ptr(), scratch.data_ptr(), M, I, O)
+    abi.check(l.pq_conv1x1_bwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(gdst, gout, what='fused dgrad sink')
+    close(dw, want_dw.float(), rt=1e-3, at=2e-3, what='fused wgrad')
+    xh = (yin.double() - mean_in.double()) * inv_in.double()
+    if stats:
+        s1, s2 = reduce_partial(partial, nblk, ldp, I)
+        close(s1.float(), gout.double().sum(0).float(), rt=1e-3, at=3e-2, what='sum g')
+        close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=3e-2, what='sum g*xhat')
+    # the two-kernel path on the same operands: same arithmetic up to summation order
+    g2 = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
+    nb2 = l.pq_conv1x1_blocks(M, I)
+    part2 = torch.zeros(nb2 * 2 * ldp, device=DEV)
+    d = abi.Conv1x1Dgrad()
+    d.dy, d.w, d.dx, d.M, d.I, d.O = dyarg, wd.data_ptr(), sink(g2, part2), M, I, O
+    abi.check(l.pq_conv1x1_dgrad(C.byref(d), stream()))
+    dw2 = torch.empty(O, I, device=DEV)
+    sc2 = torch.empty(l.pq_conv1x1_wgrad_scratch_bytes(M, I, O) // 4, device=DEV)
+    wg = abi.Conv1x1Wgrad()
+    wg.dy, wg.inp, wg.dw, wg.scratch, wg.M, wg.I, wg.O = dyarg, inarg, dw2.data_ptr(), sc2.data_ptr(), M, I, O
+    abi.check(l.pq_conv1x1_wgrad(C.byref(wg), stream()))
+    torch.cuda.synchronize()
+    close(gdst, g2, rt=1e-4, at=1e-5, what='fused vs two-kernel dgrad')
+    close(dw, dw2, rt=1e-4, at=2e-3, what='fused vs two-kernel wgrad')
+
+
+def test_conv1x1_bwd_fused_rejects_shapes_outside_its_range():
+    l = abi.lib()
+    assert l.pq_conv1x1_bwd_blocks(4096, 160, 960) == 0 and l.pq_conv1x1_bwd_blocks(1 << 20, 18, 96) == 0
+    a = abi.Conv1x1Bwd()
+    t = torch.zeros(64, device=DEV)
+    a.dy.g = a.w = a.inp.x = a.dx.g = a.dw = a.scratch = t.data_ptr()
+    a.dy.ldg, a.inp.ld, a.dx.ldg, a.dx.ldy = 960, 160, 160, 160
+    a.M, a.I, a.O = 4096, 160, 960
+    assert l.pq_conv1x1_bwd(C.byref(a), stream()) != 0
+    assert b'outside the fused' in l.pq_last_error()
+
+
 # ----------------------------------------------------------------------------------------------- depthwise 3x3
 @pytest.mark.parametrize('B,H,W,Cc,stride', [(2, 9, 13, 32, 1), (2, 10, 14, 96, 2), (1, 7, 7, 144, 1), (2, 8, 8, 960, 1),
                                              (1, 5, 9, 576, 2), (2, 40, 36, 48, 2), (1, 33, 50, 16, 1)])

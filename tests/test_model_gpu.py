@@ -307,6 +307,55 @@ def test_training_with_frozen_batchnorm_statistics():
     assert out2['loss'].item() == out['loss'].item()
 
 
+@pytest.mark.parametrize('name', ['mobilenetv2-fpn', 'regnetx-600m-fpn'])
+def test_fused_narrow_conv_backward_inside_the_engine(name, monkeypatch):
+    """pq_conv1x1_bwd replaces dgrad + wgrad on every narrow 1x1 layer when the row threshold is lowered (production:
+    2^17 rows): the plan really contains the fused op, and losses / gradients match the oracle (frozen BatchNorm
+    statistics keep the net well conditioned, so gradients are compared directly) and the two-kernel plan."""
+    from pqdet_amd import abi, tools
+    monkeypatch.setenv('PQ_PW_MIN_M', '1')
+    net, ref = _pair(seed=17, name=name)
+    x = seeded_images(2, 128, 160, 4)
+    tgt = _targets(2, 128, 160, 20, seed=3)
+    net.train(), ref.eval()
+    tools.freeze_bn_stats(net)
+    out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    out['loss'].mean().backward()
+    plan = next(iter(net._plans.values()))
+    n_fused = sum(1 for op in plan.bwd if op.code == abi.OP_CONV1X1_BWD)
+    assert n_fused >= {'mobilenetv2-fpn': 5, 'regnetx-600m-fpn': 1}[name], n_fused
+    want = ref(x, tgt)
+    want['loss'].mean().backward()
+    for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss'):
+        assert abs(out[k].item() - want[k].item()) <= 1e-3 * abs(want[k].item()) + 1e-5, k
+    for (n1, p1), (_, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        if p2.grad.norm().item() > 1e-6:
+            assert _relerr(p1.grad, p2.grad) < 5e-3, n1
+    # train-mode statistics: same step through the two-kernel plan of a second replica
+    g_fused = {}
+    net.train()
+    tools.update_bn_stats(net)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.zero_grad()
+    o1 = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    o1['loss'].mean().backward()
+    g_fused = {n: p.grad.clone() for n, p in net.named_parameters()}
+    monkeypatch.setenv('PQ_PW_BWD', '0')
+    net2 = DetectionModel(io.StringIO(_cfg_text(name))).to(DEV)
+    net2.load_state_dict(sd)
+    net2.train()
+    o2 = net2(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    o2['loss'].mean().backward()
+    assert not any(op.code == abi.OP_CONV1X1_BWD for op in next(iter(net2._plans.values())).bwd)
+    assert o1['loss'].item() == o2['loss'].item()
+    # same arithmetic up to summation order; train-mode BatchNorm amplifies the last-bit differences on a few parameters
+    # (gradients that are pure round-off -- e.g. the bias of a BatchNorm that feeds another train-mode BatchNorm -- are
+    # measured against the largest gradient norm instead of their own)
+    floor = 1e-4 * max(p.grad.norm().item() for p in net2.parameters())
+    errs = sorted((g_fused[n] - p.grad).norm().item() / max(p.grad.norm().item(), floor) for n, p in net2.named_parameters())
+    assert errs[len(errs) // 2] < 1e-4 and errs[-1] < 5e-2, (errs[len(errs) // 2], errs[-1])
+
+
 def test_short_training_run_tracks_the_oracle_loss_curve():
     """Twelve Adam steps on a fixed batch: the HIP engine's loss follows the CPU oracle's curve (same start, same data) and
     goes down by the same factor."""
