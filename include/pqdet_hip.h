@@ -184,6 +184,8 @@ typedef struct pq_dw3x3_bwd_args {
     float* dw;
     float* scratch;      /* >= pq_dw3x3_bwd_scratch_bytes */
     int32_t B, IH, IW, OH, OW, C, stride;
+    int32_t part;        /* 0: both gradients in one kernel; stride 1 also 1: input gradient only (dw, scratch, in unused),
+                            2: weight gradient only (w, dx unused) -- lets the weight half run on another stream */
 } pq_dw3x3_bwd_args;
 int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream);
 int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t C, int32_t stride);

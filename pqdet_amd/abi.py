@@ -91,7 +91,7 @@ class DwWgrad(C.Structure):
 
 class DwBwd(C.Structure):
     _fields_ = [('dy', GSrc), ('inp', Src), ('w', c_fp), ('dx', GSink), ('dw', c_fp), ('scratch', c_fp),
-                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('stride', i32)]
+                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('stride', i32), ('part', i32)]
 
 
 class StemFwd(C.Structure):

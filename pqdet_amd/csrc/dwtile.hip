@@ -164,6 +164,9 @@ __device__ __forceinline__ void s2_dgrad_row(const float4* dyt, int drow, int cx
 // Stride 1, two phases through ONE LDS tile (34 KB -> 4 workgroups per CU, ~100 VGPRs):
 //   phase 1: stage dy' (10x18), input gradient from LDS with the flipped taps -> sink; the owned dy' values stay in registers
 //   phase 2: stage x'  (10x18) into the same buffer, weight-gradient taps
+// PART: 0 = both gradients, 1 = input gradient only (phase 1), 2 = weight gradient only (phase 2; the owned dy' values are
+// read straight from global memory) -- the engine runs 1 on the main stream and 2 on the weight-gradient stream.
+template <int PART>
 __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
     constexpr int TH = 8, TWD = 16, PH = TH + 2, PW = TWD + 2, NPX = PH * PW;
     __shared__ float4 tile[NPX * PQP];
@@ -181,7 +184,19 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
     const int row = pl >> 2, col0 = (pl & 3) * 4;
     float4 s1 = f4zero(), s2 = f4zero();
     float4 dyc[4];
-    {   // ---------------- phase 1
+    if (PART == 2) {   // only the dy' values this thread owns
+        const GsrcCoef4 gk = gsrc_coef4(p.dy, cc, p.C);
+        const int oy = y0 + row;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ox = x0 + col0 + u;
+            const bool ok = cok && oy < p.OH && ox < p.OW;
+            const size_t r = ((size_t)b * p.OH + min(oy, p.OH - 1)) * p.OW + min(ox, p.OW - 1);
+            const float4 g4 = ldg4(p.dy.g + r * p.dy.ldg + cc);
+            const float4 y4 = gk.two ? ldg4(p.dy.y + r * p.dy.ldy + cc) : f4zero();
+            dyc[u] = ok ? gsrc_apply4(g4, y4, gk) : f4zero();
+        }
+    } else {   // ---------------- phase 1
         const GsrcCoef4 gk = gsrc_coef4(p.dy, cc, p.C);
         for (int e0 = 0; e0 < NPX; e0 += 32 * 2) {
             float4 rg[2], ry[2];
@@ -243,6 +258,24 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
             if (cok && y < p.IH && x < p.IW) sink_emit4(p.sink, sk, ((size_t)b * p.IH + y) * p.IW + x, c0, dx[u], s1, s2);
         }
     }
+    if (PART == 1) {      // input gradient only: statistics rows of the sink, then done
+        if (p.sink.finalize && p.sink.mean && p.sink.partial) {
+            __syncthreads();
+            float* slot = red + (pl * 8 + q) * 8;
+            slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
+            slot[4] = s2.x; slot[5] = s2.y; slot[6] = s2.z; slot[7] = s2.w;
+            __syncthreads();
+            if (t < 64) {
+                const int qq = t >> 3, comp = t & 7;
+                float a = 0.f;
+#pragma unroll
+                for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
+                const int c = (cq0 + qq) * 4 + (comp & 3);
+                if (c < p.C) p.sink.partial[(size_t)tIdx * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
+            }
+        }
+        return;
+    }
     __syncthreads();      // every wave is done reading the dy' tile
     float4 dwacc[9];
 #pragma unroll
@@ -300,7 +333,7 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
             if (c < p.C) p.wpartial[((size_t)tIdx * p.C + c) * 9 + k] = a;
         }
     }
-    if (p.sink.finalize && p.sink.mean && p.sink.partial) {     // uniform
+    if (PART == 0 && p.sink.finalize && p.sink.mean && p.sink.partial) {     // uniform
         __syncthreads();
         float* slot = red + (pl * 8 + q) * 8;
         slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
@@ -602,11 +635,14 @@ extern "C" int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW,
 }
 
 extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
-    PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->w && a->dx.g && a->dw && a->scratch, "null pointer");
+    PQ_CHECK_ARG(a && a->dy.g && a->part >= 0 && a->part <= 2, "null pointer / bad part");
+    PQ_CHECK_ARG(a->part == 2 || (a->w && a->dx.g), "input gradient needs w and the sink");
+    PQ_CHECK_ARG(a->part == 1 || (a->in.x && a->dw && a->scratch), "weight gradient needs in, dw and scratch");
+    PQ_CHECK_ARG(a->part == 0 || a->stride == 1, "the split backward exists for stride 1 only");
     PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need C%4==0, stride 1|2, pad 1)");
     PQ_CHECK_ARG(a->stride == 1 || ((a->IH & 1) == 0 && (a->IW & 1) == 0), "stride-2 backward needs even input sizes");
-    PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
-    if (act_is_special(a->dx.act) || act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_bwd: logistic/tanh are not supported"); return PQ_EUNSUPPORTED; }
+    PQ_CHECK_ARG(a->part == 2 || !(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    if ((a->part != 2 && act_is_special(a->dx.act)) || (a->part != 1 && act_is_special(a->in.act))) { pq_set_error("pq_dw3x3_bwd: logistic/tanh are not supported"); return PQ_EUNSUPPORTED; }
     DwTP p{};
     p.dy = a->dy; p.in = a->in; p.w = a->w; p.sink = a->dx; p.wpartial = a->scratch;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;
@@ -614,9 +650,12 @@ extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
     const int nblk = a->B * p.tilesH * p.tilesW;
     dim3 grid(nblk, (p.C4 + CBQ - 1) / CBQ), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (a->stride == 1) hipLaunchKernelGGL(dwt_bwd_s1_kernel, grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((dwt_bwd_kernel<2>), grid, blk, 0, st, p);
+    if (a->stride != 1) hipLaunchKernelGGL((dwt_bwd_kernel<2>), grid, blk, 0, st, p);
+    else if (a->part == 1) hipLaunchKernelGGL((dwt_bwd_s1_kernel<1>), grid, blk, 0, st, p);
+    else if (a->part == 2) hipLaunchKernelGGL((dwt_bwd_s1_kernel<2>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((dwt_bwd_s1_kernel<0>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
+    if (a->part == 1) return PQ_OK;
     const int n = a->C * 9;
     hipLaunchKernelGGL(dwt_partial_reduce_kernel, dim3((n + 63) / 64), dim3(64, 16), 0, st, (const float*)a->scratch, nblk, n, a->dw);
     PQ_CHECK_LAUNCH();

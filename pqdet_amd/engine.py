@@ -745,11 +745,22 @@ class Plan:
                             if l.pq_dw3x3_bwd_fused_pays(src.H, src.W, s) and (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0)):
                                 # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
                                 need = l.pq_dw3x3_bwd_scratch_bytes(B, src.H, src.W, out.H, out.W, out.C, s)
-                                buf = self._new(max(need, 64) // 4 + 16)
-                                a = abi.DwBwd(dy, src.src(), wsrc,
-                                              self._sink(src, l.pq_dw3x3_bwd_blocks(B, src.H, src.W, s)),
-                                              wdst, ptr(buf), B, src.H, src.W, out.H, out.W, out.C, s)
-                                self._op(self.bwd, abi.OP_DW_BWD, a)
+                                sink = self._sink(src, l.pq_dw3x3_bwd_blocks(B, src.H, src.W, s))
+                                if s == 1 and os.environ.get('PQ_DW_SPLIT', '1') != '0':
+                                    # the input-gradient chain is the critical path: the weight half of the tiled kernel
+                                    # goes to the weight-gradient stream (emitted first so that it starts early)
+                                    a = abi.DwBwd(dy, src.src(), None, abi.GSink(), wdst, None, B, src.H, src.W, out.H,
+                                                  out.W, out.C, s, 2)
+                                    idx = self._op(self.bwd, abi.OP_DW_BWD, a)
+                                    wg_ops.append((idx, 'dwb', need))
+                                    a = abi.DwBwd(dy, abi.Src(), wsrc, sink, None, None, B, src.H, src.W, out.H, out.W,
+                                                  out.C, s, 1)
+                                    self._op(self.bwd, abi.OP_DW_BWD, a)
+                                else:
+                                    buf = self._new(max(need, 64) // 4 + 16)
+                                    a = abi.DwBwd(dy, src.src(), wsrc, sink, wdst, ptr(buf), B, src.H, src.W, out.H, out.W,
+                                                  out.C, s, 0)
+                                    self._op(self.bwd, abi.OP_DW_BWD, a)
                             else:
                                 need = l.pq_dw3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C)
                                 a = abi.DwWgrad(dy, src.src(), wdst, None, B, src.H, src.W, out.H, out.W,

@@ -431,6 +431,19 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     t1, t2 = reduce_partial(part3, nb3, ldp, Cc)
     close(t1.float(), gwant.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum')
     close(t2.float(), (gwant.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum xhat')
+    if stride == 1:
+        # the two halves on their own (the engine runs the weight half on the weight-gradient stream): bit-identical
+        g3 = torch.full((B, H, W, Cc), float('nan'), device=DEV)
+        p3 = torch.zeros(nb3 * 2 * ldp, device=DEV)
+        h1 = abi.DwBwd(d.dy, abi.Src(), wd.data_ptr(), abi.GSink(g3.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
+                                                                  sv[1].data_ptr(), p3.data_ptr(), Cc, Cc, 2, 0, 1, ldp),
+                       None, None, B, H, W, OH, OW, Cc, stride, 1)
+        abi.check(l.pq_dw3x3_bwd(C.byref(h1), stream()))
+        dw3 = torch.full((Cc, 9), float('nan'), device=DEV)
+        h2 = abi.DwBwd(d.dy, a.inp, None, abi.GSink(), dw3.data_ptr(), sc2.data_ptr(), B, H, W, OH, OW, Cc, stride, 2)
+        abi.check(l.pq_dw3x3_bwd(C.byref(h2), stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(g3, gdst2) and torch.equal(p3, part3) and torch.equal(dw3, dw2)
 
 
 # ----------------------------------------------------------------------------------------------- stem
