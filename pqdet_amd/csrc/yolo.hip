@@ -174,21 +174,35 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(pq_yolo_loss_args a) {
         if (GRAD)
             for (int k = 0; k < 4; ++k) gout[k * a.gsc] = gcorner[k] * dpc[k] * mixw * gs_box;
 
-        // ---- class term
-        for (int k = 0; k < a.C; ++k) {
-            const float raw = in[(size_t)(5 + k) * a.in.sc];
-            const float q = a.from_raw ? sigmoidf_(raw) : raw;
-            const float t = lab[5 + k];
-            const float alpha_t = 2.f * fabsf(t - 1.f + 0.5f);
-            const float ad = fabsf(t - q);
-            const float focal = alpha_t * (ad * ad);
-            const float bce = bce_val(q, t);
-            lcls += 2.f * focal * respond * bce;
-            if (GRAD) {
-                const float dfocal = -2.f * alpha_t * (t - q);
-                const float dl = 2.f * respond * (dfocal * bce + focal * bce_grad(q, t));
-                const float dq = a.from_raw ? q * (1.f - q) : 1.f;
-                gout[(size_t)(5 + k) * a.gsc] = dl * dq * mixw * gs_cls;
+        // ---- class term: eight classes per round, loads first (each thread walks its own 25..86-float record, so the
+        // loads of one round are the only memory-level parallelism there is; one class per round was pure load latency)
+        constexpr int CK = 8;
+        for (int k0 = 0; k0 < a.C; k0 += CK) {
+            float raw[CK], tt[CK];
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                const int k = min(k0 + u, a.C - 1);
+                raw[u] = in[(size_t)(5 + k) * a.in.sc];
+                tt[u] = lab[5 + k];
+            }
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                const int k = k0 + u;
+                if (k < a.C) {
+                    const float q = a.from_raw ? sigmoidf_(raw[u]) : raw[u];
+                    const float t = tt[u];
+                    const float alpha_t = 2.f * fabsf(t - 1.f + 0.5f);
+                    const float ad = fabsf(t - q);
+                    const float focal = alpha_t * (ad * ad);
+                    const float bce = bce_val(q, t);
+                    lcls += 2.f * focal * respond * bce;
+                    if (GRAD) {
+                        const float dfocal = -2.f * alpha_t * (t - q);
+                        const float dl = 2.f * respond * (dfocal * bce + focal * bce_grad(q, t));
+                        const float dq = a.from_raw ? q * (1.f - q) : 1.f;
+                        gout[(size_t)(5 + k) * a.gsc] = dl * dq * mixw * gs_cls;
+                    }
+                }
             }
         }
         lcls *= mixw;
@@ -210,23 +224,39 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(pq_yolo_loss_args a) {
     }
 }
 
-__global__ __launch_bounds__(64) void yolo_loss_finalize_kernel(const float* partial, int B, int nblk, float* losses, int32_t* nan_flag) {
-    // lanes 0..2 own one loss term each; sum blocks per image in double, then mean over the batch
-    const int k = threadIdx.x;
-    double acc = 0.0;
-    if (k < 3) {
-        for (int b = 0; b < B; ++b) {
-            double s = 0.0;
-            for (int j = 0; j < nblk; ++j) s += (double)partial[((size_t)b * nblk + j) * 3 + k];
-            acc += (double)(float)s;
+__global__ __launch_bounds__(256) void yolo_loss_finalize_kernel(const float* partial, int B, int nblk, float* losses, int32_t* nan_flag) {
+    // 16 image lanes x 16 block lanes.  Per image: the block partials are summed in double (16 lanes + a butterfly, fixed
+    // order) and rounded to float like the reference's per-image .sum(); images are then added in double and averaged.
+    __shared__ double sh[3][16];
+    const int jl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b0 = 0; b0 < B; b0 += 16) {
+        const int b = b0 + bl;
+        double s[3] = {0.0, 0.0, 0.0};
+        if (b < B)
+            for (int j = jl; j < nblk; j += 16) {
+                const float* pp = partial + ((size_t)b * nblk + j) * 3;
+                s[0] += (double)pp[0]; s[1] += (double)pp[1]; s[2] += (double)pp[2];
+            }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] += __shfl_xor(s[k], off);
         }
-        acc /= (double)B;
+        if (b < B) { acc[0] += (double)(float)s[0]; acc[1] += (double)(float)s[1]; acc[2] += (double)(float)s[2]; }
     }
-    const float mine = (float)acc;
-    const float box = __shfl(mine, 0), conf = __shfl(mine, 1), cls = __shfl(mine, 2);
-    if (k == 0) {
-        const float total = box + conf + cls;
-        losses[0] = total; losses[1] = box; losses[2] = conf; losses[3] = cls;
+    if (jl == 0) { sh[0][bl] = acc[0]; sh[1][bl] = acc[1]; sh[2][bl] = acc[2]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float term[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double t = 0.0;
+            for (int q = 0; q < 16; ++q) t += sh[k][q];
+            term[k] = (float)(t / (double)B);
+        }
+        const float total = term[0] + term[1] + term[2];
+        losses[0] = total; losses[1] = term[0]; losses[2] = term[1]; losses[3] = term[2];
         if (nan_flag) *nan_flag = (total != total) ? 1 : 0;
     }
 }
@@ -310,7 +340,7 @@ extern "C" int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((yolo_loss_kernel<false>), dim3(nblk, a->B), dim3(256), 0, st, *a);
     PQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)a->partial, a->B, nblk, a->losses, a->nan_flag);
+    hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)a->partial, a->B, nblk, a->losses, a->nan_flag);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
