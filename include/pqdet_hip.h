@@ -106,7 +106,8 @@ typedef struct pq_conv1x1_dgrad_args {
     int32_t M, I, O;
     int32_t sub, OH, OW, IH, IW;   /* sub>1 (strided 1x1 conv): row (b,oy,ox) of dz lands on sink pixel (b,oy*sub,ox*sub); the
                                       sink must then be accumulate-only (finalize==0) -- untouched pixels keep their value */
-    const float* wt;     /* optional [I][O] transposed copy of w (pq_transpose2d): K-contiguous B operand, faster LDS path */
+    const float* wt;     /* optional transposed copy of w, [I][ceil4(O)] with zero pad columns (pq_transpose_batch writes that
+                            layout): K-contiguous B operand, faster LDS path */
 } pq_conv1x1_dgrad_args;
 int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream);
 
@@ -489,11 +490,12 @@ typedef struct pq_qact_bwd_args {
 int pq_qact_bwd(const pq_qact_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------ batched 2-D transposes (weights for the dgrad GEMMs)
- * dst[c][r] = src[r][c] for every item, ONE launch for the whole table (the table itself lives in device memory).
+ * dst[c][r] = src[r][c] for every item, ONE launch for the whole table (the table itself lives in device memory);
+ * dst rows have a pitch of ceil4(rows) floats (16-byte aligned rows; the pad is never written).
  * tile0 = number of 32x32 tiles of all previous items, tiles_c = ceil(cols/32). */
 typedef struct pq_transpose_item {
     const float* src;    /* [rows][cols] */
-    float* dst;          /* [cols][rows] */
+    float* dst;          /* [cols][ceil4(rows)] */
     int32_t rows, cols, tile0, tiles_c;
 } pq_transpose_item;
 typedef struct pq_transpose_args {

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const pq_transpose
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (c < it.cols && r < it.rows) it.dst[(size_t)c * it.rows + r] = tile[tx][ty + 8 * k];
+        if (c < it.cols && r < it.rows) it.dst[(size_t)c * ((it.rows + 3) & ~3) + r] = tile[tx][ty + 8 * k];   // rows padded to 16 B
     }
 }
 

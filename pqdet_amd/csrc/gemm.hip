@@ -794,8 +794,8 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->I; p.K = a->O;
     p.sink = a->dx;
     hipStream_t st = (hipStream_t)stream;
-    if (a->wt && (a->O & 3) == 0) {        // transposed weights [I][O]: B rows are K-contiguous like the forward operand
-        p.b = a->wt; p.ldb = a->O;
+    if (a->wt) {        // transposed weights [I][ceil4(O)] (pad columns zero): B rows are K-contiguous like the forward operand
+        p.b = a->wt; p.ldb = (a->O + 3) & ~3;
         if (a->dy.y) launch_nt<2, false, 2>(p, st); else launch_nt<0, false, 2>(p, st);
     } else {
         if (a->dy.y) launch_nt<2, true, 2>(p, st); else launch_nt<0, true, 2>(p, st);

@@ -643,9 +643,7 @@ class Plan:
         def transposed(conv, wsrc):
             """Device address of the [I][O] copy of a 1x1 weight, refreshed at the start of every backward."""
             O_, I_ = conv.out_channels, conv.in_channels
-            if O_ % 4:
-                return None
-            wt = self._new(I_ * O_)
+            wt = self._new(I_ * ((O_ + 3) // 4 * 4), fill=0.0)      # rows padded to 16 bytes, pad columns stay zero
             tile0 = tr_items[-1][4] + tr_items[-1][6] if tr_items else 0
             tiles_c = (I_ + 31) // 32
             tr_items.append((wsrc, wt.data_ptr(), O_, I_, tile0, tiles_c, ((O_ + 31) // 32) * tiles_c))

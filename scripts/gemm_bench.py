@@ -14,6 +14,8 @@ if os.environ.get('NARROW'):
               (65536, 192, 32), (65536, 144, 32)]
 if os.environ.get('SWEEP'):
     SHAPES = [(m, k, n) for (m, n) in ((4096, 512), (4096, 1024), (16384, 256), (65536, 128), (262144, 128)) for k in (32, 64, 128, 256, 512, 1024, 2048)]
+if os.environ.get('SHAPES'):      # "M,I,O;M,I,O;..."
+    SHAPES = [tuple(int(v) for v in t.split(',')) for t in os.environ['SHAPES'].split(';')]
 which = sys.argv[1] if len(sys.argv) > 1 else 'fwd,dgrad,wgrad'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 l = abi.lib()
@@ -59,7 +61,7 @@ for (M, I, O) in SHAPES:
                              abi.GSink(gin.data_ptr(), x.data_ptr(), a2.data_ptr(), b2.data_ptr(), mn.data_ptr(), iv.data_ptr(), part.data_ptr(), I, I, 2, 0, fin, ldp),
                              M, I, O)
         if os.environ.get('DG_WT'):
-            wt = w.t().contiguous()
+            wt = torch.zeros(I, ldo, device=dev); wt[:, :O] = w.t()
             a.wt = wt.data_ptr()
         ms = timeit(lambda: abi.check(l.pq_conv1x1_dgrad(C.byref(a), st)))
         tot['dgrad'] = tot.get('dgrad', 0) + ms

@@ -1,0 +1,43 @@
+"""Wall time of the forward and backward op lists of one train step, replayed back to back (no per-op events)."""
+import ctypes as C, io, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from pqdet_amd import abi
+from pqdet_amd.dataset import labels
+from pqdet_amd.model import zoo
+from pqdet_amd.model.interpreter import DetectionModel
+
+B, S = int(sys.argv[1]), int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+torch.manual_seed(0)
+model = DetectionModel(io.StringIO(zoo.cfg_text(os.environ.get('MODEL', 'mobilenetv2-fpn')))).cuda(); model.train()
+x = torch.randn(B, 3, S, S).cuda()
+tgt = tuple(t.cuda() for t in labels.synthetic_targets(B, S, 20, seed=1))
+plan = model._plan(x, True)
+plan._patch(x, tgt)
+l = abi.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+side = model._side_stream(); sd = C.c_void_p(side.cuda_stream)
+
+def wall(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+nf, nb = len(plan.fwd), len(plan.bwd)
+print('ops: fwd %d bwd %d' % (nf, nb))
+print('forward            %.3f ms' % wall(lambda: abi.check(l.pq_run_ops(plan.fwd_arr, nf, st))))
+print('backward 2 streams %.3f ms' % wall(lambda: abi.check(l.pq_run_ops2(plan.bwd_arr, nb, st, sd))))
+print('backward 1 stream  %.3f ms' % wall(lambda: abi.check(l.pq_run_ops(plan.bwd_arr, nb, st))))
+# per op class, back to back: replay only the ops of one class (inputs are whatever the buffers hold)
+import bench
+for arr, n, tag in ((plan.fwd_arr, nf, 'fwd'), (plan.bwd_arr, nb, 'bwd')):
+    classes = {}
+    for k in range(n):
+        classes.setdefault(bench.KERNEL_CLASS.get(arr[k].code, ('other', ''))[0], []).append(k)
+    for name, idxs in classes.items():
+        sub = (abi.Op * len(idxs))(*[arr[k] for k in idxs])
+        ms = wall(lambda: abi.check(l.pq_run_ops(sub, len(idxs), st)))
+        print('%s %-60s %4d launches %.3f ms  (%.1f us each)' % (tag, name, len(idxs), ms, ms / len(idxs) * 1e3))

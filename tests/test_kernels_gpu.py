@@ -196,15 +196,18 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
         xh = (yin.double() - mean_in.double()) * inv_in.double()
         close(s1.float(), gout.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum g')
         close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat')
-    if O % 4 == 0:
-        # same result through the transposed-weight path (weights transposed on the device by pq_transpose_batch)
-        wt = torch.full((I, O), float('nan'), device=DEV)
+    if True:
+        # same result through the transposed-weight path (weights transposed on the device by pq_transpose_batch into rows
+        # of ceil4(O) floats; the pad columns must be zero)
+        Op = (O + 3) // 4 * 4
+        wt = torch.full((I, Op), float('nan'), device=DEV)
+        wt[:, O:] = 0
         items = (abi.TransposeItem * 1)(abi.TransposeItem(wd.data_ptr(), wt.data_ptr(), O, I, 0, (I + 31) // 32))
         table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(DEV)
         tr = abi.Transpose(table.data_ptr(), 1, ((O + 31) // 32) * ((I + 31) // 32))
         abi.check(abi.lib().pq_transpose_batch(C.byref(tr), stream()))
         torch.cuda.synchronize()
-        assert torch.equal(wt, wd.t())
+        assert torch.equal(wt[:, :O], wd.t()) and bool((wt[:, O:] == 0).all())
         g2 = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
         a.dx.g = g2.data_ptr()
         a.wt = wt.data_ptr()
