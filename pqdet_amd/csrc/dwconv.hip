@@ -551,15 +551,14 @@ static int check_dw_common(int B, int IH, int IW, int OH, int OW, int C, int str
     if (B <= 0 || IH <= 0 || IW <= 0 || C <= 0) return 0;
     if (stride != 1 && stride != 2) return 0;
     if (OH != (IH - 1) / stride + 1 || OW != (IW - 1) / stride + 1) return 0;
-    if (C % 4 != 0) return 0;
-    return 1;
+    return 1;      // any channel count: kernels walk ceil(C/4) quads and mask by C; pitches (multiples of 4) are checked by callers
 }
 
 // streaming (register-window) forward; the LDS-tiled variant lives in dwtile.hip, pq_dw3x3_fwd picks one per shape
 int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream) {
     DwP p{};
     p.in = a->in; p.w = a->w; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
-    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;
+    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
     EwGeom g = ew_geom((long)a->B * a->OH * a->OW, a->C);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     size_t sh = (size_t)g.cx * g.py * 8 * sizeof(float);
@@ -572,12 +571,12 @@ int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream) {
 
 extern "C" int pq_dw3x3_dgrad(const pq_dw3x3_dgrad_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->dy.g && a->w && a->dx.g, "null pointer");
-    PQ_CHECK_ARG(check_dw_common(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need C%4==0, stride 1|2, pad 1)");
+    PQ_CHECK_ARG(check_dw_common(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1, pitches that are multiples of 4)");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_dw3x3_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }
     DwP p{};
     p.dy = a->dy; p.w = a->w; p.sink = a->dx;
-    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;
+    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
     EwGeom g = ew_geom((long)a->B * a->IH * a->IW, a->C);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     size_t sh = (size_t)g.cx * g.py * 8 * sizeof(float);
@@ -612,10 +611,10 @@ extern "C" int64_t pq_dw3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_t O
 
 extern "C" int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->dw && a->scratch, "null pointer");
-    PQ_CHECK_ARG(check_dw_common(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need C%4==0, stride 1|2, pad 1)");
+    PQ_CHECK_ARG(check_dw_common(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1, pitches that are multiples of 4)");
     DwP p{};
     p.dy = a->dy; p.in = a->in; p.wpartial = a->scratch;
-    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;
+    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
     EwGeom g;
     dw_wgrad_blocks(a->B, a->OH, a->OW, a->C, &g);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
@@ -633,17 +632,17 @@ extern "C" int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream) {
 
 // ------------------------------------------------------------------------------------------------ stem host
 static int stem_check(int B, int CI, int IH, int IW, int OH, int OW, int O, int stride) {
-    if (B <= 0 || CI != 3 || O <= 0 || O % 4) return 0;
+    if (B <= 0 || CI != 3 || O <= 0) return 0;
     if (stride != 1 && stride != 2) return 0;
     return OH == (IH - 1) / stride + 1 && OW == (IW - 1) / stride + 1;
 }
 
 extern "C" int pq_stem3x3_fwd(const pq_stem3x3_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->image && a->w && a->out, "null pointer");
-    PQ_CHECK_ARG(stem_check(a->B, a->CI, a->IH, a->IW, a->OH, a->OW, a->O, a->stride), "unsupported stem shape (CI==3, O%4==0)");
+    PQ_CHECK_ARG(stem_check(a->B, a->CI, a->IH, a->IW, a->OH, a->OW, a->O, a->stride), "unsupported stem shape (CI==3)");
     StemP p{};
     p.img = a->image; p.w = a->w; p.out = a->out; p.partial = a->partial;
-    p.B = a->B; p.CI = a->CI; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.O = a->O; p.O4 = a->O / 4;
+    p.B = a->B; p.CI = a->CI; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.O = a->O; p.O4 = (a->O + 3) / 4;
     p.S = a->stride; p.ldo = a->ldo; p.ldp = a->ldp;
     EwGeom g = ew_geom((long)a->B * a->OH * a->OW, a->O);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
@@ -664,10 +663,10 @@ extern "C" int64_t pq_stem3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_t
 
 extern "C" int pq_stem3x3_wgrad(const pq_stem3x3_wgrad_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->dy.g && a->image && a->dw && a->scratch, "null pointer");
-    PQ_CHECK_ARG(stem_check(a->B, a->CI, a->IH, a->IW, a->OH, a->OW, a->O, a->stride), "unsupported stem shape (CI==3, O%4==0)");
+    PQ_CHECK_ARG(stem_check(a->B, a->CI, a->IH, a->IW, a->OH, a->OW, a->O, a->stride), "unsupported stem shape (CI==3)");
     StemP p{};
     p.img = a->image; p.dy = a->dy; p.wpartial = a->scratch;
-    p.B = a->B; p.CI = a->CI; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.O = a->O; p.O4 = a->O / 4; p.S = a->stride;
+    p.B = a->B; p.CI = a->CI; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.O = a->O; p.O4 = (a->O + 3) / 4; p.S = a->stride;
     EwGeom g;
     stem_wgrad_blocks(a->B, a->OH, a->OW, a->O, &g);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);

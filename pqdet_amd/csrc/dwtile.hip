@@ -563,7 +563,7 @@ __global__ __launch_bounds__(1024) void dwt_partial_reduce_kernel(const float* p
 using namespace pq;
 
 static int dwt_check(int B, int IH, int IW, int OH, int OW, int C, int stride) {
-    if (B <= 0 || IH <= 0 || IW <= 0 || C <= 0 || (C & 3)) return 0;
+    if (B <= 0 || IH <= 0 || IW <= 0 || C <= 0) return 0;      // any C: quads are ceil(C/4), masked by C
     if (stride != 1 && stride != 2) return 0;
     return OH == (IH - 1) / stride + 1 && OW == (IW - 1) / stride + 1;
 }
@@ -613,13 +613,13 @@ extern "C" int32_t pq_dw3x3_bwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_
 
 extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->in.x && a->w && a->out, "null pointer");
-    PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need C%4==0, stride 1|2, pad 1)");
+    PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1)");
     PQ_CHECK_ARG((a->in.ld & 3) == 0 && (a->ldo & 3) == 0, "pitches must be multiples of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     if (!dw_fwd_use_tiled(a->OH, a->OW, a->stride)) return pq_dw_fwd_stream(a, stream);
     DwTP p{};
     p.in = a->in; p.w = a->w; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
-    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;
+    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
     fwd_tiles(a->OH, a->OW, a->stride, p.tilesH, p.tilesW);
     dim3 grid(a->B * p.tilesH * p.tilesW, (p.C4 + CBQ - 1) / CBQ), blk(256);
     hipStream_t st = (hipStream_t)stream;
@@ -639,13 +639,13 @@ extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a->part == 2 || (a->w && a->dx.g), "input gradient needs w and the sink");
     PQ_CHECK_ARG(a->part == 1 || (a->in.x && a->dw && a->scratch), "weight gradient needs in, dw and scratch");
     PQ_CHECK_ARG(a->part == 0 || a->stride == 1, "the split backward exists for stride 1 only");
-    PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need C%4==0, stride 1|2, pad 1)");
+    PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1)");
     PQ_CHECK_ARG(a->stride == 1 || ((a->IH & 1) == 0 && (a->IW & 1) == 0), "stride-2 backward needs even input sizes");
     PQ_CHECK_ARG(a->part == 2 || !(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
     if ((a->part != 2 && act_is_special(a->dx.act)) || (a->part != 1 && act_is_special(a->in.act))) { pq_set_error("pq_dw3x3_bwd: logistic/tanh are not supported"); return PQ_EUNSUPPORTED; }
     DwTP p{};
     p.dy = a->dy; p.in = a->in; p.w = a->w; p.sink = a->dx; p.wpartial = a->scratch;
-    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = a->C / 4;
+    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
     bwd_tiles(a->IH, a->IW, a->stride, p.tilesH, p.tilesW);
     const int nblk = a->B * p.tilesH * p.tilesW;
     dim3 grid(nblk, (p.C4 + CBQ - 1) / CBQ), blk(256);

@@ -149,7 +149,19 @@ __global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_bwd_finalize_kernel(pq_bn_
 // ------------------------------------------------------------------------------------------------ copy / route
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
 
-struct CopyP { pq_copy_args a; int C4; };
+// 4 consecutive channels at an address that may not be 16-byte aligned / may straddle the end of the channel range
+// (concatenations of tensors whose channel counts are not multiples of 4): lanes with c0 + j >= C are not touched
+__device__ __forceinline__ float4 ldg4_masked(const float* p, int c0, int C) {
+    return make_float4(c0 < C ? p[0] : 0.f, c0 + 1 < C ? p[1] : 0.f, c0 + 2 < C ? p[2] : 0.f, c0 + 3 < C ? p[3] : 0.f);
+}
+__device__ __forceinline__ void stg4_masked(float* p, float4 v, int c0, int C) {
+    if (c0 < C) p[0] = v.x;
+    if (c0 + 1 < C) p[1] = v.y;
+    if (c0 + 2 < C) p[2] = v.z;
+    if (c0 + 3 < C) p[3] = v.w;
+}
+
+struct CopyP { pq_copy_args a; int C4; int unal; };
 
 __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
     const pq_copy_args& a = p.a;
@@ -177,11 +189,12 @@ __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
             const float4 z = ldg4(a.gate + (size_t)(r / (a.H * a.W)) * a.ldgate + c0);
             v = make_float4(v.x * sigmoidf_(z.x), v.y * sigmoidf_(z.y), v.z * sigmoidf_(z.z), v.w * sigmoidf_(z.w));
         }
-        stg4(a.out + (size_t)r * a.ldo + a.coff + c0, v);
+        float* dst = a.out + (size_t)r * a.ldo + a.coff + c0;
+        if (p.unal) stg4_masked(dst, v, c0, a.C); else stg4(dst, v);
     }
 }
 
-struct RouteP { pq_route_bwd_args a; int C4; };
+struct RouteP { pq_route_bwd_args a; int C4; int unal; };
 
 __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -197,10 +210,12 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     for (int r = bx * blockDim.y + threadIdx.y; r < rows && cok; r += gridDim.x * blockDim.y) {
         float4 dz = f4zero();
         if (a.bcast) {                                  // global average pool: every pixel of image b receives gout[b] * mul
-            const float4 gb = ldg4(a.gout + (size_t)(r / (a.H * a.W)) * a.ldgo + a.coff + c0);
+            const float* gp = a.gout + (size_t)(r / (a.H * a.W)) * a.ldgo + a.coff + c0;
+            const float4 gb = p.unal ? ldg4_masked(gp, c0, a.C) : ldg4(gp);
             dz = make_float4(gb.x * a.mul, gb.y * a.mul, gb.z * a.mul, gb.w * a.mul);
         } else if (a.up == 1) {
-            dz = ldg4(a.gout + (size_t)r * a.ldgo + a.coff + c0);
+            const float* gp = a.gout + (size_t)r * a.ldgo + a.coff + c0;
+            dz = p.unal ? ldg4_masked(gp, c0, a.C) : ldg4(gp);
             if (a.gate) {                               // scale_channels: d(feature) = gout * sigmoid(z)
                 const float4 z = ldg4(a.gate + (size_t)(r / (a.H * a.W)) * a.ldgate + c0);
                 dz = make_float4(dz.x * sigmoidf_(z.x), dz.y * sigmoidf_(z.y), dz.z * sigmoidf_(z.z), dz.w * sigmoidf_(z.w));
@@ -213,7 +228,8 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
             for (int dy = 0; dy < a.up; ++dy)
                 for (int dx = 0; dx < a.up; ++dx) {
                     const size_t orow = ((size_t)b * OH + (size_t)y * a.up + dy) * OW + (size_t)x * a.up + dx;
-                    dz = f4add(dz, ldg4(a.gout + orow * a.ldgo + a.coff + c0));
+                    const float* gp = a.gout + orow * a.ldgo + a.coff + c0;
+                    dz = f4add(dz, p.unal ? ldg4_masked(gp, c0, a.C) : ldg4(gp));
                 }
         }
         sink_emit4(a.dx, sk, (size_t)r, c0, dz, s1, s2);
@@ -371,11 +387,12 @@ extern "C" int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream
 extern "C" int pq_copy_fwd(const pq_copy_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->a.x && a->out, "null pointer");
     PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->up >= 1, "bad shape");
-    PQ_CHECK_ARG(a->C % 4 == 0 && a->coff % 4 == 0 && a->ldo % 4 == 0 && a->a.ld % 4 == 0, "channels / offsets / pitches must be multiples of 4");
+    PQ_CHECK_ARG(a->ldo % 4 == 0 && a->a.ld % 4 == 0 && (!a->b.x || a->b.ld % 4 == 0), "pitches must be multiples of 4");
+    PQ_CHECK_ARG(!a->gate || (a->C % 4 == 0 && a->coff % 4 == 0), "gated copy needs channel count / offset multiples of 4");
     PQ_CHECK_ARG(a->H % a->up == 0 && a->W % a->up == 0, "output size must be a multiple of the upsample factor");
     PQ_CHECK_ARG(!(a->b.x && a->up != 1), "second addend needs up==1");
     if (act_is_special(a->a.act) || (a->b.x && act_is_special(a->b.act))) { pq_set_error("pq_copy_fwd: logistic/tanh operands are not supported yet"); return PQ_EUNSUPPORTED; }
-    CopyP p{*a, a->C / 4};
+    CopyP p{*a, (a->C + 3) / 4, ((a->C & 3) || (a->coff & 3)) ? 1 : 0};   // odd widths / offsets: masked scalar stores
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
     hipLaunchKernelGGL(copy_fwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), 0, (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
@@ -385,10 +402,11 @@ extern "C" int pq_copy_fwd(const pq_copy_args* a, void* stream) {
 extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->gout && a->dx.g, "null pointer");
     PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->up >= 1, "bad shape");
-    PQ_CHECK_ARG(a->C % 4 == 0 && a->coff % 4 == 0 && a->ldgo % 4 == 0 && a->dx.ldg % 4 == 0, "channels / offsets / pitches must be multiples of 4");
+    PQ_CHECK_ARG(a->ldgo % 4 == 0 && a->dx.ldg % 4 == 0, "pitches must be multiples of 4");
+    PQ_CHECK_ARG(!(a->gate || a->bcast) || (a->C % 4 == 0 && a->coff % 4 == 0), "gated / broadcast routing needs multiples of 4");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_route_bwd: logistic/tanh sinks are not supported yet"); return PQ_EUNSUPPORTED; }
-    RouteP p{*a, a->C / 4};
+    RouteP p{*a, (a->C + 3) / 4, ((a->C & 3) || (a->coff & 3)) ? 1 : 0};
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
     hipLaunchKernelGGL(route_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float),
                        (hipStream_t)stream, p);

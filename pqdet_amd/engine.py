@@ -408,7 +408,7 @@ class Plan:
                 else:
                     Ctot = sum(s_.C for s_ in srcs)
                     ld = _round_up(Ctot, 4)
-                    raw = self._new(srcs[0].rows, ld)
+                    raw = self._new(srcs[0].rows, ld) if ld == Ctot else self._new(srcs[0].rows, ld, fill=0.0)
                     out = TensorRef(raw, srcs[0].B, srcs[0].H, srcs[0].W, Ctot, ld, None, 0)
                     off = 0
                     for s_ in srcs:
@@ -424,7 +424,7 @@ class Plan:
             elif t == 'upsample':
                 a = T[resolve(i - 1, i)]
                 f = int(m.scale_factor)
-                raw = self._new(a.rows * f * f, a.ld)
+                raw = self._new(a.rows * f * f, a.ld) if a.ld == a.C else self._new(a.rows * f * f, a.ld, fill=0.0)
                 out = TensorRef(raw, a.B, a.H * f, a.W * f, a.C, a.ld, None, 0)
                 self._deferred.append(('copy', i, out, a, None, 0, f))
                 T.append(out)

@@ -347,10 +347,19 @@ def test_conv1x1_bwd_fused_rejects_shapes_outside_its_range():
 
 # ----------------------------------------------------------------------------------------------- depthwise 3x3
 @pytest.mark.parametrize('B,H,W,Cc,stride', [(2, 9, 13, 32, 1), (2, 10, 14, 96, 2), (1, 7, 7, 144, 1), (2, 8, 8, 960, 1),
-                                             (1, 5, 9, 576, 2), (2, 40, 36, 48, 2), (1, 33, 50, 16, 1)])
+                                             (1, 5, 9, 576, 2), (2, 40, 36, 48, 2), (1, 33, 50, 16, 1),
+                                             # pruned nets: channel counts that are not multiples of 4 (pitch = ceil4)
+                                             (2, 9, 13, 25, 1), (2, 10, 14, 95, 2), (1, 12, 12, 142, 1), (2, 70, 66, 25, 1),
+                                             (1, 72, 68, 95, 2)])
 def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     g = torch.Generator().manual_seed(B * H * W + Cc)
     l = abi.lib()
+    P = (Cc + 3) // 4 * 4                          # channel pitch of every NHWC buffer; pad lanes hold zeros
+
+    def padc(t):
+        o = torch.zeros(*t.shape[:-1], P, device=DEV)
+        o[..., :Cc] = t.to(DEV)
+        return o
     x = rnd(B, H, W, Cc, g=g)
     sc, sh = torch.rand(Cc, generator=g) + 0.5, rnd(Cc, g=g, scale=0.3)
     w = rnd(Cc, 1, 3, 3, g=g, scale=0.4)
@@ -359,17 +368,18 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     y = F.conv2d(xin, wr, stride=stride, padding=1, groups=Cc)
     OH, OW = y.shape[2:]
     yn = y.permute(0, 2, 3, 1).contiguous()
-    xd, wd = x.to(DEV), w.to(DEV)
+    xd, wd = padc(x), w.to(DEV)
     scd, shd = chan_vec(sc), chan_vec(sh)
-    out = torch.full((B, OH, OW, Cc), float('nan'), device=DEV)
+    out = torch.full((B, OH, OW, P), float('nan'), device=DEV)
     nblk = l.pq_dw3x3_fwd_blocks(B, OH, OW, Cc, stride)
-    ldp = Cc
+    ldp = (Cc + 15) // 16 * 16
     partial = torch.zeros(nblk * 2 * ldp, device=DEV)
-    a = abi.DwFwd(abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), Cc, 2), wd.data_ptr(), out.data_ptr(), partial.data_ptr(),
-                  B, H, W, OH, OW, Cc, stride, Cc, ldp)
+    a = abi.DwFwd(abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), P, 2), wd.data_ptr(), out.data_ptr(), partial.data_ptr(),
+                  B, H, W, OH, OW, Cc, stride, P, ldp)
     abi.check(l.pq_dw3x3_fwd(C.byref(a), stream()))
     torch.cuda.synchronize()
-    close(out, yn, what='dw fwd')
+    close(out[..., :Cc], yn, what='dw fwd')
+    assert bool((out[..., Cc:] == 0).all())
     s1, s2 = reduce_partial(partial, nblk, ldp, Cc)
     close(s1.float(), yn.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='dw sum')
     close(s2.float(), (yn.double() ** 2).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='dw sumsq')
@@ -385,21 +395,21 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     gwant = dxin * ((u > 0) & (u < 6)).float()
     mean_in = x.view(-1, Cc).mean(0)
     inv_in = 1 / torch.sqrt(x.view(-1, Cc).var(0, unbiased=False) + 1e-5)
-    gyd, ynd = gy.to(DEV), yn.detach().to(DEV)
+    gyd, ynd = padc(gy), padc(yn.detach())
     vecs = [chan_vec(v) for v in (p, q, mu, r)]
     sv = [chan_vec(v) for v in (mean_in, inv_in)]
-    gdst = torch.full((B, H, W, Cc), float('nan'), device=DEV)
+    gdst = torch.full((B, H, W, P), float('nan'), device=DEV)
     nb2 = l.pq_dw3x3_blocks(B, H, W, Cc)
     part2 = torch.zeros(nb2 * 2 * ldp, device=DEV)
     d = abi.DwDgrad()
-    d.dy = abi.GSrc(gyd.data_ptr(), ynd.data_ptr(), *[v.data_ptr() for v in vecs], Cc, Cc)
+    d.dy = abi.GSrc(gyd.data_ptr(), ynd.data_ptr(), *[v.data_ptr() for v in vecs], P, P)
     d.w = wd.data_ptr()
     d.dx = abi.GSink(gdst.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
-                     part2.data_ptr(), Cc, Cc, 2, 0, 1, ldp)
+                     part2.data_ptr(), P, P, 2, 0, 1, ldp)
     d.B, d.IH, d.IW, d.OH, d.OW, d.C, d.stride = B, H, W, OH, OW, Cc, stride
     abi.check(l.pq_dw3x3_dgrad(C.byref(d), stream()))
     torch.cuda.synchronize()
-    close(gdst, gwant, what='dw dgrad')
+    close(gdst[..., :Cc], gwant, what='dw dgrad')
     s1, s2 = reduce_partial(part2, nb2, ldp, Cc)
     xh = (x.double() - mean_in.double()) * inv_in.double()
     close(s1.float(), gwant.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='dw dgrad sum')
@@ -419,27 +429,27 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     # fused, LDS-tiled backward entry point: same results from one kernel (stride 2 needs even input sizes)
     if stride == 2 and (H % 2 or W % 2):
         return
-    gdst2 = torch.full((B, H, W, Cc), float('nan'), device=DEV)
+    gdst2 = torch.full((B, H, W, P), float('nan'), device=DEV)
     nb3 = l.pq_dw3x3_bwd_blocks(B, H, W, stride)
     part3 = torch.zeros(nb3 * 2 * ldp, device=DEV)
     dw2 = torch.full((Cc, 9), float('nan'), device=DEV)
     sc2 = torch.empty(l.pq_dw3x3_bwd_scratch_bytes(B, H, W, OH, OW, Cc, stride) // 4 + 16, device=DEV)
     fb = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(gdst2.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
-                                                         sv[1].data_ptr(), part3.data_ptr(), Cc, Cc, 2, 0, 1, ldp),
+                                                         sv[1].data_ptr(), part3.data_ptr(), P, P, 2, 0, 1, ldp),
                    dw2.data_ptr(), sc2.data_ptr(), B, H, W, OH, OW, Cc, stride)
     abi.check(l.pq_dw3x3_bwd(C.byref(fb), stream()))
     torch.cuda.synchronize()
-    close(gdst2, gwant, what='fused dw dgrad')
+    close(gdst2[..., :Cc], gwant, what='fused dw dgrad')
     close(dw2.view(Cc, 1, 3, 3), wr.grad, rt=1e-3, at=1e-3, what='fused dw wgrad')
     t1, t2 = reduce_partial(part3, nb3, ldp, Cc)
     close(t1.float(), gwant.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum')
     close(t2.float(), (gwant.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum xhat')
     if stride == 1:
         # the two halves on their own (the engine runs the weight half on the weight-gradient stream): bit-identical
-        g3 = torch.full((B, H, W, Cc), float('nan'), device=DEV)
+        g3 = torch.full((B, H, W, P), float('nan'), device=DEV)
         p3 = torch.zeros(nb3 * 2 * ldp, device=DEV)
         h1 = abi.DwBwd(d.dy, abi.Src(), wd.data_ptr(), abi.GSink(g3.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
-                                                                  sv[1].data_ptr(), p3.data_ptr(), Cc, Cc, 2, 0, 1, ldp),
+                                                                  sv[1].data_ptr(), p3.data_ptr(), P, P, 2, 0, 1, ldp),
                        None, None, B, H, W, OH, OW, Cc, stride, 1)
         abi.check(l.pq_dw3x3_bwd(C.byref(h1), stream()))
         dw3 = torch.full((Cc, 9), float('nan'), device=DEV)
@@ -748,6 +758,59 @@ def test_copy_and_route():
     torch.cuda.synchronize()
     close(gdst, gw, what='route bwd')
     t1, t2 = reduce_partial(part, nblk, C1, C1)
+    close(t1.float(), gw.double().sum((0, 1, 2)).float(), at=1e-3)
+    xh = (a1.double() - mean.double()) * inv.double()
+    close(t2.float(), (gw.double() * xh).sum((0, 1, 2)).float(), at=1e-3)
+
+
+def test_copy_and_route_with_channel_counts_that_are_not_multiples_of_four():
+    """Pruned nets concatenate e.g. 25 + 95 channels: the second slice starts at an unaligned offset and the first one ends
+    inside a quad.  Pitches stay multiples of 4; pad lanes are never written."""
+    g = torch.Generator().manual_seed(9)
+    l = abi.lib()
+    B, H, W, C1, C2 = 2, 4, 6, 25, 95
+    P1, P2, PT = 28, 96, 120                       # pitches: ceil4 of each width; the concatenation is dense (120 = 25 + 95)
+    a1 = rnd(B, H // 2, W // 2, C1, g=g)
+    s1, h1 = torch.rand(C1, generator=g) + 0.5, rnd(C1, g=g)
+    a2 = rnd(B, H, W, C2, g=g)
+    want = torch.cat([F.interpolate((a1 * s1 + h1).clamp(0, 6).permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1), a2], -1)
+    out = torch.full((B, H, W, PT), float('nan'), device=DEV)
+    a1d = torch.zeros(B, H // 2, W // 2, P1, device=DEV); a1d[..., :C1] = a1.to(DEV)
+    a2d = torch.zeros(B, H, W, P2, device=DEV); a2d[..., :C2] = a2.to(DEV)
+    s1d, h1d = chan_vec(s1), chan_vec(h1)
+    none = abi.Src(None, None, None, 0, 0)
+    c = abi.Copy(abi.Src(a1d.data_ptr(), s1d.data_ptr(), h1d.data_ptr(), P1, 2), none, out.data_ptr(), B, H, W, C1, PT, 0, 2)
+    abi.check(l.pq_copy_fwd(C.byref(c), stream()))
+    c = abi.Copy(abi.Src(a2d.data_ptr(), None, None, P2, 0), none, out.data_ptr(), B, H, W, C2, PT, C1, 1)
+    abi.check(l.pq_copy_fwd(C.byref(c), stream()))
+    torch.cuda.synchronize()
+    close(out[..., :C1 + C2], want, what='unaligned route cat + upsample')
+    # backward of both slices: the upsampled one finalises relu6' with statistics, the plain one accumulates
+    gout = rnd(B, H, W, C1 + C2, g=g)
+    goutd = torch.zeros(B, H, W, PT, device=DEV); goutd[..., :C1 + C2] = gout.to(DEV)
+    dz = gout[..., :C1].reshape(B, H // 2, 2, W // 2, 2, C1).sum((2, 4))
+    u = a1 * s1 + h1
+    gw = dz * ((u > 0) & (u < 6)).float()
+    mean = a1.reshape(-1, C1).mean(0)
+    inv = 1 / torch.sqrt(a1.reshape(-1, C1).var(0, unbiased=False) + 1e-5)
+    md, idv = chan_vec(mean), chan_vec(inv)
+    gdst = torch.zeros(B, H // 2, W // 2, P1, device=DEV)
+    nblk = l.pq_ew_blocks(B * (H // 2) * (W // 2), C1)
+    ldp = 32
+    part = torch.zeros(nblk * 2 * ldp, device=DEV)
+    r = abi.RouteBwd(goutd.data_ptr(), abi.GSink(gdst.data_ptr(), a1d.data_ptr(), s1d.data_ptr(), h1d.data_ptr(), md.data_ptr(),
+                                                 idv.data_ptr(), part.data_ptr(), P1, P1, 2, 0, 1, ldp), B, H // 2, W // 2, C1, PT, 0, 2)
+    abi.check(l.pq_route_bwd(C.byref(r), stream()))
+    old = rnd(B, H, W, C2, g=g)
+    g2 = torch.zeros(B, H, W, P2, device=DEV); g2[..., :C2] = old.to(DEV)
+    r2 = abi.RouteBwd(goutd.data_ptr(), abi.GSink(g2.data_ptr(), a2d.data_ptr(), None, None, None, None, None, P2, P2, 0, 1, 0, 0),
+                      B, H, W, C2, PT, C1, 1)
+    abi.check(l.pq_route_bwd(C.byref(r2), stream()))
+    torch.cuda.synchronize()
+    close(gdst[..., :C1], gw, what='unaligned route bwd (slice 0)')
+    assert bool((gdst[..., C1:] == 0).all()) and bool((g2[..., C2:] == 0).all()), 'pad lanes must stay zero'
+    close(g2[..., :C2], old + gout[..., C1:], what='unaligned route bwd (slice at offset 25)')
+    t1, t2 = reduce_partial(part, nblk, ldp, C1)
     close(t1.float(), gw.double().sum((0, 1, 2)).float(), at=1e-3)
     xh = (a1.double() - mean.double()) * inv.double()
     close(t2.float(), (gw.double() * xh).sum((0, 1, 2)).float(), at=1e-3)
