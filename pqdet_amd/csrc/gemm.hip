@@ -691,6 +691,25 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* slab, si
     }
 }
 
+// few slabs, many columns (the usual wgrad case: <= 64 row splits of a large O x I matrix): one thread per column, 8 loads in
+// flight, every wave reads 256 contiguous bytes per slab
+__global__ __launch_bounds__(256) void slab_reduce_cols_kernel(const float* slab, size_t stride, int splits, float* out0, int n0, float* out1, int n1) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n0 + n1) return;
+    const float* src = slab + j;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; ++k) s += src[(size_t)k * stride];
+    if (j < n0) out0[j] = s; else out1[j - n0] = s;
+}
+
 }  // namespace pq
 
 using namespace pq;
@@ -850,6 +869,12 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
     else hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
     const int n0 = a->O * a->I, n1 = a->dbias ? a->O : 0;
+    if (splits <= 64) {
+        hipLaunchKernelGGL(slab_reduce_cols_kernel, dim3((n0 + n1 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
+                           p.slab_stride, splits, a->dw, n0, a->dbias, n1);
+        PQ_CHECK_LAUNCH();
+        return PQ_OK;
+    }
     const int rb = (n0 + n1 + 31) / 32;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(32, 32), 0, st, (const float*)a->scratch, p.slab_stride, splits,
                        a->dw, n0, a->dbias, n1);

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round profile on a GPU box: kernel trace + stats of bench.py, then the two HBM counter passes (separate runs, counters only
+# with --kernel-trace), then the joined summary.  Output: gpurun_out/prof/{stats,fetch,write}/ and gpurun_out/prof/*.csv|json
+# usage (from the repo root on the GPU box): bash scripts/profile_round.sh
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r1 -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+echo "stats pass done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r1 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/fetch.log
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r1 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/write.log
+echo "write pass done"
+cd $ROOT
+S=$(dirname $(find $OUT/stats -name 'r1*kernel_stats.csv' | head -1))
+F=$(dirname $(find $OUT/fetch -name 'r1*counter_collection.csv' | head -1))
+W=$(dirname $(find $OUT/write -name 'r1*counter_collection.csv' | head -1))
+python3 scripts/pmc_summary.py $S $F $W r1 > $OUT/r1_pmc_summary.csv
+cp $(find $OUT/stats -name 'r1*kernel_stats.csv' | head -1) $OUT/r1_kernel_stats.csv
+rm -rf $OUT/fetch $OUT/write $OUT/stats
+echo "summary done"
