@@ -832,7 +832,7 @@ static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, 
     const int b = big ? 128 : 64;
     tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
     static const char* tgt_env = getenv("PQ_WG_TARGET");
-    const int target = tgt_env ? atoi(tgt_env) : 768;
+    const int target = tgt_env ? atoi(tgt_env) : 512;
     int want = (target + tiles - 1) / tiles;
     int maxs = (M + 255) / 256;
     splits = want < 1 ? 1 : (want > maxs ? maxs : want);

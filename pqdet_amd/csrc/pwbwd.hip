@@ -20,7 +20,7 @@ struct PwP {
     pq_gsrc dy; pq_src x; pq_gsink dx;
     const float* w;      // [O][I]
     float* slab;         // [gridDim.x][O*I]
-    int M, I, O, LDZ, LDX, tiles, dbg;
+    int M, I, O, LDZ, LDX, tiles;
 };
 
 constexpr int PW_BM = 64;     // rows per tile
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
         const int m0 = tile * PW_BM;
         __syncthreads();                          // previous tile's epilogue has read xs; Ws is written (first pass)
-        if (zact && !(p.dbg & 1)) {
+        if (zact) {
             const GsrcCoef4 gk = gcoef();
             for (int r0 = zy; r0 < PW_BM; r0 += PW_NB * PYz) {
                 float4 g[PW_NB], y[PW_NB];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
                 }
             }
         }
-        if (iact && !(p.dbg & 1)) {
+        if (iact) {
             const SrcCoef4 xk = xcoef();
             for (int r0 = iy; r0 < PW_BM; r0 += PW_NB * PYi) {
                 float4 xv[PW_NB];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
         for (int s_ = 0; s_ < KS; ++s_)
 #pragma unroll
             for (int c = 0; c < TD; ++c) ad[s_][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(p.dbg & 2)) {
+        {
             const float* arow = dzs + (16 * w + l16) * LDZ + lq;
             const float* brow = Ws + lq * LDX + l16;
             int k0 = 0;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
         }
         // weight gradient: wave w owns the 16-wide tiles w, w+4, w+8 of the wide side x both tiles of the narrow side;
         // contraction over the 64 rows; all (up to 6) accumulator chains advance together
-        if (!(p.dbg & 4)) {
+        {
             const float* ap = dzs + lq * LDZ + l16 + (OWIDE ? 16 * w : 0);
             const float* bp = xs + lq * LDX + l16 + (OWIDE ? 0 : 16 * w);
             const int wide16 = OWIDE ? O16 : I16, narrow16 = OWIDE ? I16 : O16;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
             }
         }
         __syncthreads();
-        if (iact && !(p.dbg & 8)) {
+        if (iact) {
             const SinkCoef4 sk = scoef();
             for (int r0 = iy; r0 < PW_BM; r0 += PW_NB * PYi) {
                 float4 go[PW_NB], yv[PW_NB];
@@ -401,8 +401,6 @@ extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
     PwP p{};
     p.dy = a->dy; p.x = a->in; p.dx = a->dx; p.w = a->w; p.slab = a->scratch;
     p.M = a->M; p.I = a->I; p.O = a->O; p.LDZ = pl.ldz; p.LDX = pl.ldx; p.tiles = pl.tiles;
-    static const char* dbg_env = getenv("PQ_PW_DBG");
-    p.dbg = dbg_env ? atoi(dbg_env) : 0;
     hipStream_t st = (hipStream_t)stream;
     const int i16 = (a->I + 15) / 16;
     int rc;
