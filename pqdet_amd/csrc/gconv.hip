@@ -33,14 +33,105 @@ constexpr int GTH = 8, GTW = 16;          // output tile
 
 __device__ __forceinline__ f32x16 gmfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-template <int EMODE>     // 1: raw store + BN statistics, 2: gradient sink
+// ---- operand tile staging.  A thread owns ONE channel quad (coefficients live in registers) and walks pixels; the loads
+// of four pixels are issued back to back at clamped (always valid) coordinates and masked afterwards -- a load inside an
+// `if` per element made the staging loop one memory latency per iteration, which dominated the stride-2 layers.
+constexpr int GUB = 4;
+template <int ITW, int NPIX>
+__device__ __forceinline__ void gc_stage_src(float4* At, int pitch, int gq, int cbase, int b, int ay0, int ax0, int AH, int AW,
+                                             const pq_src& in, int t) {
+    const int qd = t % gq, pl = t / gq, PL = 256 / gq;
+    if (pl >= PL) return;
+    const int c = cbase + 4 * qd;
+    const ActParam aact = act_param(in.act);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = in.scale ? in.scale[c + j] : 1.f; sh[j] = in.scale ? in.shift[c + j] : 0.f; }
+    const bool fq = in.qstate != nullptr;
+    const float qs = fq ? in.qstate[2] : 1.f, qinv = fq ? 1.f / qs : 1.f, qzp = fq ? in.qstate[3] : 0.f;
+    const float* base = in.x + (size_t)b * AH * AW * in.ld + c;
+    for (int pix0 = pl; pix0 < NPIX; pix0 += GUB * PL) {
+        float4 r[GUB];
+        bool ok[GUB];
+#pragma unroll
+        for (int u = 0; u < GUB; ++u) {
+            const int pix = pix0 + u * PL, pc = min(pix, NPIX - 1);
+            const int py = pc / ITW, px = pc - py * ITW;
+            const int ay = ay0 + py, ax = ax0 + px;
+            ok[u] = pix < NPIX && ay >= 0 && ay < AH && ax >= 0 && ax < AW;
+            const int yy = min(max(ay, 0), AH - 1), xx = min(max(ax, 0), AW - 1);
+            r[u] = ldg4(base + ((size_t)yy * AW + xx) * in.ld);
+        }
+#pragma unroll
+        for (int u = 0; u < GUB; ++u) {
+            const int pix = pix0 + u * PL;
+            if (pix < NPIX) {
+                float e4[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e4[j] = act_fwd(fmaf(sc[j], e4[j], sh[j]), aact);
+                    if (fq) e4[j] = fq_act(e4[j], qs, qinv, qzp);
+                }
+                At[pix * pitch + qd] = ok[u] ? make_float4(e4[0], e4[1], e4[2], e4[3]) : f4zero();
+            }
+        }
+    }
+}
+// gradient operand dy' = p*g + q*(y-mu) + r on a PH x PW plane; up: the tile lives on the zero-inserted (2x) grid
+template <int ITW, int NPIX>
+__device__ __forceinline__ void gc_stage_gsrc(float4* At, int pitch, int gq, int cbase, int b, int ay0, int ax0, int AH, int AW,
+                                              const pq_gsrc& dy, int up, int DH, int DW, int t) {
+    const int qd = t % gq, pl = t / gq, PL = 256 / gq;
+    if (pl >= PL) return;
+    const int c = cbase + 4 * qd;
+    const bool two = dy.y != nullptr;
+    float cp[4], cq[4], cm[4], cr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cp[j] = two ? dy.p[c + j] : 1.f; cq[j] = two ? dy.q[c + j] : 0.f; cm[j] = two ? dy.mu[c + j] : 0.f; cr[j] = two ? dy.r[c + j] : 0.f;
+    }
+    const int PH = up ? DH : AH, PW = up ? DW : AW;
+    const float* gb = dy.g + (size_t)b * PH * PW * dy.ldg + c;
+    const float* yb = two ? dy.y + (size_t)b * PH * PW * dy.ldy + c : nullptr;
+    for (int pix0 = pl; pix0 < NPIX; pix0 += GUB * PL) {
+        float4 rg[GUB], ry[GUB];
+        bool ok[GUB];
+#pragma unroll
+        for (int u = 0; u < GUB; ++u) {
+            const int pix = pix0 + u * PL, pc = min(pix, NPIX - 1);
+            const int py = pc / ITW, px = pc - py * ITW;
+            const int ay = ay0 + py, ax = ax0 + px;
+            bool in = pix < NPIX && ay >= 0 && ay < AH && ax >= 0 && ax < AW;
+            int yy = min(max(ay, 0), AH - 1), xx = min(max(ax, 0), AW - 1);
+            if (up) { in = in && !(ay & 1) && !(ax & 1); yy >>= 1; xx >>= 1; in = in && yy < DH && xx < DW; yy = min(yy, DH - 1); xx = min(xx, DW - 1); }
+            ok[u] = in;
+            const size_t row = (size_t)yy * PW + xx;
+            rg[u] = ldg4(gb + row * dy.ldg);
+            ry[u] = two ? ldg4(yb + row * dy.ldy) : f4zero();
+        }
+#pragma unroll
+        for (int u = 0; u < GUB; ++u) {
+            const int pix = pix0 + u * PL;
+            if (pix < NPIX) {
+                float e4[4] = {rg[u].x, rg[u].y, rg[u].z, rg[u].w};
+                const float y4[4] = {ry[u].x, ry[u].y, ry[u].z, ry[u].w};
+                if (two) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e4[j] = fmaf(cp[j], e4[j], fmaf(cq[j], y4[j] - cm[j], cr[j]));
+                }
+                At[pix * pitch + qd] = ok[u] ? make_float4(e4[0], e4[1], e4[2], e4[3]) : f4zero();
+            }
+        }
+    }
+}
+
+template <int EMODE, int S>     // EMODE 1: raw store + BN statistics, 2: gradient sink; S: stride of the tile walk (dgrad: 1)
 __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int gw = p.gw, gq = gw >> 2, pitch = gq + 1;          // quads per pixel (+1 pad)
     const int K = 9 * gw, KP = K + 4;
-    const int S = p.S;
-    const int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3;
+    constexpr int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3;
     float4* At = reinterpret_cast<float4*>(smem);                       // [ITH*ITW][pitch]
     float* Bt = smem + (size_t)ITH * ITW * pitch * 4;                   // [32][KP]
     float* red = Bt + 32 * KP;                                          // [2][4][32]
@@ -53,57 +144,30 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
     const int cbase = g * gw;
 
     // ---- stage A (operand tile with halo)
-    const int npix = ITH * ITW;
-    const ActParam aact = act_param(p.in.act);
-    for (int e = t; e < npix * gq; e += 256) {
-        const int pix = e / gq, qd = e - pix * gq;
-        const int py = pix / ITW, px = pix - py * ITW;
-        const int ay = ay0 + py, ax = ax0 + px;
-        const int c = cbase + 4 * qd;
-        bool ok = ay >= 0 && ay < p.AH && ax >= 0 && ax < p.AW;
-        float4 v = f4zero();
-        if (!p.grad) {
-            if (ok) {
-                const float4 r = ldg4(p.in.x + (((size_t)b * p.AH + ay) * p.AW + ax) * p.in.ld + c);
-                float e4[4] = {r.x, r.y, r.z, r.w};
+    if (!p.grad) gc_stage_src<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.in, t);
+    else gc_stage_gsrc<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.dy, p.up, p.DH, p.DW, t);
+    // ---- stage B (this group's weights, k = tap*gw + i): row n = t/8, eight lanes walk k; four loads in flight
+    {
+        const int n = t >> 3, kk = t & 7;
+        const int nc = min(n, gw - 1);
+        int tap = 0, j = kk;
+        while (j >= gw) { j -= gw; ++tap; }
+        for (int k0 = kk; k0 < K; k0 += 8 * GUB) {
+            float v[GUB];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float sc = p.in.scale ? p.in.scale[c + j] : 1.f, sh = p.in.scale ? p.in.shift[c + j] : 0.f;
-                    e4[j] = act_fwd(fmaf(sc, e4[j], sh), aact);
-                    if (p.in.qstate) e4[j] = fq_act(e4[j], p.in.qstate[2], 1.f / p.in.qstate[2], p.in.qstate[3]);
-                }
-                v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            for (int u = 0; u < GUB; ++u) {
+                const int tc = min(tap, 8);
+                const size_t idx = p.wmode == 0 ? ((size_t)(cbase + nc) * gw + j) * 9 + tc : ((size_t)(cbase + j) * gw + nc) * 9 + (8 - tc);
+                v[u] = p.w[idx];
+                j += 8;
+                while (j >= gw) { j -= gw; ++tap; }
             }
-        } else {
-            int dyy = ay, dxx = ax;
-            if (p.up) { ok = ok && !(ay & 1) && !(ax & 1); dyy = ay >> 1; dxx = ax >> 1; ok = ok && dyy < p.DH && dxx < p.DW; }
-            if (ok) {
-                const int PH = p.up ? p.DH : p.AH, PW = p.up ? p.DW : p.AW;
-                const size_t r = ((size_t)b * PH + dyy) * PW + dxx;
-                const float4 gg = ldg4(p.dy.g + r * p.dy.ldg + c);
-                float e4[4] = {gg.x, gg.y, gg.z, gg.w};
-                if (p.dy.y) {
-                    const float4 yy = ldg4(p.dy.y + r * p.dy.ldy + c);
-                    const float y4[4] = {yy.x, yy.y, yy.z, yy.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        e4[j] = fmaf(p.dy.p[c + j], e4[j], fmaf(p.dy.q[c + j], y4[j] - p.dy.mu[c + j], p.dy.r[c + j]));
-                }
-                v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            for (int u = 0; u < GUB; ++u) {
+                const int k = k0 + 8 * u;
+                if (k < K) Bt[n * KP + k] = n < gw ? v[u] : 0.f;
             }
         }
-        At[pix * pitch + qd] = v;
-    }
-    // ---- stage B (this group's weights, k = tap*gw + i)
-    for (int e = t; e < 32 * K; e += 256) {
-        const int n = e / K, k = e - n * K;
-        const int tap = k / gw, j = k - tap * gw;
-        float v = 0.f;
-        if (n < gw) {
-            if (p.wmode == 0) v = p.w[((size_t)(cbase + n) * gw + j) * 9 + tap];           // n = o, j = i
-            else v = p.w[((size_t)(cbase + j) * gw + n) * 9 + (8 - tap)];                  // n = i, j = o, flipped tap
-        }
-        Bt[n * KP + k] = v;
     }
     __syncthreads();
 
@@ -224,20 +288,19 @@ struct GcWP {
     int B, IH, IW, OH, OW, C, gw, S, tilesH, tilesW, nsplit;
 };
 
-template <int NC>      // 32-wide column chunks of the (tap, i) axis: ceil(9*gw/32) <= NC
+template <int NC, int S>      // NC: 32-wide column chunks of the (tap, i) axis, ceil(9*gw/32) <= NC; S: stride
 __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GcWP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int gw = p.gw, gq = gw >> 2, pitch = gq + 1, S = p.S;
+    const int gw = p.gw, gq = gw >> 2, pitch = gq + 1;
     const int K = 9 * gw, NCH = (K + 31) / 32;
-    const int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3;
+    constexpr int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3;
     float* Xt = smem;                                            // [ITH*ITW][pitch*4]
     float* Yt = Xt + (size_t)ITH * ITW * pitch * 4;              // [128][32]  dy' (o padded to 32)
     float* red = Yt + 128 * 32;                                  // [4][32*32]
     const int g = blockIdx.x, split = blockIdx.y;
     const int cbase = g * gw;
     const int ntiles = p.B * p.tilesH * p.tilesW;
-    const ActParam aact = act_param(p.in.act);
     const int lrow = lane & 31, lh = lane >> 5;
 
     f32x16 acc[NC];
@@ -259,51 +322,50 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GcWP p) {
         boff[c] = (ky * ITW + kx) * pitch * 4 + i;
     }
 
+    float yc[4][4];          // p, q, mu, r of this thread's dy' channel quad (t & 7)
+    {
+        const int qd = t & 7;
+        const int c = cbase + 4 * (qd < gq ? qd : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            yc[0][j] = p.dy.y ? p.dy.p[c + j] : 1.f; yc[1][j] = p.dy.y ? p.dy.q[c + j] : 0.f;
+            yc[2][j] = p.dy.y ? p.dy.mu[c + j] : 0.f; yc[3][j] = p.dy.y ? p.dy.r[c + j] : 0.f;
+        }
+    }
     for (int tile = split; tile < ntiles; tile += p.nsplit) {
         const int tw = tile % p.tilesW, th = (tile / p.tilesW) % p.tilesH, b = tile / (p.tilesW * p.tilesH);
         const int oy0 = th * GTH, ox0 = tw * GTW;
         const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
         __syncthreads();
         // stage x' tile
-        for (int e = t; e < ITH * ITW * gq; e += 256) {
-            const int pix = e / gq, qd = e - pix * gq;
-            const int py = pix / ITW, px = pix - py * ITW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const int c = cbase + 4 * qd;
-            float4 v = f4zero();
-            if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) {
-                const float4 r = ldg4(p.in.x + (((size_t)b * p.IH + iy) * p.IW + ix) * p.in.ld + c);
-                float e4[4] = {r.x, r.y, r.z, r.w};
+        gc_stage_src<ITW, ITH * ITW>(reinterpret_cast<float4*>(Xt), pitch, gq, cbase, b, iy0, ix0, p.IH, p.IW, p.in, t);
+        // stage dy' tile: [pixel 0..127][o 0..31]; thread = (quad t&7, pixel lane t>>3), four pixels in flight
+        {
+            const int qd = t & 7, pl = t >> 3;
+            const bool qok = qd < gq;
+            const int c = cbase + 4 * (qok ? qd : 0);
+            float4 rg[4], ry[4];
+            bool ok[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float sc = p.in.scale ? p.in.scale[c + j] : 1.f, sh = p.in.scale ? p.in.shift[c + j] : 0.f;
-                    e4[j] = act_fwd(fmaf(sc, e4[j], sh), aact);
-                    if (p.in.qstate) e4[j] = fq_act(e4[j], p.in.qstate[2], 1.f / p.in.qstate[2], p.in.qstate[3]);
-                }
-                v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            for (int u = 0; u < 4; ++u) {
+                const int pix = pl + 32 * u;
+                const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+                ok[u] = qok && oy < p.OH && ox < p.OW;
+                const size_t r = ((size_t)b * p.OH + min(oy, p.OH - 1)) * p.OW + min(ox, p.OW - 1);
+                rg[u] = ldg4(p.dy.g + r * p.dy.ldg + c);
+                ry[u] = p.dy.y ? ldg4(p.dy.y + r * p.dy.ldy + c) : f4zero();
             }
-            *reinterpret_cast<float4*>(&Xt[(pix * pitch + qd) * 4]) = v;
-        }
-        // stage dy' tile: [pixel 0..127][o 0..31]
-        for (int e = t; e < 128 * 8; e += 256) {
-            const int pix = e >> 3, qd = e & 7;
-            const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
-            float4 v = f4zero();
-            if (qd < gq && oy < p.OH && ox < p.OW) {
-                const int c = cbase + 4 * qd;
-                const size_t r = ((size_t)b * p.OH + oy) * p.OW + ox;
-                const float4 gg = ldg4(p.dy.g + r * p.dy.ldg + c);
-                float e4[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pix = pl + 32 * u;
+                float e4[4] = {rg[u].x, rg[u].y, rg[u].z, rg[u].w};
                 if (p.dy.y) {
-                    const float4 yy = ldg4(p.dy.y + r * p.dy.ldy + c);
-                    const float y4[4] = {yy.x, yy.y, yy.z, yy.w};
+                    const float y4[4] = {ry[u].x, ry[u].y, ry[u].z, ry[u].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        e4[j] = fmaf(p.dy.p[c + j], e4[j], fmaf(p.dy.q[c + j], y4[j] - p.dy.mu[c + j], p.dy.r[c + j]));
+                    for (int j = 0; j < 4; ++j) e4[j] = fmaf(yc[0][j], e4[j], fmaf(yc[1][j], y4[j] - yc[2][j], yc[3][j]));
                 }
-                v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                *reinterpret_cast<float4*>(&Yt[pix * 32 + 4 * qd]) = ok[u] ? make_float4(e4[0], e4[1], e4[2], e4[3]) : f4zero();
             }
-            *reinterpret_cast<float4*>(&Yt[pix * 32 + 4 * qd]) = v;
         }
         __syncthreads();
         // wave wv: pixels 32*wv .. +31 (k dimension), 16 steps of 2 pixels
@@ -377,8 +439,14 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
     p.B = a->B; p.AH = a->IH; p.AW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.gw = a->gw; p.S = a->stride;
     p.tilesH = (a->OH + GTH - 1) / GTH; p.tilesW = (a->OW + GTW - 1) / GTW;
     const size_t lds = gc_lds_bytes(a->gw, a->stride);
-    (void)hipFuncSetAttribute((const void*)gconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((gconv_kernel<1>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
+    const dim3 grid(a->B * p.tilesH * p.tilesW, a->C / a->gw);
+    if (a->stride == 1) {
+        (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((gconv_kernel<1, 1>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((gconv_kernel<1, 2>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -396,8 +464,8 @@ extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) 
     if (a->stride == 1) { p.AH = a->OH; p.AW = a->OW; }
     p.tilesH = (a->IH + GTH - 1) / GTH; p.tilesW = (a->IW + GTW - 1) / GTW;
     const size_t lds = gc_lds_bytes(a->gw, 1);
-    (void)hipFuncSetAttribute((const void*)gconv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((gconv_kernel<2>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
+    (void)hipFuncSetAttribute((const void*)gconv_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((gconv_kernel<2, 1>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -427,16 +495,18 @@ extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) 
     const size_t lds = ((size_t)ITH * ITW * pitch * 4 + 128 * 32 + 4 * 1024) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int nch = (9 * a->gw + 31) / 32;
-    if (nch <= 5) {
-        (void)hipFuncSetAttribute((const void*)gconv_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(gconv_wgrad_kernel<5>, dim3(G, p.nsplit), dim3(256), lds, st, p);
-    } else if (nch <= 7) {
-        (void)hipFuncSetAttribute((const void*)gconv_wgrad_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(gconv_wgrad_kernel<7>, dim3(G, p.nsplit), dim3(256), lds, st, p);
+    const dim3 wgrid(G, p.nsplit);
+#define PQ_GCW_LAUNCH(NCH_, S_)                                                                                              \
+    do {                                                                                                                     \
+        (void)hipFuncSetAttribute((const void*)gconv_wgrad_kernel<NCH_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((gconv_wgrad_kernel<NCH_, S_>), wgrid, dim3(256), lds, st, p);                                     \
+    } while (0)
+    if (S == 1) {
+        if (nch <= 5) PQ_GCW_LAUNCH(5, 1); else if (nch <= 7) PQ_GCW_LAUNCH(7, 1); else PQ_GCW_LAUNCH(9, 1);
     } else {
-        (void)hipFuncSetAttribute((const void*)gconv_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(gconv_wgrad_kernel<9>, dim3(G, p.nsplit), dim3(256), lds, st, p);
+        if (nch <= 5) PQ_GCW_LAUNCH(5, 2); else if (nch <= 7) PQ_GCW_LAUNCH(7, 2); else PQ_GCW_LAUNCH(9, 2);
     }
+#undef PQ_GCW_LAUNCH
     PQ_CHECK_LAUNCH();
     const int total = G * a->gw * 9 * a->gw;
     hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)a->scratch, G, p.nsplit, a->gw, a->dw);
