@@ -368,19 +368,20 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GcWP p) {
             }
         }
         __syncthreads();
-        // wave wv: pixels 32*wv .. +31 (k dimension), 16 steps of 2 pixels
+        // wave wv: pixels 32*wv .. +31 (k dimension), 16 steps of 2 pixels.  All NC chunks are multiplied (columns past
+        // 9*gw read a valid offset and are masked to zero): the operands of a step are fetched from LDS first and the MFMAs
+        // follow back to back -- per-chunk branches made every MFMA wait for its own LDS read.
+#pragma unroll 2
         for (int ks = 0; ks < 16; ++ks) {
             const int pp = 32 * wv + 2 * ks + lh;
             const int py = pp >> 4, px = pp & 15;
             const float a = Yt[pp * 32 + lrow];
             const float* xb = Xt + ((py * S) * ITW + px * S) * pitch * 4;
+            float bv[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                if (c < NCH) {
-                    const float bv = bok[c] ? xb[boff[c]] : 0.f;
-                    acc[c] = gmfma(a, bv, acc[c]);
-                }
-            }
+            for (int c = 0; c < NC; ++c) bv[c] = xb[boff[c]];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = gmfma(a, bok[c] ? bv[c] : 0.f, acc[c]);
         }
     }
     // reduce the four waves' accumulators chunk by chunk; D[o][j]: row o = (r&3)+8*(r>>2)+4*lh, column j = lrow
@@ -401,16 +402,35 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GcWP p) {
     }
 }
 
-// dw[(cbase+o)][i][tap] = sum_split partial[g][split][o][tap*gw+i]
-__global__ void gconv_wgrad_reduce_kernel(const float* partial, int G, int nsplit, int gw, float* dw) {
+// dw[(cbase+o)][i][tap] = sum_split partial[g][split][o][tap*gw+i]; block = 32 elements x 32 split lanes (a thread per
+// element walking all splits was one memory latency per split: 60 us of a 110 us weight gradient)
+__global__ __launch_bounds__(1024) void gconv_wgrad_reduce_kernel(const float* partial, int G, int nsplit, int gw, float* dw) {
+    __shared__ float red[32][33];
     const int K = 9 * gw;
     const int total = G * gw * K;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int k = e % K, o = (e / K) % gw, g = e / (K * gw);
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)(g * nsplit + sp) * gw + o) * K + k];
+    const int e = blockIdx.x * 32 + threadIdx.x;
+    float s = 0.f;
+    int k = 0, o = 0, g = 0;
+    if (e < total) {
+        k = e % K; o = (e / K) % gw; g = e / (K * gw);
+        const float* src = partial + ((size_t)g * nsplit * gw + o) * K + k;
+        const size_t stride = (size_t)gw * K;
+        int sp = threadIdx.y;
+        for (; sp + 3 * 32 < nsplit; sp += 4 * 32) {
+            const float v0 = src[(size_t)sp * stride], v1 = src[(size_t)(sp + 32) * stride];
+            const float v2 = src[(size_t)(sp + 64) * stride], v3 = src[(size_t)(sp + 96) * stride];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; sp < nsplit; sp += 32) s += src[(size_t)sp * stride];
+    }
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && e < total) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tsum += red[q][threadIdx.x];
         const int tap = k / gw, i = k - tap * gw;
-        dw[((size_t)(g * gw + o) * gw + i) * 9 + tap] = s;
+        dw[((size_t)(g * gw + o) * gw + i) * 9 + tap] = tsum;
     }
 }
 
@@ -502,14 +522,14 @@ extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) 
         hipLaunchKernelGGL((gconv_wgrad_kernel<NCH_, S_>), wgrid, dim3(256), lds, st, p);                                     \
     } while (0)
     if (S == 1) {
-        if (nch <= 5) PQ_GCW_LAUNCH(5, 1); else if (nch <= 7) PQ_GCW_LAUNCH(7, 1); else PQ_GCW_LAUNCH(9, 1);
+        if (nch <= 3) PQ_GCW_LAUNCH(3, 1); else if (nch <= 5) PQ_GCW_LAUNCH(5, 1); else if (nch <= 7) PQ_GCW_LAUNCH(7, 1); else PQ_GCW_LAUNCH(9, 1);
     } else {
-        if (nch <= 5) PQ_GCW_LAUNCH(5, 2); else if (nch <= 7) PQ_GCW_LAUNCH(7, 2); else PQ_GCW_LAUNCH(9, 2);
+        if (nch <= 3) PQ_GCW_LAUNCH(3, 2); else if (nch <= 5) PQ_GCW_LAUNCH(5, 2); else if (nch <= 7) PQ_GCW_LAUNCH(7, 2); else PQ_GCW_LAUNCH(9, 2);
     }
 #undef PQ_GCW_LAUNCH
     PQ_CHECK_LAUNCH();
     const int total = G * a->gw * 9 * a->gw;
-    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)a->scratch, G, p.nsplit, a->gw, a->dw);
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, G, p.nsplit, a->gw, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
