@@ -281,6 +281,155 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stride-2 data gradient
+// dx[2a+pi, 2b+pj] only receives the taps with ky = pi+1 (mod 2), kx = pj+1 (mod 2): 1 / 2 / 2 / 4 taps for the four pixel
+// parities instead of 9 taps on a zero-inserted plane (4x the MFMA work, 4x the LDS tile, 3/4 of the staged pixels zero).
+// A workgroup owns a 16x32 tile of dx of one group = four 8x16 parity classes; it stages the 9x17 dy' tile once (no halo on
+// top / left: odd rows also use dy row a+1), wave wv owns pixels 32*wv..+31 of every class.
+//   class (pi, pj), pixel (a, b):  dx = sum over (ky, dr) in {pi=0: (1,0); pi=1: (0,+1), (2,0)} x (kx, dc) likewise of
+//   dy'[a+dr][b+dc][o] * w[o][i][ky][kx]
+__global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(GcP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int DTH = 9, DTW = 17, NPIX = DTH * DTW;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int gw = p.gw, gq = gw >> 2, pitch = gq + 1;
+    const int K = 9 * gw, KP = K + 4;
+    float4* At = reinterpret_cast<float4*>(smem);                       // [9*17][pitch]   dy' tile
+    float* Bt = smem + (size_t)NPIX * pitch * 4;                        // [32][KP]        B[i][tap*gw + o] = w[o][i][tap]
+    float* red = Bt + 32 * KP;                                          // [2][4][32]
+    int tIdx, g;
+    xcd_block(tIdx, g);
+    const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
+    const int iy0 = th * 16, ix0 = tw * 32;                             // dx tile origin (p.OH x p.OW is the dx plane here)
+    const int cbase = g * gw;
+    gc_stage_gsrc<DTW, NPIX>(At, pitch, gq, cbase, b, iy0 >> 1, ix0 >> 1, p.DH, p.DW, p.dy, 0, 0, 0, t);
+    {
+        const int n = t >> 3, kk = t & 7;
+        const int nc = min(n, gw - 1);
+        int tap = 0, j = kk;
+        while (j >= gw) { j -= gw; ++tap; }
+        for (int k0 = kk; k0 < K; k0 += 8 * GUB) {
+            float v[GUB];
+#pragma unroll
+            for (int u = 0; u < GUB; ++u) {
+                v[u] = p.w[((size_t)(cbase + j) * gw + nc) * 9 + min(tap, 8)];      // n = i, j = o
+                j += 8;
+                while (j >= gw) { j -= gw; ++tap; }
+            }
+#pragma unroll
+            for (int u = 0; u < GUB; ++u) {
+                const int k = k0 + 8 * u;
+                if (k < K) Bt[n * KP + k] = n < gw ? v[u] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int pp = 32 * wv + lrow, pa = pp >> 4, pb = pp & 15;
+    const int n = lrow;
+    const bool nok = n < gw;
+    const int ch = cbase + (nok ? n : 0);
+    const pq_gsink& sk = p.sink;
+    const bool affine = sk.scale != nullptr;
+    const bool stats = sk.mean != nullptr && sk.partial != nullptr;
+    const bool qmask = sk.finalize && sk.qstate != nullptr;
+    const float qinv = qmask ? 1.f / sk.qstate[2] : 0.f, qzp = qmask ? sk.qstate[3] : 0.f;
+    const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats || qmask);
+    const bool want_stats = sk.finalize && stats;
+    const ActParam sact = act_param(sk.act);
+    const float ca = affine ? sk.scale[ch] : 1.f, cb = affine ? sk.shift[ch] : 0.f;
+    const float cm = stats ? sk.mean[ch] : 0.f, ci = stats ? sk.invstd[ch] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    const float4* bq = reinterpret_cast<const float4*>(Bt);
+    const int KPq = KP >> 2;
+
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+        const int pi = cls >> 1, pj = cls & 1;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+            if (ty > pi) continue;                                  // pi = 0: one row tap, pi = 1: two
+            const int ky = pi ? 2 * ty : 1, dr = pi ? 1 - ty : 0;   // (ky=0, dr=+1), (ky=2, dr=0) | (ky=1, dr=0)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx) {
+                if (tx > pj) continue;
+                const int kx = pj ? 2 * tx : 1, dc = pj ? 1 - tx : 0;
+                const int tap = ky * 3 + kx;
+                const float4* arow = At + ((pa + dr) * DTW + pb + dc) * pitch;
+                if ((gw & 7) == 0) {
+                    const float4* brow = bq + lrow * KPq + (tap * gw >> 2);
+                    for (int s_ = 0; s_ < (gw >> 3); ++s_) {
+                        const float4 af = arow[2 * s_ + lh];
+                        const float4 bf = brow[2 * s_ + lh];
+                        acc = gmfma(af.x, bf.x, acc);
+                        acc = gmfma(af.y, bf.y, acc);
+                        acc = gmfma(af.z, bf.z, acc);
+                        acc = gmfma(af.w, bf.w, acc);
+                    }
+                } else {
+                    const float* ar = reinterpret_cast<const float*>(arow);
+                    const float* br = Bt + lrow * KP + tap * gw;
+                    for (int s_ = 0; s_ < gq; ++s_) {
+                        acc = gmfma(ar[4 * s_ + 2 * lh], br[4 * s_ + 2 * lh], acc);
+                        acc = gmfma(ar[4 * s_ + 2 * lh + 1], br[4 * s_ + 2 * lh + 1], acc);
+                    }
+                }
+            }
+        }
+        // sink epilogue of this parity class: C row r = pixel q of the wave's 32, column = channel lrow
+        float yv[16], gv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int iy = min(iy0 + 2 * (q >> 4) + pi, p.OH - 1), ix = min(ix0 + 2 * (q & 15) + pj, p.OW - 1);
+            const size_t row = ((size_t)b * p.OH + iy) * p.OW + ix;
+            yv[r] = need_y ? sk.y[row * sk.ldy + ch] : 0.f;
+            gv[r] = sk.accumulate ? sk.g[row * sk.ldg + ch] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int iy = iy0 + 2 * (q >> 4) + pi, ix = ix0 + 2 * (q & 15) + pj;
+            float dz = acc[r] + gv[r];
+            if (need_y) {
+                const float uu = fmaf(ca, yv[r], cb);
+                dz *= act_bwd(uu, sact);
+                if (qmask) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz = (qv >= 0.f && qv <= 255.f) ? dz : 0.f; }
+            }
+            if (nok && iy < p.OH && ix < p.OW) {
+                sk.g[(((size_t)b * p.OH + iy) * p.OW + ix) * sk.ldg + ch] = dz;
+                if (stats) { s1 += dz; s2 = fmaf(dz, (yv[r] - cm) * ci, s2); }
+            }
+        }
+    }
+    if (want_stats) {       // uniform.  The statistics rows are those of the 8x16 tiling (pq_gconv3x3_blocks): this workgroup
+        s1 += __shfl_xor(s1, 32);       // covers up to four of them -- sums go to the first, zeros to the others
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0) { red[(0 * 4 + wv) * 32 + lrow] = s1; red[(1 * 4 + wv) * 32 + lrow] = s2; }
+        __syncthreads();
+        if (t < 32 && t < gw) {
+            float a = 0.f, bsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a += red[(0 * 4 + q) * 32 + t]; bsum += red[(1 * 4 + q) * 32 + t]; }
+            const int tH8 = (p.OH + GTH - 1) / GTH, tW16 = (p.OW + GTW - 1) / GTW;
+            for (int sy = 0; sy < 2; ++sy)
+                for (int sx = 0; sx < 2; ++sx) {
+                    const int r8 = 2 * th + sy, c16 = 2 * tw + sx;
+                    if (r8 < tH8 && c16 < tW16) {
+                        float* dst = sk.partial + ((size_t)(b * tH8 + r8) * tW16 + c16) * 2 * sk.ldp;
+                        const bool first = sy == 0 && sx == 0;
+                        dst[cbase + t] = first ? a : 0.f;
+                        dst[sk.ldp + cbase + t] = first ? bsum : 0.f;
+                    }
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct GcWP {
     pq_gsrc dy; pq_src in;
@@ -476,6 +625,19 @@ extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) 
     PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape (group width multiple of 4 and <= 32, stride 1|2, pad 1)");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_gconv3x3_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }
+    static const char* s2env = getenv("PQ_GC_DGRAD_S2");       // "zero": the zero-insertion formulation (A/B timing)
+    if (a->stride == 2 && !(s2env && s2env[0] == 'z')) {
+        GcP q{};
+        q.dy = a->dy; q.grad = 1; q.w = a->w; q.sink = a->dx; q.DH = a->OH; q.DW = a->OW;
+        q.B = a->B; q.OH = a->IH; q.OW = a->IW; q.C = a->C; q.gw = a->gw; q.S = 2;
+        q.tilesH = (a->IH + 15) / 16; q.tilesW = (a->IW + 31) / 32;
+        const int pitch = a->gw / 4 + 1;
+        const size_t lds2 = ((size_t)9 * 17 * pitch * 4 + 32 * (9 * a->gw + 4) + 2 * 4 * 32) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(gconv_dgrad_s2_kernel, dim3(a->B * q.tilesH * q.tilesW, a->C / a->gw), dim3(256), lds2, (hipStream_t)stream, q);
+        PQ_CHECK_LAUNCH();
+        return PQ_OK;
+    }
     GcP p{};
     p.dy = a->dy; p.grad = 1; p.w = a->w; p.wmode = 1; p.sink = a->dx;
     p.up = a->stride == 2; p.DH = a->OH; p.DW = a->OW;
