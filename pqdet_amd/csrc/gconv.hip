@@ -125,7 +125,10 @@ __device__ __forceinline__ void gc_stage_gsrc(float4* At, int pitch, int gq, int
     }
 }
 
-template <int EMODE, int S>     // EMODE 1: raw store + BN statistics, 2: gradient sink; S: stride of the tile walk (dgrad: 1)
+// PERSIST: the workgroup keeps its group's weight image in LDS and walks tiles bx, bx + gridDim.x, ... -- used for the big
+// stride-2 forward layers, where one workgroup fills a CU's LDS (nothing overlaps the image gather) and has >= 8 tiles to walk;
+// elsewhere the loop costs registers (occupancy) and loses.
+template <int EMODE, int S, bool PERSIST = false>     // EMODE 1: raw store + BN statistics, 2: gradient sink; S: stride of the tile walk (dgrad: 1)
 __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -138,14 +141,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
 
     int tIdx, g;
     xcd_block(tIdx, g);
-    const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
-    const int oy0 = th * GTH, ox0 = tw * GTW;
-    const int ay0 = oy0 * S - 1, ax0 = ox0 * S - 1;
     const int cbase = g * gw;
-
-    // ---- stage A (operand tile with halo)
-    if (!p.grad) gc_stage_src<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.in, t);
-    else gc_stage_gsrc<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.dy, p.up, p.DH, p.DW, t);
+    const int ntiles = p.B * p.tilesH * p.tilesW;
     // ---- stage B (this group's weights, k = tap*gw + i): row n = t/8, eight lanes walk k; four loads in flight
     {
         const int n = t >> 3, kk = t & 7;
@@ -169,10 +166,18 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
             }
         }
     }
+    const int lrow = lane & 31, lh = lane >> 5;
+    do {                               // one pass unless PERSIST
+    const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
+    const int oy0 = th * GTH, ox0 = tw * GTW;
+    const int ay0 = oy0 * S - 1, ax0 = ox0 * S - 1;
+    if (PERSIST) __syncthreads();      // the previous tile's reads of At / red are done
+    // ---- stage A (operand tile with halo)
+    if (!p.grad) gc_stage_src<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.in, t);
+    else gc_stage_gsrc<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.dy, p.up, p.DH, p.DW, t);
     __syncthreads();
 
     // ---- MFMA: wave wv owns pixels 32*wv .. +31 of the tile (two tile rows), all 32 (padded) output channels
-    const int lrow = lane & 31, lh = lane >> 5;
     const int pp = 32 * wv + lrow, py = pp >> 4, px = pp & 15;
     f32x16 acc;
 #pragma unroll
@@ -279,6 +284,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
             dst[ldp + cbase + t] = bsum;
         }
     }
+    if (!PERSIST) break;
+    tIdx += gridDim.x;
+    } while (tIdx < ntiles);
 }
 
 // ------------------------------------------------------------------------------------------------ stride-2 data gradient
@@ -613,8 +621,19 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
         (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((gconv_kernel<1, 1>), grid, dim3(256), lds, (hipStream_t)stream, p);
     } else {
-        (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((gconv_kernel<1, 2>), grid, dim3(256), lds, (hipStream_t)stream, p);
+        // big stride-2 layers: persistent workgroups (one resident wave of them), at least 8 tiles each
+        static const char* penv = getenv("PQ_GC_PERSIST");            // "0": one workgroup per tile (A/B timing)
+        const int G = a->C / a->gw, ntiles = a->B * p.tilesH * p.tilesW;
+        int occ = (int)((160 * 1024) / lds); if (occ > 3) occ = 3; if (occ < 1) occ = 1;
+        int nb = 256 * occ / G; if (nb < 1) nb = 1;
+        const int per = (ntiles + nb - 1) / nb;
+        if (!(penv && penv[0] == '0') && nb < ntiles && per >= 8) {
+            (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((gconv_kernel<1, 2, true>), dim3((ntiles + per - 1) / per, G), dim3(256), lds, (hipStream_t)stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((gconv_kernel<1, 2>), grid, dim3(256), lds, (hipStream_t)stream, p);
+        }
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
