@@ -383,20 +383,29 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwP p) {
     }
 }
 
-// out[j] = sum_k part[k*n + j]; block = 64 columns x 16 row lanes (deterministic tree)
+// out[j] = sum_k part[k*n + j]; block = 32 columns x 32 row lanes (deterministic tree)
 __global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* part, int nblk, int n, float* out) {
-    __shared__ float red[16][65];
-    const int j = blockIdx.x * 64 + threadIdx.x;
+    __shared__ float red[32][33];
+    const int j = blockIdx.x * 32 + threadIdx.x;
     float s = 0.f;
-    if (j < n)
-        for (int k = threadIdx.y; k < nblk; k += 16) s += part[(size_t)k * n + j];
+    if (j < n) {
+        int k = threadIdx.y;
+        for (; k + 7 * 32 < nblk; k += 8 * 32) {       // 8 independent loads in flight (the loop is pure load latency)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + 32 * u) * n + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nblk; k += 32) s += part[(size_t)k * n + j];
+    }
     red[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && j < n) {
-        float t = 0.f;
+        float tt = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-        out[j] = t;
+        for (int k = 0; k < 32; ++k) tt += red[k][threadIdx.x];
+        out[j] = tt;
     }
 }
 
@@ -624,7 +633,7 @@ extern "C" int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream) {
     else hipLaunchKernelGGL((dw_wgrad_kernel<2, 2>), grid, blk, sh, st, p);
     PQ_CHECK_LAUNCH();
     const int n = a->C * 9;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 63) / 64), dim3(64, 16), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -674,7 +683,7 @@ extern "C" int pq_stem3x3_wgrad(const pq_stem3x3_wgrad_args* a, void* stream) {
     hipLaunchKernelGGL((stem_wgrad_kernel<3>), grid, blk, (size_t)g.cx * g.py * 4 * sizeof(float), st, p);
     PQ_CHECK_LAUNCH();
     const int n = a->O * a->CI * 9;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 63) / 64), dim3(64, 16), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
