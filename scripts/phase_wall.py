@@ -40,4 +40,6 @@ for arr, n, tag in ((plan.fwd_arr, nf, 'fwd'), (plan.bwd_arr, nb, 'bwd')):
     for name, idxs in classes.items():
         sub = (abi.Op * len(idxs))(*[arr[k] for k in idxs])
         ms = wall(lambda: abi.check(l.pq_run_ops(sub, len(idxs), st)))
-        print('%s %-60s %4d launches %.3f ms  (%.1f us each)' % (tag, name, len(idxs), ms, ms / len(idxs) * 1e3))
+        fl = sum(bench.op_work(arr[k])[0] for k in idxs); by = sum(bench.op_work(arr[k])[1] for k in idxs)
+        print('%s %-60s %4d launches %.3f ms  (%.1f us each)  %6.1f TF/s %7.0f GB/s (algorithmic)' % (
+            tag, name, len(idxs), ms, ms / len(idxs) * 1e3, fl / ms / 1e9, by / ms / 1e6))
