@@ -476,6 +476,87 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemP p) {
     if (p.partial) block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, lds, bx);
 }
 
+// LDS-tiled forward: a workgroup walks 4x32-pixel output tiles (tile = bx, bx + gridDim.x, ...; one statistics row per
+// workgroup as before), stages the CI x PH x PW image patch once with coalesced row loads and every lane reads its 27
+// taps from LDS (the 8 channel-quad lanes of a pixel hit the same word: broadcast).  The streaming version above issued 27
+// scalar global loads per output pixel and lane.
+template <int CI>
+__global__ __launch_bounds__(256) void stem_fwd_tiled_kernel(StemP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TH = 4, TW = 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx, c0 = c4 * 4;
+    const bool cok = c4 < p.O4;
+    const int S = p.S, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWp = PW + 1;
+    float* red = lds;                                   // [256][8] for the statistics reduction
+    float* patch = lds + 256 * 8;                       // [CI][PH][PWp]
+    float4 wk[CI * 9];
+#pragma unroll
+    for (int t = 0; t < CI * 9; ++t) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = (c0 + j < p.O) ? p.w[(size_t)(c0 + j) * CI * 9 + t] : 0.f;
+        wk[t] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    const int tilesH = (p.OH + TH - 1) / TH, tilesW = (p.OW + TW - 1) / TW, ntiles = p.B * tilesH * tilesW;
+    const int tid = ty * blockDim.x + tx, nthr = blockDim.x * blockDim.y;
+    const int npatch = CI * PH * PW;
+    float4 s1 = f4zero(), s2 = f4zero();
+    for (int tile = bx; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tilesW, th = (tile / tilesW) % tilesH, b = tile / (tilesW * tilesH);
+        const int oy0 = th * TH, ox0 = tw * TW;
+        const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        __syncthreads();                                // the previous tile's taps have been read
+        for (int e0 = tid; e0 < npatch; e0 += 4 * nthr) {
+            float v[4];
+            int dst[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * nthr, npatch - 1);
+                const int ci = e / (PH * PW), rem = e - ci * PH * PW;
+                const int py = rem / PW, px = rem - py * PW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                dst[u] = (ci * PH + py) * PWp + px;
+                v[u] = p.img[(((size_t)b * CI + ci) * p.IH + min(max(iy, 0), p.IH - 1)) * p.IW + min(max(ix, 0), p.IW - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * nthr < npatch) patch[dst[u]] = ok[u] ? v[u] : 0.f;
+        }
+        __syncthreads();
+        if (cok) {
+            for (int pi = ty; pi < TH * TW; pi += blockDim.y) {
+                const int oyl = pi / TW, oxl = pi - oyl * TW;
+                const int oy = oy0 + oyl, ox = ox0 + oxl;
+                if (oy < p.OH && ox < p.OW) {
+                    float4 acc = f4zero();
+                    const float* pp = patch + (oyl * S) * PWp + oxl * S;
+#pragma unroll
+                    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const float v = pp[(ci * PH + ky) * PWp + kx];
+                                acc = f4fma(make_float4(v, v, v, v), wk[ci * 9 + ky * 3 + kx], acc);
+                            }
+                    stg4(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.ldo + c0, acc);
+                    s1 = f4add(s1, acc);
+                    s2 = f4fma(acc, acc, s2);
+                }
+            }
+        }
+    }
+    if (p.partial) {
+        __syncthreads();
+        block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, red, bx);
+    }
+}
+
 template <int CI>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -540,6 +621,91 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemP p) {
             if (c0 + 1 < p.O) dst[CI * 9] = s.y;
             if (c0 + 2 < p.O) dst[2 * CI * 9] = s.z;
             if (c0 + 3 < p.O) dst[3 * CI * 9] = s.w;
+        }
+    }
+}
+
+// LDS-tiled weight gradient of the stem: same tile walk and image patch as stem_fwd_tiled_kernel; a lane keeps its 27 x 4
+// accumulators over all tiles of the workgroup, then the usual reduction over the pixel lanes.
+template <int CI>
+__global__ __launch_bounds__(256) void stem_wgrad_tiled_kernel(StemP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TH = 4, TW = 32;
+    const int tx = threadIdx.x, ty = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
+    int bx, by;
+    xcd_block(bx, by);
+    const int c4 = by * blockDim.x + tx, c0 = c4 * 4;
+    const bool cok = c4 < p.O4;
+    const int S = p.S, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWp = PW + 1;
+    float* patch = lds + 256 * 4;                       // after the [ny*nx] float4 reduction area
+    const GsrcCoef4 gk = gsrc_coef4(p.dy, c0, p.O);
+    float4 acc[CI * 9];
+#pragma unroll
+    for (int t = 0; t < CI * 9; ++t) acc[t] = f4zero();
+    const int tilesH = (p.OH + TH - 1) / TH, tilesW = (p.OW + TW - 1) / TW, ntiles = p.B * tilesH * tilesW;
+    const int tid = ty * nx + tx, nthr = nx * ny;
+    const int npatch = CI * PH * PW;
+    for (int tile = bx; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tilesW, th = (tile / tilesW) % tilesH, b = tile / (tilesW * tilesH);
+        const int oy0 = th * TH, ox0 = tw * TW;
+        const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        __syncthreads();
+        for (int e0 = tid; e0 < npatch; e0 += 4 * nthr) {
+            float v[4];
+            int dst[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * nthr, npatch - 1);
+                const int ci = e / (PH * PW), rem = e - ci * PH * PW;
+                const int py = rem / PW, px = rem - py * PW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                dst[u] = (ci * PH + py) * PWp + px;
+                v[u] = p.img[(((size_t)b * CI + ci) * p.IH + min(max(iy, 0), p.IH - 1)) * p.IW + min(max(ix, 0), p.IW - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * nthr < npatch) patch[dst[u]] = ok[u] ? v[u] : 0.f;
+        }
+        __syncthreads();
+        if (cok) {
+            for (int pi = ty; pi < TH * TW; pi += ny) {
+                const int oyl = pi / TW, oxl = pi - oyl * TW;
+                const int oy = oy0 + oyl, ox = ox0 + oxl;
+                if (oy < p.OH && ox < p.OW) {
+                    const size_t row = ((size_t)b * p.OH + oy) * p.OW + ox;
+                    const float4 g = ldg4(p.dy.g + row * p.dy.ldg + c0);
+                    const float4 y = gk.two ? ldg4(p.dy.y + row * p.dy.ldy + c0) : f4zero();
+                    const float4 dy = gsrc_apply4(g, y, gk);
+                    const float* pp = patch + (oyl * S) * PWp + oxl * S;
+#pragma unroll
+                    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const float v = pp[(ci * PH + ky) * PWp + kx];
+                                acc[ci * 9 + ky * 3 + kx] = f4fma(dy, make_float4(v, v, v, v), acc[ci * 9 + ky * 3 + kx]);
+                            }
+                }
+            }
+        }
+    }
+    float4* l4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int t = 0; t < CI * 9; ++t) {
+        __syncthreads();
+        l4[ty * nx + tx] = acc[t];
+        __syncthreads();
+        if (ty == 0 && cok) {
+            float4 sum = f4zero();
+            for (int y = 0; y < ny; ++y) sum = f4add(sum, l4[y * nx + tx]);
+            float* dst = p.wpartial + ((size_t)bx * p.O + c0) * (CI * 9) + t;
+            if (c0 + 0 < p.O) dst[0] = sum.x;
+            if (c0 + 1 < p.O) dst[CI * 9] = sum.y;
+            if (c0 + 2 < p.O) dst[2 * CI * 9] = sum.z;
+            if (c0 + 3 < p.O) dst[3 * CI * 9] = sum.w;
         }
     }
 }
@@ -655,7 +821,14 @@ extern "C" int pq_stem3x3_fwd(const pq_stem3x3_fwd_args* a, void* stream) {
     p.S = a->stride; p.ldo = a->ldo; p.ldp = a->ldp;
     EwGeom g = ew_geom((long)a->B * a->OH * a->OW, a->O);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
-    hipLaunchKernelGGL((stem_fwd_kernel<3>), grid, blk, (size_t)g.cx * g.py * 8 * sizeof(float), (hipStream_t)stream, p);
+    static const char* senv = getenv("PQ_STEM");                  // "stream": the per-pixel global-load version (A/B timing)
+    if (senv && senv[0] == 's') {
+        hipLaunchKernelGGL((stem_fwd_kernel<3>), grid, blk, (size_t)g.cx * g.py * 8 * sizeof(float), (hipStream_t)stream, p);
+    } else {
+        const int PH = 3 * a->stride + 3, PW = 31 * a->stride + 3;
+        const size_t sh = ((size_t)256 * 8 + (size_t)3 * PH * (PW + 1) + 16) * sizeof(float);
+        hipLaunchKernelGGL((stem_fwd_tiled_kernel<3>), grid, blk, sh, (hipStream_t)stream, p);
+    }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -680,7 +853,14 @@ extern "C" int pq_stem3x3_wgrad(const pq_stem3x3_wgrad_args* a, void* stream) {
     stem_wgrad_blocks(a->B, a->OH, a->OW, a->O, &g);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((stem_wgrad_kernel<3>), grid, blk, (size_t)g.cx * g.py * 4 * sizeof(float), st, p);
+    static const char* senv = getenv("PQ_STEM");                  // "stream": the per-pixel global-load version (A/B timing)
+    if (senv && senv[0] == 's') {
+        hipLaunchKernelGGL((stem_wgrad_kernel<3>), grid, blk, (size_t)g.cx * g.py * 4 * sizeof(float), st, p);
+    } else {
+        const int PH = 3 * a->stride + 3, PW = 31 * a->stride + 3;
+        const size_t sh = ((size_t)256 * 4 + (size_t)3 * PH * (PW + 1) + 16) * sizeof(float);
+        hipLaunchKernelGGL((stem_wgrad_tiled_kernel<3>), grid, blk, sh, st, p);
+    }
     PQ_CHECK_LAUNCH();
     const int n = a->O * a->CI * 9;
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
