@@ -125,7 +125,7 @@ def profile_kernels(plan, x, tgt, side=None, passes=3):
 PMC_PATTERN = {
     'conv1x1_dgrad (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, 2, ', None),
     'conv1x1_fwd (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], ', None),
-    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<', r'pq::slab_reduce_kernel'),
+    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<', r'pq::slab_reduce'),
     'conv1x1_bwd narrow layers (fused dgrad+wgrad, one pass over dy)': (r'pw_bwd_kernel<', r'pw_slab_reduce_kernel'),
 }
 
