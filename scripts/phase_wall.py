@@ -43,3 +43,28 @@ for arr, n, tag in ((plan.fwd_arr, nf, 'fwd'), (plan.bwd_arr, nb, 'bwd')):
         fl = sum(bench.op_work(arr[k])[0] for k in idxs); by = sum(bench.op_work(arr[k])[1] for k in idxs)
         print('%s %-60s %4d launches %.3f ms  (%.1f us each)  %6.1f TF/s %7.0f GB/s (algorithmic)' % (
             tag, name, len(idxs), ms, ms / len(idxs) * 1e3, fl / ms / 1e9, by / ms / 1e6))
+
+# per GEMM op, replayed alone (hot caches: optimistic for the big layers): time against max(MFMA, HBM) bound
+if os.environ.get('PER_OP'):
+    rows = []
+    for arr, n, tag in ((plan.fwd_arr, nf, 'fwd'), (plan.bwd_arr, nb, 'bwd')):
+        for k in range(n):
+            code = arr[k].code
+            if code not in (abi.OP_CONV1X1_FWD, abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_WGRAD, abi.OP_CONV1X1_BWD):
+                continue
+            a = getattr(arr[k].u, abi.OP_FIELD[code])
+            sub = (abi.Op * 1)(arr[k])
+            ms = wall(lambda: abi.check(l.pq_run_ops(sub, 1, st)))
+            fl = 2.0 * a.M * a.I * a.O * (2 if code == abi.OP_CONV1X1_BWD else 1)
+            by = 4.0 * a.M * {abi.OP_CONV1X1_FWD: a.I + a.O, abi.OP_CONV1X1_DGRAD: 2 * a.O + 2 * a.I,
+                              abi.OP_CONV1X1_WGRAD: 2 * a.O + a.I, abi.OP_CONV1X1_BWD: 2 * a.O + 3 * a.I}[code]
+            bound = max(fl / 157.3e9, by / 4.0e9)          # ms
+            rows.append((ms - bound, ms, bound, tag, bench.KERNEL_CLASS[code][0][:14], a.M, a.I, a.O))
+    agg = {}
+    for r in rows:
+        key = r[4:]
+        e = agg.setdefault(key, [0, 0.0, 0.0]); e[0] += 1; e[1] += r[1]; e[2] += r[2]
+    print('--- GEMM ops alone: count, total ms, bound ms (max of fp32 MFMA peak and real bytes at 4 TB/s), excess')
+    for key, e in sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2]))[:40]:
+        print('%-14s M=%-8d I=%-5d O=%-5d x%d  %.3f ms  bound %.3f  excess %.3f' % (key + (e[0], e[1], e[2], e[1] - e[2])))
+    print('total %.3f ms, bound %.3f ms' % (sum(e[1] for e in agg.values()), sum(e[2] for e in agg.values())))

@@ -74,6 +74,9 @@ def reduce_partial(partial, nblk, ldp, C_):
     (512, 1024, 75, 2, True, True, False),
     (130, 16, 96, 0, False, False, True),
     (64, 320, 1280, 1, True, False, True),
+    (4096, 512, 256, 2, True, False, True),       # split-K shapes (few tiles, long contraction)
+    (4096, 1024, 75, 2, True, True, False),
+    (4000, 960, 160, 0, False, False, True),
 ])
 def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
     g = torch.Generator().manual_seed(M + I + O)
@@ -109,6 +112,23 @@ def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
         s1, s2 = reduce_partial(partial, nblk, ldp, O)
         close(s1.float(), want.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum')
         close(s2.float(), (want.double() ** 2).sum(0).float(), rt=1e-3, at=1e-2, what='sumsq')
+    if M >= 4000:
+        # same layer through split-K: slices of the contraction into slabs, one reduction pass with bias + statistics
+        l = abi.lib()
+        assert l.pq_conv1x1_splitk(M, O, I) > 1
+        scratch = torch.full((l.pq_conv1x1_splitk_scratch_bytes(M, O, I) // 4,), float('nan'), device=DEV)
+        out2 = torch.full((M, ldo), float('nan'), device=DEV)
+        nb2 = l.pq_ew_blocks(M, O)
+        part2 = torch.zeros(nb2 * 2 * ldp, device=DEV) if stats else None
+        a.out, a.partial, a.scratch = out2.data_ptr(), abi.ptr(part2), scratch.data_ptr()
+        abi.check(l.pq_conv1x1_fwd(C.byref(a), stream()))
+        torch.cuda.synchronize()
+        close(out2[:, :O], want, what='conv1x1 out (split-K)')
+        assert torch.isnan(out2[:, O:]).all(), 'split-K wrote outside the logical channels'
+        if stats:
+            s1, s2 = reduce_partial(part2, nb2, ldp, O)
+            close(s1.float(), want.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum (split-K)')
+            close(s2.float(), (want.double() ** 2).sum(0).float(), rt=1e-3, at=1e-2, what='sumsq (split-K)')
 
 
 def test_conv1x1_fwd_strided_rows():
@@ -148,6 +168,8 @@ def _bn_bwd_coeffs(g_, y, gamma, eps=1e-5):
     (257, 960, 160, True, 2, False, True),
     (512, 1024, 75, False, 2, False, True),
     (130, 96, 576, True, 0, True, False),
+    (4096, 160, 960, True, 2, False, True),       # split-K shapes
+    (4000, 320, 1280, True, 0, True, True),
 ])
 def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
     g = torch.Generator().manual_seed(M + I + O + 1)
@@ -214,6 +236,27 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
         abi.check(abi.lib().pq_conv1x1_dgrad(C.byref(a), stream()))
         torch.cuda.synchronize()
         close(g2, gout, what='dgrad sink (transposed weights)')
+        if M >= 4000:
+            # split-K: slabs of the slices, one pass through the sink (statistics rows: pq_ew_blocks)
+            l = abi.lib()
+            assert l.pq_conv1x1_splitk(M, I, O) > 1
+            scratch = torch.full((l.pq_conv1x1_splitk_scratch_bytes(M, I, O) // 4,), float('nan'), device=DEV)
+            g3 = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
+            nb3 = l.pq_ew_blocks(M, I)
+            part3 = torch.zeros(nb3 * 2 * ldp, device=DEV)
+            for use_wt in (True, False):
+                a.dx.g, a.dx.partial, a.scratch = g3.data_ptr(), (part3.data_ptr() if stats else None), scratch.data_ptr()
+                a.wt = wt.data_ptr() if use_wt else None
+                if accum:
+                    g3.copy_(old.to(DEV))
+                abi.check(l.pq_conv1x1_dgrad(C.byref(a), stream()))
+                torch.cuda.synchronize()
+                close(g3, gout, what='dgrad sink (split-K, wt=%s)' % use_wt)
+                if stats:
+                    s1, s2 = reduce_partial(part3, nb3, ldp, I)
+                    xh = (yin.double() - mean_in.double()) * inv_in.double()
+                    close(s1.float(), gout.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum g (split-K)')
+                    close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat (split-K)')
 
 
 @pytest.mark.parametrize('M,I,O,two,bias', [(3000, 32, 16, True, False), (1000, 24, 144, True, False),
