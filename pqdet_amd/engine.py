@@ -347,6 +347,9 @@ class Plan:
                 out = TensorRef(raw, B, OH, OW, Cout, ld, bn, act)
                 out.is_gate = is_gate
                 want_stats = bn is not None and self.bn_train
+                if self.qat and Cout % 4 and bn is not None:
+                    raise NotImplementedError('quantisation-aware training needs channel counts that are multiples of 4 '
+                                              '(layer %d has %d); fine-tune the pruned net in float' % (i, Cout))
                 if self.qat:
                     wq = self._new(conv.weight.numel())
                     sfv = self._new(_round_up(Cout, ALIGN), fill=1.0)
