@@ -634,17 +634,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTP p) {
         store_tiles(mb);
         __syncthreads();
         if (mb + 32 < mend) load_tiles(mb + 32);
+        // operands of step kk+1 are fetched from LDS before the MFMAs of step kk are issued (one accumulator per wave on the
+        // 64x64 tile: without the prefetch every pair of MFMAs waited for its own LDS round trip)
+        float af[TO], bf[TI];
+#pragma unroll
+        for (int a = 0; a < TO; ++a) af[a] = Ys[lh * BO + wo * WO + 32 * a + lrow];
+#pragma unroll
+        for (int b = 0; b < TI; ++b) bf[b] = Xs[lh * BIc + wi * WI + 32 * b + lrow];
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            float af[TO], bf[TI];
+            float an[TO], bn[TI];
+            if (kk + 1 < 16) {
 #pragma unroll
-            for (int a = 0; a < TO; ++a) af[a] = Ys[(2 * kk + lh) * BO + wo * WO + 32 * a + lrow];
+                for (int a = 0; a < TO; ++a) an[a] = Ys[(2 * (kk + 1) + lh) * BO + wo * WO + 32 * a + lrow];
 #pragma unroll
-            for (int b = 0; b < TI; ++b) bf[b] = Xs[(2 * kk + lh) * BIc + wi * WI + 32 * b + lrow];
+                for (int b = 0; b < TI; ++b) bn[b] = Xs[(2 * (kk + 1) + lh) * BIc + wi * WI + 32 * b + lrow];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMAs (the scheduler sinks it back otherwise)
 #pragma unroll
             for (int a = 0; a < TO; ++a)
 #pragma unroll
                 for (int b = 0; b < TI; ++b) acc[a][b] = mfma32(af[a], bf[b], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < 16) {
+#pragma unroll
+                for (int a = 0; a < TO; ++a) af[a] = an[a];
+#pragma unroll
+                for (int b = 0; b < TI; ++b) bf[b] = bn[b];
+            }
         }
     }
 
