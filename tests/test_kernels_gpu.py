@@ -376,6 +376,62 @@ def test_conv1x1_bwd_fused_matches_the_two_kernel_backward(M, I, O, two, act, ac
     close(dw, dw2, rt=1e-4, at=2e-3, what='fused vs two-kernel wgrad')
 
 
+def test_conv1x1_bwd_fused_with_qat_observers_matches_the_two_kernel_backward():
+    """QAT plans hand the fused kernel a fake-quantising input operand (pq_src.qstate) and a sink with the straight-through
+    mask (pq_gsink.qstate); both go through the same helpers as in pq_conv1x1_wgrad / pq_conv1x1_dgrad, so the two paths
+    must agree up to summation order (512x512 QAT steps take the fused path from 2^17 rows; the QAT goldens are smaller)."""
+    l = abi.lib()
+    M, I, O, act = 40000, 16, 96, 1
+    g = torch.Generator().manual_seed(123)
+    gy, yout = rnd(M, O, g=g), rnd(M, O, g=g) + 0.3
+    gamma = torch.rand(O, generator=g) + 0.5
+    w = rnd(O, I, g=g, scale=1 / math.sqrt(O))
+    p, q, mu, r, _ = _bn_bwd_coeffs(gy, yout, gamma)
+    yin = rnd(M, I, g=g) * 2 + 1
+    a_in, b_in = torch.rand(I, generator=g) + 0.5, rnd(I, g=g, scale=0.5)
+    mean_in = yin.mean(0)
+    inv_in = 1 / torch.sqrt(yin.var(0, unbiased=False) + 1e-5)
+    qstate = torch.tensor([0.0, 3.0, 3.0 / 255, 0.0], device=DEV)       # {min, max, scale, zero point}: clips at 3.0
+    gyd, youtd, wd, yind = gy.to(DEV), yout.to(DEV), w.to(DEV), yin.to(DEV)
+    vecs = [chan_vec(v) for v in (p, q, mu, r)]
+    sv = [chan_vec(v) for v in (a_in, b_in, mean_in, inv_in)]
+    ldp = 16
+    dyarg = abi.GSrc(gyd.data_ptr(), youtd.data_ptr(), *[v.data_ptr() for v in vecs], O, O)
+    inarg = abi.Src(yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(), I, act, qstate.data_ptr())
+
+    def sink(gdst, partial):
+        return abi.GSink(gdst.data_ptr(), yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(), sv[2].data_ptr(), sv[3].data_ptr(),
+                         partial.data_ptr(), I, I, act, 0, 1, ldp, qstate.data_ptr())
+
+    nblk = l.pq_conv1x1_bwd_blocks(M, I, O)
+    g1 = torch.full((M, I), float('nan'), device=DEV)
+    part1 = torch.zeros(nblk * 2 * ldp, device=DEV)
+    dw1 = torch.full((O, I), float('nan'), device=DEV)
+    scratch = torch.empty(l.pq_conv1x1_bwd_scratch_bytes(M, I, O) // 4, device=DEV)
+    a = abi.Conv1x1Bwd(dyarg, wd.data_ptr(), inarg, sink(g1, part1), dw1.data_ptr(), scratch.data_ptr(), M, I, O)
+    abi.check(l.pq_conv1x1_bwd(C.byref(a), stream()))
+    g2 = torch.full((M, I), float('nan'), device=DEV)
+    nb2 = l.pq_conv1x1_blocks(M, I)
+    part2 = torch.zeros(nb2 * 2 * ldp, device=DEV)
+    d = abi.Conv1x1Dgrad()
+    d.dy, d.w, d.dx, d.M, d.I, d.O = dyarg, wd.data_ptr(), sink(g2, part2), M, I, O
+    abi.check(l.pq_conv1x1_dgrad(C.byref(d), stream()))
+    dw2 = torch.empty(O, I, device=DEV)
+    sc2 = torch.empty(l.pq_conv1x1_wgrad_scratch_bytes(M, I, O) // 4, device=DEV)
+    wg = abi.Conv1x1Wgrad()
+    wg.dy, wg.inp, wg.dw, wg.scratch, wg.M, wg.I, wg.O = dyarg, inarg, dw2.data_ptr(), sc2.data_ptr(), M, I, O
+    abi.check(l.pq_conv1x1_wgrad(C.byref(wg), stream()))
+    torch.cuda.synchronize()
+    # the mask must actually bite: a good share of the activations lies above the 3.0 clip
+    assert 0.05 < (g2 == 0).float().mean().item() < 0.95
+    close(g1, g2, rt=1e-4, at=1e-5, what='fused vs two-kernel dgrad (QAT)')
+    close(dw1, dw2, rt=1e-4, at=2e-3, what='fused vs two-kernel wgrad (QAT)')
+    s1a, s2a = reduce_partial(part1, nblk, ldp, I)
+    s1b, s2b = reduce_partial(part2, nb2, ldp, I)
+    close(s1a.float(), s1b.float(), rt=1e-3, at=1e-2, what='stats sum (QAT)')
+    close(s2a.float(), s2b.float(), rt=1e-3, at=1e-2, what='stats sum xhat (QAT)')
+
+
 def test_conv1x1_bwd_fused_rejects_shapes_outside_its_range():
     l = abi.lib()
     assert l.pq_conv1x1_bwd_blocks(4096, 160, 960) == 0 and l.pq_conv1x1_bwd_blocks(1 << 20, 18, 96) == 0
