@@ -446,9 +446,15 @@ typedef struct pq_nms_args {
     int32_t cand_cap;    /* > 0: compact the (box, class) pairs above score_thr first and sort only cand_cap of them
                             (ordered compaction, same tie order); *count = -1 if there were more -- call again with a
                             larger value or 0.  0: sort all N*C pairs (any candidate count) */
+    int32_t B;           /* > 1: a whole batch in one call: bboxes is [B][N][4+C], every image is suppressed on its own (classes and
+                            the coordinate offset of batched_nms are per image, as in one torch_nms call per image); the kept
+                            rows of all images come out in descending score order with their image in img[] (a stable sort by
+                            image gives the per-image lists); cap / cand_cap / count then cover the whole batch */
+    int32_t* img;        /* [cap] image index per kept row (B > 1), else NULL */
 } pq_nms_args;
 int pq_nms(const pq_nms_args* a, void* stream);
 int64_t pq_nms_scratch_bytes(int32_t N, int32_t C);
+int64_t pq_nms_batch_scratch_bytes(int32_t B, int32_t N, int32_t C);
 
 /* ------------------------------------------------------------------ quantisation-aware training (BASELINE config 5)
  * replaces what the reference gets from torch.ao's QAT modules (tools.py:256-290, model/parser.py:143-183,

@@ -171,7 +171,8 @@ class Recover(C.Structure):
 
 class Nms(C.Structure):
     _fields_ = [('bboxes', c_fp), ('dets', c_fp), ('count', c_fp), ('scratch', c_fp), ('scratch_bytes', i64),
-                ('N', i32), ('C', i32), ('cap', i32), ('score_thr', f32), ('iou_thr', f32), ('cand_cap', i32)]
+                ('N', i32), ('C', i32), ('cap', i32), ('score_thr', f32), ('iou_thr', f32), ('cand_cap', i32),
+                ('B', i32), ('img', c_fp)]
 
 
 class CreateLabel(C.Structure):
@@ -298,6 +299,7 @@ SIGNATURES = {
     'pq_create_label': (C.c_int, [C.POINTER(CreateLabel), C.c_void_p]),
     'pq_nms': (C.c_int, [C.POINTER(Nms), C.c_void_p]),
     'pq_nms_scratch_bytes': (i64, [i32, i32]),
+    'pq_nms_batch_scratch_bytes': (i64, [i32, i32, i32]),
     'pq_run_ops': (C.c_int, [C.POINTER(Op), i32, C.c_void_p]),
     'pq_run_ops2': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p]),
     'pq_run_ops_timed': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.POINTER(C.c_float)]),

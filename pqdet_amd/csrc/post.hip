@@ -141,9 +141,12 @@ struct NmsMeta { unsigned count; unsigned maxbits; unsigned kept; unsigned pad; 
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned o) { unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; return __uint_as_float(u); }
 
+// maxb[img] = largest coordinate of image img's candidates (the class offsets of batched_nms are per call, i.e. per image);
+// nimg = boxes per image (== N for a single image, where the wave-reduced path below serves maxb[0])
 __global__ __launch_bounds__(256) void nms_mark_kernel(const float* bboxes, int N, int C, float thr, float* keys, unsigned* vals,
-                                                        NmsMeta* meta) {
+                                                        NmsMeta* meta, unsigned* maxb, int nimg) {
     const long E = (long)N * C;
+    const bool batch = nimg < N;
     unsigned cnt = 0, mx = 0;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long)gridDim.x * 256) {
         const int i = (int)(e / C), c = (int)(e % C);
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(256) void nms_mark_kernel(const float* bboxes, int 
             ++cnt;
             const float m = fmaxf(fmaxf(row[0], row[1]), fmaxf(row[2], row[3]));
             const unsigned o = f2ord(m);
-            mx = o > mx ? o : mx;
+            if (batch) atomicMax(&maxb[i / nimg], o);          // candidates are sparse
+            else mx = o > mx ? o : mx;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void nms_mark_kernel(const float* bboxes, int 
     }
     if ((threadIdx.x & 63) == 0) {
         if (cnt) atomicAdd(&meta->count, cnt);
-        if (mx) atomicMax(&meta->maxbits, mx);
+        if (mx) atomicMax(&maxb[0], mx);
     }
 }
 
@@ -179,9 +183,11 @@ __global__ __launch_bounds__(256) void nms_fill_kernel(float* keys, unsigned* va
     for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) { keys[i] = -INFINITY; vals[i] = 0u; }
 }
 
-__global__ __launch_bounds__(256) void nms_count_kernel(const float* bboxes, int N, int C, float thr, unsigned* bcnt, NmsMeta* meta) {
+__global__ __launch_bounds__(256) void nms_count_kernel(const float* bboxes, int N, int C, float thr, unsigned* bcnt, NmsMeta* meta,
+                                                         unsigned* maxb, int nimg) {
     __shared__ unsigned sc[4], sm[4];
     const long E = (long)N * C;
+    const bool batch = nimg < N;
     const long base = (long)blockIdx.x * NMS_CHUNK + (long)threadIdx.x * 16;
     unsigned cnt = 0, mx = 0;
     for (int j = 0; j < 16; ++j) {
@@ -192,7 +198,8 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const float* bboxes, int
         if (row[4 + c] > thr) {
             ++cnt;
             const unsigned o = f2ord(fmaxf(fmaxf(row[0], row[1]), fmaxf(row[2], row[3])));
-            mx = o > mx ? o : mx;
+            if (batch) atomicMax(&maxb[i / nimg], o);
+            else mx = o > mx ? o : mx;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -205,8 +212,9 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const float* bboxes, int
     if (threadIdx.x == 0) {
         bcnt[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
         const unsigned m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-        if (m) atomicMax(&meta->maxbits, m);
+        if (m) atomicMax(&maxb[0], m);
     }
+    (void)meta;
 }
 
 __global__ void nms_scan_kernel(unsigned* bcnt, int G, NmsMeta* meta, unsigned S) {
@@ -247,12 +255,13 @@ __global__ __launch_bounds__(256) void nms_write_kernel(const float* bboxes, int
 
 // class key per rank (0xFFFF for non-candidates) + histogram
 __global__ __launch_bounds__(256) void nms_classkey_kernel(const unsigned* sorted_vals, long E, int C, const NmsMeta* meta,
-                                                            unsigned* ckeys, unsigned* ranks, unsigned* hist) {
+                                                            unsigned* ckeys, unsigned* ranks, unsigned* hist, int nimg) {
     const unsigned K = meta->count;
     for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < E; r += (long)gridDim.x * 256) {
         ranks[r] = (unsigned)r;
         if (r < K) {
-            const unsigned c = sorted_vals[r] % (unsigned)C;
+            const unsigned e = sorted_vals[r];
+            const unsigned c = e % (unsigned)C + (unsigned)C * ((e / (unsigned)C) / (unsigned)nimg);     // class id, per image
             ckeys[r] = c;
             atomicAdd(&hist[c], 1u);
         } else {
@@ -279,7 +288,7 @@ __device__ __forceinline__ bool nms_overlap(float ax1, float ay1, float ax2, flo
 }
 
 __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* bboxes, int C, const unsigned* sorted_vals,
-                                                          const unsigned* class_ranks, const unsigned* offs, const NmsMeta* meta,
+                                                          const unsigned* class_ranks, const unsigned* offs, const unsigned* maxb,
                                                           float thr, float* keptbuf, unsigned* keepflag) {
     __shared__ unsigned sdead[4][64];
     __shared__ unsigned s_nk;
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* bboxes, in
     const unsigned beg = offs[c], end = offs[c + 1];
     if (beg == end) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float off = (float)c * (ord2f(meta->maxbits) + 1.f);
+    const float off = (float)(c % C) * (ord2f(maxb[c / C]) + 1.f);          // blockIdx = image * C + class
     float* kept = keptbuf + (size_t)beg * 5;
     if (threadIdx.x == 0) s_nk = 0;
     __syncthreads();
@@ -349,7 +358,8 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* bboxes, in
 
 // single workgroup: ordered compaction of keepflag[0..K) -> dets
 __global__ __launch_bounds__(1024) void nms_compact_kernel(const float* bboxes, int C, const float* sorted_keys, const unsigned* sorted_vals,
-                                                            const unsigned* keepflag, NmsMeta* meta, float* dets, int cap, int32_t* count) {
+                                                            const unsigned* keepflag, NmsMeta* meta, float* dets, int cap, int32_t* count,
+                                                            int32_t* img, int nimg) {
     __shared__ unsigned wsum[16];
     __shared__ unsigned running;
     const unsigned K = meta->count;
@@ -374,6 +384,7 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const float* bboxes, 
                 d[0] = row[0]; d[1] = row[1]; d[2] = row[2]; d[3] = row[3];
                 d[4] = sorted_keys[r];
                 d[5] = (float)(e % (unsigned)C);
+                if (img) img[pos] = (int32_t)((e / (unsigned)C) / (unsigned)nimg);
             }
         }
         __syncthreads();
@@ -419,13 +430,15 @@ extern "C" int pq_create_label(const pq_create_label_args* a, void* stream) {
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct NmsLayout {
-    size_t keys0, keys1, vals0, vals1, ckeys0, ckeys1, rk0, rk1, keep, kept, hist, offs, bcnt, meta, tmp, total;
+    size_t keys0, keys1, vals0, vals1, ckeys0, ckeys1, rk0, rk1, keep, kept, hist, offs, bcnt, meta, maxb, tmp, total;
 };
-static NmsLayout nms_layout(long E, int C) {
+// C = number of class segments (classes x images for a batched call), B = images
+static NmsLayout nms_layout(long E, int C, int B = 1) {
     NmsLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
     L.meta = take(sizeof(NmsMeta));
+    L.maxb = take((size_t)(B + 1) * 4);
     L.hist = take((size_t)(C + 1) * 4);
     L.offs = take((size_t)(C + 2) * 4);
     L.bcnt = take((size_t)((E + NMS_CHUNK - 1) / NMS_CHUNK + 2) * 4);
@@ -447,16 +460,28 @@ extern "C" int64_t pq_nms_scratch_bytes(int32_t N, int32_t C) {
     return (int64_t)(L.total + (size_t)E * 24 + (8u << 20));
 }
 
+extern "C" int64_t pq_nms_batch_scratch_bytes(int32_t B, int32_t N, int32_t C) {
+    const long E = (long)B * N * C;
+    NmsLayout L = nms_layout(E, B * C, B);
+    return (int64_t)(L.total + (size_t)E * 24 + (8u << 20));
+}
+
 extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->bboxes && a->dets && a->count && a->scratch, "null pointer");
     PQ_CHECK_ARG(a->N > 0 && a->C > 0 && a->C < 65535 && a->cap > 0, "bad shape");
-    const long E = (long)a->N * a->C;
+    const int B = a->B > 1 ? a->B : 1;                 // images; bboxes is [B*N][4+C], classes are separated per image
+    const int NC = B * a->C;                           // class segments
+    PQ_CHECK_ARG(NC < 65535, "too many (image, class) segments");
+    PQ_CHECK_ARG(B == 1 || a->img, "a batched call needs the img output");
+    const int Ntot = B * a->N;
+    const long E = (long)Ntot * a->C;
     PQ_CHECK_ARG(E < (1l << 31), "too many (box, class) pairs");
     hipStream_t st = (hipStream_t)stream;
-    NmsLayout L = nms_layout(E, a->C);
+    NmsLayout L = nms_layout(E, NC, B);
     PQ_CHECK_ARG((int64_t)L.total < a->scratch_bytes, "scratch too small");
     char* base = (char*)a->scratch;
     NmsMeta* meta = (NmsMeta*)(base + L.meta);
+    unsigned* maxb = (unsigned*)(base + L.maxb);
     unsigned* hist = (unsigned*)(base + L.hist);
     unsigned* offs = (unsigned*)(base + L.offs);
     unsigned* keep = (unsigned*)(base + L.keep);
@@ -475,15 +500,15 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
     long nb = (S + 255) / 256; if (nb > 2048) nb = 2048;
     if (S == E) {
         long nbe = (E + 255) / 256; if (nbe > 2048) nbe = 2048;
-        hipLaunchKernelGGL(nms_mark_kernel, dim3((unsigned)nbe), dim3(256), 0, st, a->bboxes, a->N, a->C, a->score_thr, keys0, vals0, meta);
+        hipLaunchKernelGGL(nms_mark_kernel, dim3((unsigned)nbe), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, keys0, vals0, meta, maxb, a->N);
         PQ_CHECK_LAUNCH();
     } else {
         unsigned* bcnt = (unsigned*)(base + L.bcnt);
         const int G = (int)((E + NMS_CHUNK - 1) / NMS_CHUNK);
         hipLaunchKernelGGL(nms_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, keys0, vals0, (int)S);
-        hipLaunchKernelGGL(nms_count_kernel, dim3(G), dim3(256), 0, st, a->bboxes, a->N, a->C, a->score_thr, bcnt, meta);
+        hipLaunchKernelGGL(nms_count_kernel, dim3(G), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, bcnt, meta, maxb, a->N);
         hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, bcnt, G, meta, (unsigned)S);
-        hipLaunchKernelGGL(nms_write_kernel, dim3(G), dim3(256), 0, st, a->bboxes, a->N, a->C, a->score_thr, (const unsigned*)bcnt, keys0, vals0,
+        hipLaunchKernelGGL(nms_write_kernel, dim3(G), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, (const unsigned*)bcnt, keys0, vals0,
                            (unsigned)S);
         PQ_CHECK_LAUNCH();
     }
@@ -492,20 +517,20 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
     if (e != hipSuccess || need > tmp_avail) { pq_set_error("pq_nms: sort scratch (%zu needed, %zu available)", need, tmp_avail); return PQ_EINVAL; }
     e = rocprim::radix_sort_pairs_desc(tmp, need, keys0, keys1, vals0, vals1, (size_t)S, 0, 32, st);
     if (e != hipSuccess) { pq_set_error("pq_nms: radix sort failed: %s", hipGetErrorString(e)); return PQ_ELAUNCH; }
-    hipLaunchKernelGGL(nms_classkey_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const unsigned*)vals1, S, a->C, (const NmsMeta*)meta, ck0, rk0, hist);
+    hipLaunchKernelGGL(nms_classkey_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const unsigned*)vals1, S, a->C, (const NmsMeta*)meta, ck0, rk0, hist, a->N);
     PQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)hist, a->C, offs);
+    hipLaunchKernelGGL(nms_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)hist, NC, offs);
     PQ_CHECK_LAUNCH();
     size_t need2 = 0;
     e = rocprim::radix_sort_pairs(nullptr, need2, ck0, ck1, rk0, rk1, (size_t)S, 0, 16, st);
     if (e != hipSuccess || need2 > tmp_avail) { pq_set_error("pq_nms: class-sort scratch (%zu needed, %zu available)", need2, tmp_avail); return PQ_EINVAL; }
     e = rocprim::radix_sort_pairs(tmp, need2, ck0, ck1, rk0, rk1, (size_t)S, 0, 16, st);
     if (e != hipSuccess) { pq_set_error("pq_nms: class sort failed: %s", hipGetErrorString(e)); return PQ_ELAUNCH; }
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a->C), dim3(256), 0, st, a->bboxes, a->C, (const unsigned*)vals1, (const unsigned*)rk1,
-                       (const unsigned*)offs, (const NmsMeta*)meta, a->iou_thr, kept, keep);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(NC), dim3(256), 0, st, a->bboxes, a->C, (const unsigned*)vals1, (const unsigned*)rk1,
+                       (const unsigned*)offs, (const unsigned*)maxb, a->iou_thr, kept, keep);
     PQ_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(1024), 0, st, a->bboxes, a->C, (const float*)keys1, (const unsigned*)vals1,
-                       (const unsigned*)keep, meta, a->dets, a->cap, a->count);
+                       (const unsigned*)keep, meta, a->dets, a->cap, a->count, a->img, a->N);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -78,6 +78,19 @@ class Evaluator:
         boxes = self._recover_bboxes(pred, torch.FloatTensor(self._input_size).to(dev), shapes.to(dev))
         b, n, w = boxes.shape
         cap = n * (w - 4)
+        if b > 1 and b * (w - 4) < 65535:
+            # the whole batch in one pq_nms call (images separated like one torch_nms call each); ONE device -> host copy
+            dets, img, cnt = ops.nms_batch(boxes, self._score_threshold, self._iou_threshold, cap=self._batch_cap(b, n, w - 4))
+            k = int(cnt.item())
+            if 0 <= k <= dets.shape[0]:
+                order = torch.sort(img[:k], stable=True).indices          # per-image lists, score order kept
+                rows = torch.cat([dets[:k][order], img[:k][order].float().unsqueeze(1)], 1).cpu().numpy()
+                res = []
+                for i in range(b):
+                    mine = rows[rows[:, 6] == i][:, :6]
+                    res.append(mine if len(mine) else np.zeros((0,), dtype=np.float32))
+                return res
+            ops.nms_grow(n, w - 4)              # candidate / output capacity exceeded: per-image path below sorts everything
         outs = [ops.nms(boxes[i], self._score_threshold, self._iou_threshold, cap=cap) for i in range(b)]
         counts = torch.cat([c for _, c in outs]).cpu().tolist()                     # the one synchronisation per batch
         if any(k < 0 for k in counts):          # candidate capacity exceeded somewhere: redo those images over all pairs
@@ -90,6 +103,11 @@ class Evaluator:
         for (dets, _), k in zip(outs, counts):
             res.append(dets[:k].cpu().numpy() if k else np.zeros((0,), dtype=np.float32))
         return res
+
+    @staticmethod
+    def _batch_cap(b: int, n: int, ncls: int) -> int:
+        """rows the batched NMS may return: every candidate the adaptive sort capacity admits can survive"""
+        return max(1024, min(b * n * ncls, b * ops.nms_capacity(n, ncls)))
 
     def evaluate(self) -> AP:
         for batch_img, batch_file_name, batch_img_shape, batch_label, batch_diff in self.dataset:

@@ -213,6 +213,37 @@ def nms(bboxes: torch.Tensor, score_thr: float, iou_thr: float, cap: Optional[in
     return dets, count
 
 
+def nms_batch(bboxes: torch.Tensor, score_thr: float, iou_thr: float, cap: Optional[int] = None, cand_cap: Optional[int] = None):
+    """Whole batch in ONE ``pq_nms`` call: ``bboxes`` (B, N, 4+C) -> (dets[cap,6], img int32[cap], count int32[1]) on device.
+    Every image is suppressed on its own exactly like one ``nms`` call per image (classes and the coordinate offset are per
+    image); the kept rows of all images come in descending score order, ``img`` holds their image -- a stable sort by ``img``
+    gives the per-image lists.  ``count == -1``: ``cand_cap`` (for the whole batch) was too small."""
+    _need_cuda(bboxes)
+    bboxes = bboxes.contiguous().float()
+    b, n, w = bboxes.shape
+    ncls = w - 4
+    total = b * n * ncls
+    cap = cap or total
+    if cand_cap is None:
+        cand_cap = b * nms_capacity(n, ncls)
+    if cand_cap >= total:
+        cand_cap = 0
+    l = lib()
+    need = l.pq_nms_batch_scratch_bytes(b, n, ncls)
+    key = (bboxes.device, need)
+    scratch = _nms_scratch.get(key)
+    if scratch is None:
+        scratch = torch.empty(need, device=bboxes.device, dtype=torch.uint8)
+        _nms_scratch.clear()
+        _nms_scratch[key] = scratch
+    dets = torch.empty(cap, 6, device=bboxes.device, dtype=torch.float32)
+    img = torch.zeros(cap, device=bboxes.device, dtype=torch.int32)
+    count = torch.zeros(1, device=bboxes.device, dtype=torch.int32)
+    args = abi.Nms(ptr(bboxes), ptr(dets), ptr(count), ptr(scratch), need, n, ncls, cap, score_thr, iou_thr, cand_cap, b, ptr(img))
+    check(l.pq_nms(C.byref(args), _stream()), 'pq_nms (batch)')
+    return dets, img, count
+
+
 # ----------------------------------------------------------------------------------------------- misc
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _need_cuda(param, grad)
