@@ -48,6 +48,7 @@ KERNEL_CLASS = {
     abi.OP_COPY_FWD: ('copy_fwd (shortcut/route/upsample)', 'hbm'), abi.OP_ROUTE_BWD: ('route_bwd', 'hbm'),
     abi.OP_LOSS_FWD: ('yolo_loss_fwd', 'hbm'), abi.OP_LOSS_BWD: ('yolo_loss_bwd', 'hbm'), abi.OP_FILL: ('fill', 'hbm'),
     abi.OP_TRANSPOSE: ('weight transposes (one launch)', 'hbm'),
+    abi.OP_BN_EVAL: ('bn vectors from running statistics (one launch)', 'hbm'),
     abi.OP_QAT_WPREP: ('qat weight scale+observe+quantise (one launch)', 'hbm'),
     abi.OP_QACT_FWD: ('qat activation observe+quantise', 'hbm'), abi.OP_QACT_BWD: ('qat activation backward', 'hbm'),
 }

@@ -280,6 +280,22 @@ typedef struct pq_bn_fwd_finalize_args {
 } pq_bn_fwd_finalize_args;
 int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream);
 
+/* Inference / frozen statistics: the per-channel vectors of EVERY BatchNorm of a net from its running statistics in ONE launch
+ * (one workgroup per table entry; the table lives in device memory).  Same arithmetic as pq_bn_fwd_finalize with train == 0:
+ * mean = rm*sf, invstd = 1/sqrt(rv+eps)/sf, scale = gamma*invstd, shift = beta - rm*gamma/sqrt(rv+eps)   (sf = 1 without QAT) */
+typedef struct pq_bn_eval_item {
+    const float* gamma; const float* beta; const float* running_mean; const float* running_var;
+    float* mean; float* invstd; float* scale; float* shift;
+    const float* sf;        /* QAT weight scale per channel or NULL */
+    float eps;
+    int32_t C;
+} pq_bn_eval_item;
+typedef struct pq_bn_eval_args {
+    const pq_bn_eval_item* items;   /* device pointer */
+    int32_t n_items;
+} pq_bn_eval_args;
+int pq_bn_eval_batch(const pq_bn_eval_args* a, void* stream);
+
 typedef struct pq_bn_bwd_finalize_args {
     const float* partial;   /* [nblk][2][ldp]: sum g, sum g*xhat */
     const float* gamma;
@@ -524,7 +540,8 @@ enum {
     PQ_OP_STEM_FWD, PQ_OP_STEM_WGRAD, PQ_OP_BN_FWD_FIN, PQ_OP_BN_BWD_FIN, PQ_OP_COPY_FWD, PQ_OP_ROUTE_BWD,
     PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD,
     PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD, PQ_OP_TRANSPOSE,
-    PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE, PQ_OP_CONV1X1_BWD
+    PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE, PQ_OP_CONV1X1_BWD,
+    PQ_OP_BN_EVAL
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -539,7 +556,7 @@ typedef struct pq_op {
         pq_bn_fwd_finalize_args bnf; pq_bn_bwd_finalize_args bnb;
         pq_copy_args cp; pq_route_bwd_args rb;
         pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill; pq_transpose_args tr;
-        pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr; pq_conv1x1_bwd_args c1b;
+        pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr; pq_conv1x1_bwd_args c1b; pq_bn_eval_args bne;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);

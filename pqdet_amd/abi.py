@@ -112,6 +112,15 @@ class BnFwdFin(C.Structure):
                 ('scratch', c_fp), ('tickets', c_fp), ('sf', c_fp)]
 
 
+class BnEvalItem(C.Structure):
+    _fields_ = [('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp), ('mean', c_fp), ('invstd', c_fp),
+                ('scale', c_fp), ('shift', c_fp), ('sf', c_fp), ('eps', f32), ('C', i32)]
+
+
+class BnEval(C.Structure):
+    _fields_ = [('items', c_fp), ('n_items', i32)]
+
+
 class BnBwdFin(C.Structure):
     _fields_ = [('partial', c_fp), ('gamma', c_fp), ('invstd', c_fp), ('dgamma', c_fp), ('dbeta', c_fp),
                 ('p', c_fp), ('q', c_fp), ('r', c_fp), ('nblk', i32), ('ldp', i32), ('C', i32), ('train', i32),
@@ -217,7 +226,7 @@ class _OpU(C.Union):
                 ('bnf', BnFwdFin), ('bnb', BnBwdFin), ('cp', Copy), ('rb', RouteBwd),
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
                 ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose),
-                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce), ('c1b', Conv1x1Bwd)]
+                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce), ('c1b', Conv1x1Bwd), ('bne', BnEval)]
 
 
 OPF_SIDE = 1
@@ -230,7 +239,7 @@ class Op(C.Structure):
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
  OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE, OP_QAT_WPREP, OP_QAT_WGRAD, OP_QACT_FWD,
- OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD) = range(1, 29)
+ OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL) = range(1, 30)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
@@ -238,7 +247,7 @@ OP_FIELD = {
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
     OP_TRANSPOSE: 'tr', OP_QAT_WPREP: 'qw', OP_QAT_WGRAD: 'qw', OP_QACT_FWD: 'qa', OP_QACT_BWD: 'qb',
-    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b',
+    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b', OP_BN_EVAL: 'bne',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -269,6 +278,7 @@ SIGNATURES = {
     'pq_stem3x3_wgrad': (C.c_int, [C.POINTER(StemWgrad), C.c_void_p]),
     'pq_stem3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32, i32]),
     'pq_bn_fwd_finalize': (C.c_int, [C.POINTER(BnFwdFin), C.c_void_p]),
+    'pq_bn_eval_batch': (C.c_int, [C.POINTER(BnEval), C.c_void_p]),
     'pq_bn_bwd_finalize': (C.c_int, [C.POINTER(BnBwdFin), C.c_void_p]),
     'pq_bn_finalize_scratch_bytes': (i64, [i32]),
     'pq_bn_finalize_tickets': (i32, [i32]),

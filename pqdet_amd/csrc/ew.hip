@@ -128,6 +128,19 @@ __global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_fwd_finalize_kernel(pq_bn_
     }
 }
 
+// every BatchNorm of a net from its running statistics, one workgroup per layer (same expressions as the eval branch above)
+__global__ __launch_bounds__(256) void bn_eval_batch_kernel(const pq_bn_eval_item* items) {
+    const pq_bn_eval_item it = items[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += 256) {
+        const float inv = 1.f / sqrtf(it.running_var[c] + it.eps);
+        const float sf = it.sf ? it.sf[c] : 1.f;
+        it.mean[c] = it.running_mean[c] * sf;
+        it.invstd[c] = inv / sf;
+        it.scale[c] = it.gamma[c] * inv / sf;
+        it.shift[c] = it.beta[c] - it.running_mean[c] * (it.gamma[c] * inv);
+    }
+}
+
 __global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_bwd_finalize_kernel(pq_bn_bwd_finalize_args a) {
     const int c = blockIdx.x * BNF_CH + (threadIdx.x & (BNF_CH - 1));
     double t1, t2;
@@ -371,6 +384,13 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
     PQ_CHECK_ARG(a->train || (a->running_mean && a->running_var), "eval mode needs running statistics");
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, a->train ? bn_row_groups(a->nblk, a->scratch && a->tickets) : 1),
                        dim3(BNF_CH * BNF_RL), 0, (hipStream_t)stream, *a);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_bn_eval_batch(const pq_bn_eval_args* a, void* stream) {
+    PQ_CHECK_ARG(a && a->items && a->n_items > 0, "bad args");
+    hipLaunchKernelGGL(bn_eval_batch_kernel, dim3(a->n_items), dim3(256), 0, (hipStream_t)stream, a->items);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -485,6 +485,10 @@ class Plan:
 
         if self.qat:
             self._emit_qat_weight_ops(flat, mods)
+        # statistics not trained (inference, model.eval() losses, tools.freeze_bn_stats): the per-channel vectors of all
+        # BatchNorms come from the running statistics in ONE launch at the start (slot filled in after the loop)
+        bne_idx = self._op(self.fwd, abi.OP_BN_EVAL, abi.BnEval(None, 0)) if not self.bn_train else None
+        bne_items = []
         for item in self._deferred:
             kind = item[0]
             if kind == 'qimg':                                 # QuantStub: observe + fake-quantise the input batch
@@ -533,6 +537,11 @@ class Plan:
                 b = out.bn
                 bm = b.module
                 train = self.bn_train
+                if not train:
+                    bne_items.append(abi.BnEvalItem(ptr(bm.weight), ptr(bm.bias), ptr(bm.running_mean), ptr(bm.running_var),
+                                                    ptr(b.mean), ptr(b.invstd), ptr(b.scale), ptr(b.shift),
+                                                    ptr(self._wq[i][1]) if self.qat else None, float(bm.eps), b.C))
+                    continue
                 sc, tk = self._bn_scratch(b.C)
                 a = abi.BnFwdFin(ptr(b.fwd_partial) if train else None, ptr(bm.weight), ptr(bm.bias), ptr(bm.running_mean),
                                  ptr(bm.running_var), ptr(bm.num_batches_tracked) if train else None, ptr(b.mean),
@@ -555,6 +564,18 @@ class Plan:
                 a = abi.Copy(a_.src(), b_.src() if b_ is not None else none, ptr(out.raw), out.B, out.H, out.W, a_.C,
                              out.ld, coff, up)
                 self._op(self.fwd, abi.OP_COPY_FWD, a)
+        if bne_idx is not None:
+            if bne_items:
+                table = (abi.BnEvalItem * len(bne_items))(*bne_items)
+                dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
+                self.keep.append(dev_table)
+                self.fwd[bne_idx].u.bne = abi.BnEval(dev_table.data_ptr(), len(bne_items))
+            else:                                   # a net without BatchNorm: turn the slot into a no-op
+                dummy = self._new(4)
+                nop = abi.Op()
+                nop.code = abi.OP_FILL
+                nop.u.fill = abi.Fill(dummy.data_ptr(), 0.0, 0)
+                self.fwd[bne_idx] = nop
         # heads
         nh = len(heads)
         self.nheads = nh
