@@ -17,13 +17,73 @@ import ctypes as C
 import io
 import json
 import os
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+MODELS = ('mobilenetv2-fpn', 'regnetx-600m-fpn', 'regnetx-600m-pan', 'regnety-400m-fpn')
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--model', default='mobilenetv2-fpn',
+                    help='BASELINE.json configs: mobilenetv2-fpn (the metric), regnetx-600m-fpn / -pan (configs 3, 4); '
+                         'any cfg name of pqdet_amd.model.zoo')
+    ap.add_argument('--qat', action='store_true', help='BASELINE config 5: quantisation-aware training step (use --batch 12)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3, help='timed steps of the CPU oracle leg (SURVEY 8d: >= 3)')
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (this parent has not touched the GPU
+    and never does), one per GPU, and relay them.  Rank 0's stdout carries the JSON line.  Mirrors what
+    ``python -m torch.distributed.run --nproc-per-node N`` sets up (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def resolve_world(args):
+    """(world, rank, local) from the launcher's environment; --gpus must agree with it.  Exits non-zero on a mismatch:
+    a silent one-GPU run printed as an N-GPU line would be an invalid measurement."""
+    if 'WORLD_SIZE' not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+        return 1, 0, 0
+    world = int(os.environ['WORLD_SIZE'])
+    if world != args.gpus:
+        print('[bench] --gpus %d does not match WORLD_SIZE=%d of the launcher: refusing to run' % (args.gpus, world),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    return world, int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+if __name__ == '__main__':
+    # decided BEFORE torch / the HIP library are imported: the parent of a self-launched multi-rank run stays GPU-free
+    _ARGS = parse_args()
+    _WORLD = resolve_world(_ARGS)
+
+import torch  # noqa: E402
 
 from pqdet_amd import abi, optim  # noqa: E402
 from pqdet_amd.dataset import labels  # noqa: E402
@@ -193,22 +253,9 @@ def cpu_baseline(batch, size, steps=2, model='mobilenetv2-fpn'):
                       '%.2f s/step' % (steps, model, size, size, batch, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=16)
-    ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--model', default='mobilenetv2-fpn', choices=zoo.available(),
-                    help='BASELINE.json configs: mobilenetv2-fpn (the metric), regnetx-600m-fpn / -pan (configs 3, 4)')
-    ap.add_argument('--qat', action='store_true', help='BASELINE config 5: quantisation-aware training step (use --batch 12)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+def main(args, world, rank, local):
+    if args.model not in zoo.available():
+        sys.exit('[bench] unknown model %r (have: %s)' % (args.model, ', '.join(zoo.available())))
     dist = None
     rehearsal = os.environ.get('PQ_BENCH_REHEARSAL') == '1'     # all ranks on cuda:0 over gloo: exercises this file's
     if rehearsal:                                               # multi-rank flow on a one-GPU box (never a measurement)
@@ -303,7 +350,7 @@ def main():
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline and not args.qat:
-            line['cpu_baseline'] = cpu_baseline(B, S, model=args.model)
+            line['cpu_baseline'] = cpu_baseline(B, S, steps=max(1, args.cpu_steps), model=args.model)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -311,4 +358,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    main(_ARGS, *_WORLD)

@@ -91,7 +91,7 @@ typedef struct pq_conv1x1_fwd_args {
     const float* w;      /* [O][I] */
     const float* bias;   /* [O] or NULL */
     float* out;          /* [M][ldo] raw */
-    float* partial;      /* [pq_conv1x1_blocks(M, O)][2][ldp] or NULL */
+    float* partial;      /* [pq_conv1x1_blocks_k(M, O, I, 0)][2][ldp] or NULL */
     int32_t M, I, O, ldo, ldp;
     int32_t sub, OH, OW, IH, IW;   /* sub==1: plain; else strided gather of input rows */
     float* scratch;      /* optional, >= pq_conv1x1_splitk_scratch_bytes(M, O, I): enables split-K where pq_conv1x1_splitk(M, O, I) > 1;
@@ -100,6 +100,11 @@ typedef struct pq_conv1x1_fwd_args {
 int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream);
 /* row-blocks (partial-sum rows) a GEMM with M rows and N output columns uses: fwd N=O, dgrad sink N=I */
 int32_t pq_conv1x1_blocks(int32_t M, int32_t N);
+/* the same count for a known contraction length K (kind 0: forward, N = O, K = I; kind 1: data gradient, N = I, K = O).
+ * pq_conv1x1_fwd / _dgrad tile their rows by this function of (M, N, K, kind): `partial` (forward) and the sink's `partial`
+ * (data gradient) must be sized with it.  pq_conv1x1_blocks(M, N) == pq_conv1x1_blocks_k(M, N, 0, 0) only describes
+ * contractions that are not multiples of 32. */
+int32_t pq_conv1x1_blocks_k(int32_t M, int32_t N, int32_t K, int32_t kind);
 /* split-K factor the GEMM with M rows, N output columns and a K-long contraction uses when given scratch (1 = none) */
 int32_t pq_conv1x1_splitk(int32_t M, int32_t N, int32_t K);
 int64_t pq_conv1x1_splitk_scratch_bytes(int32_t M, int32_t N, int32_t K);

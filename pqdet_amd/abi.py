@@ -254,6 +254,7 @@ OP_FIELD = {
 SIGNATURES = {
     'pq_conv1x1_fwd': (C.c_int, [C.POINTER(Conv1x1Fwd), C.c_void_p]),
     'pq_conv1x1_blocks': (i32, [i32, i32]),
+    'pq_conv1x1_blocks_k': (i32, [i32, i32, i32, i32]),
     'pq_conv1x1_splitk': (i32, [i32, i32, i32]),
     'pq_conv1x1_splitk_scratch_bytes': (C.c_int64, [i32, i32, i32]),
     'pq_conv1x1_dgrad': (C.c_int, [C.POINTER(Conv1x1Dgrad), C.c_void_p]),

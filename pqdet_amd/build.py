@@ -16,6 +16,7 @@ ARCH = 'gfx950'
 SOURCES = {            # file -> extra flags
     'api.hip': [],
     'gemm.hip': [],
+    'gemm2.hip': ['-Wno-inline-asm'],
     'dwconv.hip': [],
     'dwtile.hip': [],
     'gconv.hip': [],

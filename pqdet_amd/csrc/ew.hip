@@ -5,18 +5,19 @@
 namespace pq {
 
 // ------------------------------------------------------------------------------------------------ BN finalize
-// partial is [nblk][2][ldp] (one row pair per producer row-block).  Block = 64 channels x 4 row lanes (a wave reads 256
-// contiguous bytes of one partial row); grid = (ceil(C/64), R).  Each block sums its slice of the rows with 8 independent
-// loads in flight per thread (the kernel is pure load latency).  R > 1 (long partial lists, up to 8192 rows for the
+// partial is [nblk][2][ldp] (one row pair per producer row-block).  Block = 16 channels x 16 row lanes (a wave reads 64
+// contiguous bytes of four partial rows); grid = (ceil(C/16), R).  Each block sums its slice of the rows with 8 independent
+// loads in flight per thread: the kernel is pure load latency and sits on the layer-to-layer critical path, so the rows
+// are spread over many lanes (a 128-row list is ONE batch of loads per thread; 64 x 4 lanes needed four dependent rounds).  R > 1 (long partial lists, up to 8192 rows for the
 // 1M-pixel layers): slices go to a double scratch, an agent-scope ticket elects the last block of a channel group, which
 // adds the R slices in fixed order (deterministic) and finalises; it also re-arms the ticket for the next launch.
-constexpr int BNF_CH = 64, BNF_RL = 4, BNF_UNROLL = 8, BNF_MAXR = 64;
+constexpr int BNF_CH = 16, BNF_RL = 16, BNF_UNROLL = 8, BNF_MAXR = 64;
 
 __device__ __forceinline__ bool bn_reduce_partials(const float* partial, int nblk, int ldp, int C, double* scratch,
                                                     unsigned* tickets, double& t1, double& t2) {
     __shared__ double sh[2][BNF_RL][BNF_CH];
     __shared__ unsigned s_ticket;
-    const int cl = threadIdx.x & (BNF_CH - 1), rl = threadIdx.x >> 6;
+    const int cl = threadIdx.x & (BNF_CH - 1), rl = threadIdx.x / BNF_CH;
     const int cg = blockIdx.x, c = cg * BNF_CH + cl;
     const int R = gridDim.y, r = blockIdx.y;
     const int per = (nblk + R - 1) / R;

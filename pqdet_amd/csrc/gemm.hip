@@ -817,14 +817,51 @@ static TilePick pick_tile(int M, int N) {
     }
     return {0, best, kTiles[best].bm, kTiles[best].bn};
 }
-extern "C" int32_t pq_conv1x1_blocks(int32_t M, int32_t N) {
-    const TilePick t = pick_tile(M, N);
-    return (M + t.bm - 1) / t.bm;
-}
+// gemm2.hip (LDS-DMA ring kernels)
+int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st);
+int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st);
+int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* stride_out, hipStream_t st);
+int g2_wgrad_splits(int M, int I, int O);
 
+// Row-block height of the GEMM (M rows, N output columns, contraction K; kind 0 forward, 1 data gradient).  The BatchNorm
+// statistics rows are sized from it at plan time, so it is a pure function of the shape.  K % 32 == 0 (K >= 64) shapes are
+// tiled for the LDS-DMA kernels: the largest tile that still gives every CU two workgroups; the data gradient stages two
+// tensors per row, so its row block is 64 wherever that keeps two workgroups per CU in LDS.  PQ_G2_BM=64|128 forces (A/B).
+static int row_bm(int M, int N, int K, int kind) {
+    static const char* g2off = getenv("PQ_G2");
+    const bool g2 = !(g2off && g2off[0] == '0') && K >= (kind == 0 ? 128 : 64) && (K & 31) == 0 && N >= 64;
+    if (!g2) return pick_tile(M, N).bm;
+    static const char* force = getenv("PQ_G2_BM");
+    if (force) return atoi(force) >= 128 ? 128 : 64;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
+    if (kind == 0) return (t128 >= 400 || t12864 >= 400) ? 128 : 64;
+    return t128 >= 1024 ? 128 : 64;
+}
+extern "C" int32_t pq_conv1x1_blocks_k(int32_t M, int32_t N, int32_t K, int32_t kind) {
+    const int bm = row_bm(M, N, K, kind);
+    return (M + bm - 1) / bm;
+}
+extern "C" int32_t pq_conv1x1_blocks(int32_t M, int32_t N) { return pq_conv1x1_blocks_k(M, N, 0, 0); }
+
+// best column width for a fixed row-block height (same cost model as pick_tile)
+static TilePick pick_tile_bm(int M, int N, int bm) {
+    TilePick t = pick_tile(M, N);
+    if (t.bm == bm) return t;
+    int best = -1;
+    float best_cost = 3.4e38f;
+    for (int c = 0; c < 4; ++c) {
+        if (kTiles[c].bm != bm) continue;
+        const long gm = (M + kTiles[c].bm - 1) / kTiles[c].bm, gn = (N + kTiles[c].bn - 1) / kTiles[c].bn;
+        const long slots = 256L * kTiles[c].occ;
+        const long rounds = (gm * gn + slots - 1) / slots;
+        const float cost = (float)rounds * kTiles[c].occ * kTiles[c].bm * kTiles[c].bn / kTiles[c].eff;
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return {0, best, kTiles[best].bm, kTiles[best].bn};
+}
 template <int AMODE, bool BKN, int EMODE>
-static void launch_nt(const GemmP& p, hipStream_t st) {
-    const TilePick t = pick_tile(p.M, p.N);
+static void launch_nt(const GemmP& p, hipStream_t st, int bm) {
+    const TilePick t = pick_tile_bm(p.M, p.N, bm);
     dim3 blk(256);
     dim3 grid((p.N + t.bn - 1) / t.bn, (p.M + t.bm - 1) / t.bm);
     if (t.kind == 0) {
@@ -911,10 +948,16 @@ extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
         PQ_CHECK_LAUNCH();
         return PQ_OK;
     }
+    const int bm = row_bm(a->M, a->O, a->I, 0);
+    {
+        const int rc = g2_conv1x1_fwd(a, bm, st);
+        if (rc < 0) return rc;
+        if (rc == 1) { PQ_CHECK_LAUNCH(); return PQ_OK; }
+    }
     if (xform) {
-        if (a->partial) launch_nt<1, false, 1>(p, st); else launch_nt<1, false, 0>(p, st);
+        if (a->partial) launch_nt<1, false, 1>(p, st, bm); else launch_nt<1, false, 0>(p, st, bm);
     } else {
-        if (a->partial) launch_nt<0, false, 1>(p, st); else launch_nt<0, false, 0>(p, st);
+        if (a->partial) launch_nt<0, false, 1>(p, st, bm); else launch_nt<0, false, 0>(p, st, bm);
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -953,11 +996,17 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
         PQ_CHECK_LAUNCH();
         return PQ_OK;
     }
+    const int bm = row_bm(a->M, a->I, a->O, 1);
+    {
+        const int rc = g2_conv1x1_dgrad(a, bm, st);
+        if (rc < 0) return rc;
+        if (rc == 1) { PQ_CHECK_LAUNCH(); return PQ_OK; }
+    }
     if (a->wt) {        // transposed weights [I][ceil4(O)] (pad columns zero): B rows are K-contiguous like the forward operand
         p.b = a->wt; p.ldb = (a->O + 3) & ~3;
-        if (a->dy.y) launch_nt<2, false, 2>(p, st); else launch_nt<0, false, 2>(p, st);
+        if (a->dy.y) launch_nt<2, false, 2>(p, st, bm); else launch_nt<0, false, 2>(p, st, bm);
     } else {
-        if (a->dy.y) launch_nt<2, true, 2>(p, st); else launch_nt<0, true, 2>(p, st);
+        if (a->dy.y) launch_nt<2, true, 2>(p, st, bm); else launch_nt<0, true, 2>(p, st, bm);
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -984,6 +1033,8 @@ static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, 
 extern "C" int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t O) {
     bool big; int tiles, splits, rows;
     wgrad_plan(M, I, O, big, tiles, splits, rows);
+    const int s2 = g2_wgrad_splits(M, I, O);
+    if (s2 > splits) splits = s2;
     return (int64_t)splits * ((int64_t)O * I + O) * 4;
 }
 
@@ -993,6 +1044,22 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->in.ld & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "pitches must be multiples of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_conv1x1_wgrad: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     bool big; int tiles, splits, rows;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        int s2 = 0; size_t stride2 = 0;
+        const int rc = g2_conv1x1_wgrad(a, &s2, &stride2, st);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            PQ_CHECK_LAUNCH();
+            const int n0 = a->O * a->I;
+            if (s2 <= 64) hipLaunchKernelGGL(slab_reduce_cols_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
+                                             stride2, s2, a->dw, n0, (float*)nullptr, 0);
+            else hipLaunchKernelGGL(slab_reduce_kernel, dim3((n0 + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, stride2, s2,
+                                    a->dw, n0, (float*)nullptr, 0);
+            PQ_CHECK_LAUNCH();
+            return PQ_OK;
+        }
+    }
     wgrad_plan(a->M, a->I, a->O, big, tiles, splits, rows);
     GemmTP p{};
     p.dy = a->dy; p.x = a->in; p.slab = a->scratch; p.M = a->M; p.O = a->O; p.I = a->I;
@@ -1003,7 +1070,6 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
         PQ_CHECK_ARG((a->OH - 1) * a->sub < a->IH && (a->OW - 1) * a->sub < a->IW, "strided wgrad: input plane too small");
     }
     p.slab_stride = (size_t)a->O * a->I + a->O;
-    hipStream_t st = (hipStream_t)stream;
     dim3 grid(tiles, splits), blk(256);
     if (big) hipLaunchKernelGGL((gemm_tn_kernel<128, 128>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);

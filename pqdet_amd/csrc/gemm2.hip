@@ -1,0 +1,646 @@
+// 1x1 convolution GEMMs, second generation: operand tiles travel HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into
+// a ring of S stages, with the loads of D = S-1 k-tiles in flight behind a COUNTED s_waitcnt vmcnt + one raw s_barrier per
+// k-tile.  No staging registers, no ds_write, no address masking in the loop; the operand transform (BatchNorm affine +
+// activation clamp of the forward operand, the closed-form BatchNorm backward of the gradient pair) is applied to the
+// fragments after the ds_read, in the shadow of the 64-cycle v_mfma_f32_32x32x2_f32.  The per-k coefficients of a k-tile
+// ride in the same ring (global_load_lds_dword into a 256-byte slot per wave).
+//
+//   gemm2_nt : C[m][n] = sum_k A'[m][k] * B[n][k]     forward (A' = clamp(scale*x+shift), B = W[O][I])
+//                                                      dgrad   (A' = p*g + q*(y-mu) + r,  B = Wt[I][O])
+//   gemm2_tn : C[o][i] = sum_m dY'[m][o] * X'[m][i]    wgrad, rows split into slabs (same slab reduce as gemm.hip)
+//
+// LDS images are lane-linear per LDS-DMA piece (64 lanes x 16 B = 1 KiB): a k-tile row is 32 floats = 8 chunks of 16 B and
+// the chunk index is XOR-swizzled with (row >> 1) & 7 on the SOURCE address and again on the fragment read, which makes the
+// ds_read_b128 fragment reads (lane = row, lane half = k group) bank-conflict free without padding.
+//
+// The LDS-DMA instructions are issued from inline asm: hipcc then neither drains vmcnt(0) in front of every ds_read (it does
+// for its own builtin, because the DMA "may alias" the LDS array) nor counts them; ordering is by hand:
+//   RAW  issuing wave: s_waitcnt vmcnt(N) -> s_barrier -> any wave may ds_read the tile
+//   WAR  a stage is refilled only after the barrier that follows its last ds_read (whose data the MFMAs have consumed).
+//
+// mirrors: nn.Conv2d(k=1) forward / backward inside the conv blocks of the reference, model/parser.py:389-410.
+#include "common.h"
+
+namespace pq {
+
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte) : "memory", "m0");
+}
+__device__ __forceinline__ void glds4(const void* g, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_byte) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `tiles` k-tiles (NL loads each) of this wave are still in flight; tiles in 0..2
+template <int NL>
+__device__ __forceinline__ void wait_tiles(int tiles) {
+    if (tiles >= 2) wait_vmcnt<2 * NL>();
+    else if (tiles == 1) wait_vmcnt<NL>();
+    else wait_vmcnt<0>();
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+__device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+struct G2P {
+    const float* a0; const float* a1;                                    // x | g, y    [M][lda]
+    const float* c0; const float* c1; const float* c2; const float* c3;  // scale, shift | p, q, mu, r
+    int lda0, lda1;
+    float lo, hi;                                                         // clamp of the forward operand (relu6: 0, 6)
+    const float* b; int ldb;                                              // [N][ldb], contraction index contiguous
+    int M, N, K;
+    float* out; const float* bias; float* partial; int ldo, ldp;          // EMODE 0 / 1
+    pq_gsink sink;                                                        // EMODE 2
+};
+
+// AMODE 0: A as stored; 1: clamp(c0*a + c1, lo, hi); 2: c0*g + c1*(y - c2) + c3.   EMODE 0: store(+bias); 1: + statistics;
+// 2: gradient sink (16-byte rows only: the host checks alignment).   K % 32 == 0.
+template <int BM, int BN, int AMODE, int EMODE, int S>
+__global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
+    constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
+    constexpr int NA = AMODE == 2 ? 2 : 1;
+    constexpr int A_FL = BM * 32, B_FL = BN * 32;
+    constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);        // coefficient floats per wave per stage
+    constexpr int NC = AMODE == 2 ? 2 : (AMODE == 1 ? 1 : 0);
+    constexpr int STAGE = NA * A_FL + B_FL + 4 * CW;                     // floats
+    constexpr int PA = BM / 32, PB = BN / 32;                            // 1 KiB pieces per wave per k-tile
+    constexpr int NL = NA * PA + PB + NC;                                // LDS-DMA instructions per wave per k-tile
+    constexpr int D = S - 1;
+    static_assert(D >= 1 && D <= 3, "ring depth");
+    static_assert(2 * NL <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    int bnx, bmy;
+    xcd_block(bnx, bmy);
+    const int m0 = bmy * BM, n0 = bnx * BN;
+    const int M = p.M, N = p.N, K = p.K;
+    const int nk = K / 32;
+
+    // ---- source pointers of this lane's share of a k-tile (advanced by 32 floats per issued tile)
+    const float* pa[NA][PA];
+    const float* pb[PB];
+    const float* pc[NC > 0 ? NC : 1];
+    {
+        const int sl = lane & 7;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int r = 8 * (w * PA + q) + (lane >> 3);
+            const int c = sl ^ ((r >> 1) & 7);
+            const size_t row = (size_t)min(m0 + r, M - 1);
+            pa[0][q] = p.a0 + row * (size_t)p.lda0 + 4 * c;
+            if (AMODE == 2) pa[NA - 1][q] = p.a1 + row * (size_t)p.lda1 + 4 * c;
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int r = 8 * (w * PB + q) + (lane >> 3);
+            const int c = sl ^ ((r >> 1) & 7);
+            pb[q] = p.b + (size_t)min(n0 + r, N - 1) * (size_t)p.ldb + 4 * c;
+        }
+        if (AMODE == 1) pc[0] = (lane < 32 ? p.c0 : p.c1) + (lane & 31);
+        if (AMODE == 2) { pc[0] = (lane < 32 ? p.c0 : p.c1) + (lane & 31); pc[NC - 1] = (lane < 32 ? p.c2 : p.c3) + (lane & 31); }
+    }
+    const unsigned lbase = lds_addr(lds);
+    auto issue = [&](int s) {
+        const unsigned sb = lbase + (unsigned)(s * STAGE) * 4u;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int q = 0; q < PA; ++q) {
+                glds16(pa[a][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(a * A_FL + (w * PA + q) * 256) * 4u));
+                pa[a][q] += 32;
+            }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            glds16(pb[q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NA * A_FL + (w * PB + q) * 256) * 4u));
+            pb[q] += 32;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            glds4(pc[c], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NA * A_FL + B_FL + w * CW + 64 * c) * 4u));
+            pc[c] += 32;
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int swz = (lrow >> 1) & 7;
+    const float lo = p.lo, hi = p.hi;
+    auto compute = [&](int s) {
+        const float* As = lds + s * STAGE;
+        const float* Bs = As + NA * A_FL;
+        const float* Cs = Bs + B_FL + w * CW;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ((2 * ks + lh) ^ swz) << 2;
+            float4 af[TI], yf[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + 32 * i + lrow) * 32 + ch]);
+                if (AMODE == 2) yf[i] = *reinterpret_cast<const float4*>(&As[A_FL + (wm * WM + 32 * i + lrow) * 32 + ch]);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + 32 * j + lrow) * 32 + ch]);
+            float ak[TI][4], bk[TJ][4];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) { bk[j][0] = bf[j].x; bk[j][1] = bf[j].y; bk[j][2] = bf[j].z; bk[j][3] = bf[j].w; }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) { ak[i][0] = af[i].x; ak[i][1] = af[i].y; ak[i][2] = af[i].z; ak[i][3] = af[i].w; }
+            if (AMODE == 1) {
+                const float4 c0 = *reinterpret_cast<const float4*>(&Cs[ks * 8 + 4 * lh]);
+                const float4 c1 = *reinterpret_cast<const float4*>(&Cs[32 + ks * 8 + 4 * lh]);
+                const float s4[4] = {c0.x, c0.y, c0.z, c0.w}, h4[4] = {c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ak[i][q] = __builtin_amdgcn_fmed3f(fmaf(s4[q], ak[i][q], h4[q]), lo, hi);
+            } else if (AMODE == 2) {
+                const float4 c0 = *reinterpret_cast<const float4*>(&Cs[ks * 8 + 4 * lh]);
+                const float4 c1 = *reinterpret_cast<const float4*>(&Cs[32 + ks * 8 + 4 * lh]);
+                const float4 c2 = *reinterpret_cast<const float4*>(&Cs[64 + ks * 8 + 4 * lh]);
+                const float4 c3 = *reinterpret_cast<const float4*>(&Cs[96 + ks * 8 + 4 * lh]);
+                const float p4[4] = {c0.x, c0.y, c0.z, c0.w}, q4[4] = {c1.x, c1.y, c1.z, c1.w};
+                const float m4[4] = {c2.x, c2.y, c2.z, c2.w}, r4[4] = {c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const float yy[4] = {yf[i].x, yf[i].y, yf[i].z, yf[i].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ak[i][q] = fmaf(p4[q], ak[i][q], fmaf(q4[q], yy[q] - m4[q], r4[q]));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32x2(ak[i][q], bk[j][q], acc[i][j]);
+        }
+    };
+
+    // ---- main loop: ring of S stages, D tiles in flight
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) issue(d);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int issued = min(nk, kt + D);
+        wait_tiles<NL>(issued - kt - 1);
+        __builtin_amdgcn_s_barrier();
+        if (kt + D < nk) issue((kt + D) % S);
+        compute(kt % S);
+    }
+    __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring: it becomes epilogue scratch
+
+    // ---------------------------------------------------------------- epilogue (same row-major LDS patches as gemm.hip)
+    float* patch = lds + w * (32 * 36);
+    float* red = lds + 4 * (32 * 36);              // [2][2][BN]
+    bool want_stats = false;
+    if (EMODE == 2) {
+        const pq_gsink& sk = p.sink;
+        const bool affine = sk.scale != nullptr;
+        const bool stats = sk.mean != nullptr && sk.partial != nullptr;
+        const ActParam sact = act_param(sk.act);
+        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
+        want_stats = sk.finalize && stats;
+        const int c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int nb = n0 + wn * WN + 32 * j;
+            const int nn = nb + c4;
+            const bool nok = nn < N;
+            const int nc = nok ? nn : 0;
+            float ca[4], cb[4], cm[4], ci[4], t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ca[u] = affine ? sk.scale[nc + u] : 1.f; cb[u] = affine ? sk.shift[nc + u] : 0.f;
+                cm[u] = stats ? sk.mean[nc + u] : 0.f; ci[u] = stats ? sk.invstd[nc + u] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int mb = m0 + wm * WM + 32 * i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lrow] = acc[i][j][r];
+                float4 yq[4], gq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mc = min(mb + (lane >> 3) + 8 * q, M - 1);
+                    yq[q] = need_y ? ldg4(sk.y + (size_t)mc * sk.ldy + nc) : f4zero();
+                    gq[q] = sk.accumulate ? ldg4(sk.g + (size_t)mc * sk.ldg + nc) : f4zero();
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = (lane >> 3) + 8 * q, m = mb + row;
+                    const float4 a4 = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
+                    float dz[4] = {a4.x + gq[q].x, a4.y + gq[q].y, a4.z + gq[q].z, a4.w + gq[q].w};
+                    const float yy[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w};
+                    if (need_y) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) dz[u] *= act_bwd(fmaf(ca[u], yy[u], cb[u]), sact);
+                    }
+                    if (m < M && nok) {
+                        stg4(sk.g + (size_t)m * sk.ldg + nn, make_float4(dz[0], dz[1], dz[2], dz[3]));
+                        if (stats) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { t1[u] += dz[u]; t2[u] = fmaf(dz[u], (yy[u] - cm[u]) * ci[u], t2[u]); }
+                        }
+                    }
+                }
+            }
+            if (want_stats) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int off = 8; off <= 32; off <<= 1) { t1[u] += __shfl_xor(t1[u], off); t2[u] += __shfl_xor(t2[u], off); }
+                    if (lane < 8) {
+                        red[(0 * 2 + wm) * BN + wn * WN + 32 * j + c4 + u] = t1[u];
+                        red[(1 * 2 + wm) * BN + wn * WN + 32 * j + c4 + u] = t2[u];
+                    }
+                }
+            }
+        }
+    } else {
+        want_stats = (EMODE == 1) && p.partial != nullptr;
+        const bool vec_out = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
+        float s1[TJ], s2[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int nb = n0 + wn * WN + 32 * j;
+            const int n = nb + lrow;
+            const bool nok = n < N;
+            const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int mb = m0 + wm * WM + 32 * i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float v = acc[i][j][r] + bias;
+                    if (vec_out) patch[row * 36 + lrow] = v;
+                    else if (mb + row < M && nok) p.out[(size_t)(mb + row) * p.ldo + n] = v;
+                    if (EMODE == 1 && mb + row < M && nok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                }
+                if (vec_out) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
+                        const int m = mb + row, nn = nb + c4;
+                        if (m < M && nn < N) {
+                            const float4 v4 = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
+                            float* dst = p.out + (size_t)m * p.ldo + nn;
+                            if (nn + 3 < N) stg4(dst, v4);
+                            else { const float e[4] = {v4.x, v4.y, v4.z, v4.w}; for (int u = 0; u < 4 && nn + u < N; ++u) dst[u] = e[u]; }
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                s1[j] += __shfl_xor(s1[j], 32);
+                s2[j] += __shfl_xor(s2[j], 32);
+                if (lh == 0) {
+                    red[(0 * 2 + wm) * BN + wn * WN + 32 * j + lrow] = s1[j];
+                    red[(1 * 2 + wm) * BN + wn * WN + 32 * j + lrow] = s2[j];
+                }
+            }
+        }
+    }
+    if (want_stats) {   // uniform across the block
+        float* part = (EMODE == 2) ? p.sink.partial : p.partial;
+        const int ldp = (EMODE == 2) ? p.sink.ldp : p.ldp;
+        __syncthreads();
+        if (t < BN) {
+            const float a = red[(0 * 2 + 0) * BN + t] + red[(0 * 2 + 1) * BN + t];
+            const float b = red[(1 * 2 + 0) * BN + t] + red[(1 * 2 + 1) * BN + t];
+            const int n = n0 + t;
+            if (n < N) {
+                float* dst = part + (size_t)bmy * 2 * ldp;
+                dst[n] = a;
+                dst[ldp + n] = b;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad (TN)
+struct G2TP {
+    const float* g; const float* y; const float* p; const float* q; const float* mu; const float* r; int ldg, ldy;
+    const float* x; const float* scale; const float* shift; int ldx; float lo, hi;
+    float* slab; size_t slab_stride;
+    int M, O, I, rows_per_split;
+};
+
+// TWO: dy' = p*g + q*(y-mu) + r (else dy' = g).  XA: x' = clamp(scale*x + shift, lo, hi) (else x' = x).
+// 4 waves as WGO x (4 / WGO) over (O, I).  rows_per_split % 32 == 0 and M % 32 == 0.
+template <int BO, int BI, int WGO, bool TWO, bool XA, int S>
+__global__ __launch_bounds__(256) void gemm2_tn_kernel(G2TP p) {
+    constexpr int WGI = 4 / WGO;
+    constexpr int WO = BO / WGO, WI = BI / WGI, TO = WO / 32, TI = WI / 32;
+    constexpr int NY = TWO ? 2 : 1;
+    constexpr int Y_FL = 32 * BO, X_FL = 32 * BI;
+    constexpr int STAGE = NY * Y_FL + X_FL;
+    constexpr int PY = BO / 32, PX = BI / 32;             // 1 KiB pieces per wave per k-tile (256 floats each)
+    constexpr int NL = NY * PY + PX;
+    constexpr int D = S - 1;
+    static_assert(WO % 32 == 0 && WI % 32 == 0, "wave tile");
+    static_assert(BO % 32 == 0 && BI % 32 == 0, "pieces per wave");
+    static_assert(2 * NL <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wo = w / WGI, wi = w % WGI;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int tiles_i = (p.I + BI - 1) / BI;
+    int btile, split;
+    xcd_block(btile, split);
+    const int to = btile / tiles_i, ti = btile % tiles_i;
+    const int o0 = to * BO, i0 = ti * BI;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    const int nk = (mend - mbeg) / 32;
+    const int Opad = (p.O + 3) & ~3, Ipad = (p.I + 3) & ~3;
+
+    // ---- source pointers: piece q of a [32][BW] tile covers floats [256*q', 256*q'+256) of the row-major tile image
+    const float* py[NY][PY];
+    const float* px[PX];
+#pragma unroll
+    for (int q = 0; q < PY; ++q) {
+        const int f = (w * PY + q) * 256 + lane * 4;
+        const int r = f / BO, c = min(o0 + f % BO, Opad - 4);
+        py[0][q] = p.g + (size_t)(mbeg + r) * (size_t)p.ldg + c;
+        if (TWO) py[NY - 1][q] = p.y + (size_t)(mbeg + r) * (size_t)p.ldy + c;
+    }
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+        const int f = (w * PX + q) * 256 + lane * 4;
+        const int r = f / BI, c = min(i0 + f % BI, Ipad - 4);
+        px[q] = p.x + (size_t)(mbeg + r) * (size_t)p.ldx + c;
+    }
+    const size_t sg = (size_t)32 * p.ldg, sy = (size_t)32 * p.ldy, sx = (size_t)32 * p.ldx;
+    const unsigned lbase = lds_addr(lds);
+    auto issue = [&](int s) {
+        const unsigned sb = lbase + (unsigned)(s * STAGE) * 4u;
+#pragma unroll
+        for (int q = 0; q < PY; ++q) {
+            glds16(py[0][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)((w * PY + q) * 256) * 4u));
+            py[0][q] += sg;
+            if (TWO) {
+                glds16(py[NY - 1][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(Y_FL + (w * PY + q) * 256) * 4u));
+                py[NY - 1][q] += sy;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            glds16(px[q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NY * Y_FL + (w * PX + q) * 256) * 4u));
+            px[q] += sx;
+        }
+    };
+
+    // prologue tiles first, then this lane's per-column coefficients (they never change: registers).  These are the only
+    // compiler-visible global loads of the kernel; the empty asm below makes the compiler wait for them HERE, once (it
+    // drains the prologue tiles with them, which the first k-tile needs anyway) -- left alone it puts its vmcnt(0) at their
+    // first use inside the k-loop, where it would drain the LDS-DMA ring on every iteration.
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) issue(d);
+    float cp[TO], cq[TO], cm[TO], cr[TO], xs[TI], xh[TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a) {
+        const int o = min(o0 + wo * WO + 32 * a + lrow, p.O - 1);
+        cp[a] = TWO ? p.p[o] : 1.f; cq[a] = TWO ? p.q[o] : 0.f; cm[a] = TWO ? p.mu[o] : 0.f; cr[a] = TWO ? p.r[o] : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < TI; ++b) {
+        const int i = min(i0 + wi * WI + 32 * b + lrow, p.I - 1);
+        xs[b] = (XA && p.scale) ? p.scale[i] : 1.f; xh[b] = (XA && p.scale) ? p.shift[i] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < TO; ++a) asm volatile("" : "+v"(cp[a]), "+v"(cq[a]), "+v"(cm[a]), "+v"(cr[a]));
+#pragma unroll
+    for (int b = 0; b < TI; ++b) asm volatile("" : "+v"(xs[b]), "+v"(xh[b]));
+    const float lo = p.lo, hi = p.hi;
+
+    f32x16 acc[TO][TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto compute = [&](int s) {
+        const float* Gs = lds + s * STAGE + wo * WO + lrow;
+        const float* Xs = lds + s * STAGE + NY * Y_FL + wi * WI + lrow;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int row = 2 * kk + lh;
+            float av[TO], bv[TI];
+#pragma unroll
+            for (int a = 0; a < TO; ++a) {
+                const float g = Gs[row * BO + 32 * a];
+                if (TWO) { const float y = Gs[Y_FL + row * BO + 32 * a]; av[a] = fmaf(cp[a], g, fmaf(cq[a], y - cm[a], cr[a])); }
+                else av[a] = g;
+            }
+#pragma unroll
+            for (int b = 0; b < TI; ++b) {
+                const float x = Xs[row * BI + 32 * b];
+                bv[b] = XA ? __builtin_amdgcn_fmed3f(fmaf(xs[b], x, xh[b]), lo, hi) : x;
+            }
+#pragma unroll
+            for (int a = 0; a < TO; ++a)
+#pragma unroll
+                for (int b = 0; b < TI; ++b) acc[a][b] = mfma32x2(av[a], bv[b], acc[a][b]);
+        }
+    };
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int issued = min(nk, kt + D);
+        wait_tiles<NL>(issued - kt - 1);
+        __builtin_amdgcn_s_barrier();
+        if (kt + D < nk) issue((kt + D) % S);
+        compute(kt % S);
+    }
+
+    float* dst = p.slab + (size_t)split * p.slab_stride;
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b) {
+            const int i = i0 + wi * WI + 32 * b + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo * WO + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < p.O && i < p.I) dst[(size_t)o * p.I + i] = acc[a][b][r];
+            }
+        }
+}
+
+}  // namespace pq
+
+using namespace pq;
+
+// ------------------------------------------------------------------------------------------------ host side
+static bool g2_enabled() {
+    static const char* e = getenv("PQ_G2");
+    return !(e && e[0] == '0');
+}
+static bool g2_raise_lds(const void* fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+}
+
+template <int BM, int BN, int AMODE, int EMODE, int S>
+static int g2_launch_nt(const G2P& p, hipStream_t st) {
+    constexpr int NA = AMODE == 2 ? 2 : 1;
+    constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);
+    constexpr int STAGE = NA * BM * 32 + BN * 32 + 4 * CW;
+    constexpr size_t ring = (size_t)S * STAGE * 4, epi = (size_t)(4 * 32 * 36 + 4 * BN) * 4;
+    constexpr size_t bytes = ring > epi ? ring : epi;
+    static bool ok = g2_raise_lds((const void*)gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>);
+    if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>), grid, dim3(256), bytes, st, p);
+    return PQ_OK;
+}
+
+// Column-tile width for a row-block height the caller has fixed (pq_conv1x1_blocks decides BM from (M, N) alone because the
+// statistics rows are sized from it): 128-wide tiles while they still give every CU two workgroups.
+static int g2_pick_bn(int M, int N, int bm) {
+    static const char* force = getenv("PQ_G2_BN");
+    if (force) return atoi(force) >= 128 ? 128 : 64;
+    if (N <= 64) return 64;
+    const long tiles128 = (long)((M + bm - 1) / bm) * ((N + 127) / 128);
+    return tiles128 >= 512 ? 128 : 64;
+}
+
+template <int AMODE, int EMODE>
+static int g2_dispatch_nt(const G2P& p, int bm, hipStream_t st) {
+    const int bn = g2_pick_bn(p.M, p.N, bm);
+    // ring depth by LDS budget: two workgroups per CU (<= 80 KB each)
+    if (AMODE == 2) {
+        if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 3>(p, st) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st);
+        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st);
+    }
+    if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st);
+    return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st);
+}
+
+static bool act_clamp(int act, float& lo, float& hi) {
+    const float inf = __builtin_huge_valf();
+    if (act == PQ_ACT_LINEAR) { lo = -inf; hi = inf; return true; }
+    if (act == PQ_ACT_RELU) { lo = 0.f; hi = inf; return true; }
+    if (act == PQ_ACT_RELU6) { lo = 0.f; hi = 6.f; return true; }
+    return false;
+}
+
+// returns 1 when the launch was taken, 0 when the shape / operands are outside this kernel family (caller falls back),
+// < 0 on error
+int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st) {
+    if (!g2_enabled() || a->sub > 1 || a->in.qstate || (a->I & 31) || a->I < 128 || a->O < 64 || a->scratch) return 0;
+    if ((a->in.ld & 3) || (((uintptr_t)a->in.x) & 15) || (((uintptr_t)a->w) & 15)) return 0;
+    G2P p{};
+    if (!act_clamp(a->in.act, p.lo, p.hi)) return 0;
+    const bool xform = a->in.scale != nullptr;
+    if (!xform && a->in.act != PQ_ACT_LINEAR) return 0;
+    p.a0 = a->in.x; p.lda0 = a->in.ld; p.c0 = a->in.scale; p.c1 = a->in.shift;
+    p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->O; p.K = a->I;
+    p.out = a->out; p.bias = a->bias; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
+    int rc;
+    if (xform) rc = a->partial ? g2_dispatch_nt<1, 1>(p, bm, st) : g2_dispatch_nt<1, 0>(p, bm, st);
+    else rc = a->partial ? g2_dispatch_nt<0, 1>(p, bm, st) : g2_dispatch_nt<0, 0>(p, bm, st);
+    return rc == PQ_OK ? 1 : rc;
+}
+
+int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st) {
+    if (!g2_enabled() || a->sub > 1 || !a->wt || a->scratch || (a->O & 31) || a->O < 64 || a->I < 64 || a->dx.qstate) return 0;
+    const pq_gsink& sk = a->dx;
+    const bool stats = sk.mean != nullptr && sk.partial != nullptr;
+    const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
+    if ((a->I & 3) || (sk.ldg & 3) || (((uintptr_t)sk.g) & 15) || (need_y && ((sk.ldy & 3) || (((uintptr_t)sk.y) & 15)))) return 0;
+    if ((((uintptr_t)a->dy.g) & 15) || (a->dy.y && (((uintptr_t)a->dy.y) & 15)) || (((uintptr_t)a->wt) & 15)) return 0;
+    G2P p{};
+    p.a0 = a->dy.g; p.a1 = a->dy.y; p.lda0 = a->dy.ldg; p.lda1 = a->dy.ldy;
+    p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
+    p.b = a->wt; p.ldb = a->O; p.M = a->M; p.N = a->I; p.K = a->O;      // O % 32 == 0: the transposed rows have no pad
+    p.sink = a->dx;
+    const int rc = a->dy.y ? g2_dispatch_nt<2, 2>(p, bm, st) : g2_dispatch_nt<0, 2>(p, bm, st);
+    return rc == PQ_OK ? 1 : rc;
+}
+
+// ---- wgrad
+struct G2WPlan { bool ok; int bo, bi, wgo, tiles, splits, rows; };
+static G2WPlan g2_wgrad_plan(int M, int I, int O) {
+    G2WPlan pl{};
+    // measured (scripts/gemm_bench.py wgrad): the ring kernel ties the register-staged gemm_tn on the neck shapes (70 TF) and
+    // loses on the short-contraction mid layers, so it is opt-in (PQ_G2_TN=1) until its slab epilogue is reworked
+    static const char* tn_env = getenv("PQ_G2_TN");
+    pl.ok = g2_enabled() && tn_env && tn_env[0] == '1' && (M % 32) == 0 && I >= 32 && O >= 32 && (I & 3) == 0 && (O & 3) == 0;
+    if (!pl.ok) return pl;
+    pl.bo = O >= 96 ? 128 : 64;
+    pl.bi = I >= 112 ? 128 : (I > 64 ? 96 : 64);
+    if (pl.bo == 64 && pl.bi == 96) pl.bi = 128;
+    static const char* tile_env = getenv("PQ_G2_WG_TILE");          // "BOxBI" (A/B timing)
+    if (tile_env) { int a = 0, b = 0; if (sscanf(tile_env, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || b == 128)) { pl.bo = a; pl.bi = b; } }
+    pl.wgo = (pl.bi == 96) ? 4 : 2;
+    pl.tiles = ((O + pl.bo - 1) / pl.bo) * ((I + pl.bi - 1) / pl.bi);
+    static const char* tgt_env = getenv("PQ_G2_WG_TARGET");
+    const int target = tgt_env ? atoi(tgt_env) : 256;
+    int want = (target + pl.tiles - 1) / pl.tiles;
+    const int maxs = M / 128 > 0 ? M / 128 : 1;                    // at least four k-tiles per workgroup
+    int splits = want < 1 ? 1 : (want > maxs ? maxs : want);
+    pl.rows = (((M + splits - 1) / splits) + 31) / 32 * 32;
+    pl.splits = (M + pl.rows - 1) / pl.rows;
+    return pl;
+}
+int g2_wgrad_splits(int M, int I, int O) { const G2WPlan pl = g2_wgrad_plan(M, I, O); return pl.ok ? pl.splits : 0; }
+
+template <int BO, int BI, int WGO, bool TWO, bool XA, int S>
+static int g2_launch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
+    constexpr size_t bytes = (size_t)S * ((TWO ? 2 : 1) * 32 * BO + 32 * BI) * 4;
+    static bool ok = g2_raise_lds((const void*)gemm2_tn_kernel<BO, BI, WGO, TWO, XA, S>);
+    if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
+    hipLaunchKernelGGL((gemm2_tn_kernel<BO, BI, WGO, TWO, XA, S>), dim3(pl.tiles, pl.splits), dim3(256), bytes, st, p);
+    return PQ_OK;
+}
+template <bool TWO, bool XA>
+static int g2_dispatch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
+    if (pl.bo == 128 && pl.bi == 128) return g2_launch_tn<128, 128, 2, TWO, XA, 3>(p, pl, st);
+    if (pl.bo == 128 && pl.bi == 96) return g2_launch_tn<128, 96, 4, TWO, XA, 3>(p, pl, st);
+    if (pl.bo == 128 && pl.bi == 64) return g2_launch_tn<128, 64, 2, TWO, XA, 3>(p, pl, st);
+    if (pl.bo == 64 && pl.bi == 128) return g2_launch_tn<64, 128, 2, TWO, XA, 3>(p, pl, st);
+    return g2_launch_tn<64, 64, 2, TWO, XA, 3>(p, pl, st);
+}
+
+// the GEMM half of pq_conv1x1_wgrad (the caller runs the slab reduction); 1 = taken, 0 = not eligible
+int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* stride_out, hipStream_t st) {
+    if (a->sub > 1 || a->dbias || a->in.qstate) return 0;
+    const G2WPlan pl = g2_wgrad_plan(a->M, a->I, a->O);
+    if (!pl.ok) return 0;
+    if ((a->dy.ldg & 3) || (a->in.ld & 3) || (a->dy.y && (a->dy.ldy & 3))) return 0;
+    if ((((uintptr_t)a->dy.g) & 15) || (a->dy.y && (((uintptr_t)a->dy.y) & 15)) || (((uintptr_t)a->in.x) & 15)) return 0;
+    G2TP p{};
+    if (!act_clamp(a->in.act, p.lo, p.hi)) return 0;
+    const bool xa = a->in.scale != nullptr || a->in.act != PQ_ACT_LINEAR;
+    p.g = a->dy.g; p.y = a->dy.y; p.p = a->dy.p; p.q = a->dy.q; p.mu = a->dy.mu; p.r = a->dy.r; p.ldg = a->dy.ldg; p.ldy = a->dy.ldy;
+    p.x = a->in.x; p.scale = a->in.scale; p.shift = a->in.shift; p.ldx = a->in.ld;
+    p.slab = a->scratch; p.slab_stride = (size_t)a->O * a->I + a->O;
+    p.M = a->M; p.O = a->O; p.I = a->I; p.rows_per_split = pl.rows;
+    int rc;
+    if (a->dy.y) rc = xa ? g2_dispatch_tn<true, true>(p, pl, st) : g2_dispatch_tn<true, false>(p, pl, st);
+    else rc = xa ? g2_dispatch_tn<false, true>(p, pl, st) : g2_dispatch_tn<false, false>(p, pl, st);
+    if (rc != PQ_OK) return rc;
+    *splits_out = pl.splits;
+    *stride_out = p.slab_stride;
+    return 1;
+}

@@ -366,7 +366,7 @@ class Plan:
                 else:
                     src = T[resolve(i - 1, i)]
                     if k == 1 and groups == 1:
-                        nblk = l.pq_conv1x1_blocks(rows, Cout)
+                        nblk = l.pq_conv1x1_blocks_k(rows, Cout, Cin, 0)
                         self._deferred.append(('c1_fwd', i, out, nblk, src, s))
                     elif k == 3 and groups == Cin == Cout and conv.padding[0] == 1:
                         nblk = l.pq_dw3x3_fwd_blocks(B, OH, OW, Cout, s)
@@ -734,7 +734,7 @@ class Plan:
                             idx = self._op(self.bwd, abi.OP_CONV1X1_WGRAD, a)
                             wg_ops.append((idx, 'c1w', need))
                             if src.needs_grad and s == 1:
-                                d = abi.Conv1x1Dgrad(dy, wsrc, self._sink(src, l.pq_conv1x1_blocks(src.rows, src.C)), out.rows,
+                                d = abi.Conv1x1Dgrad(dy, wsrc, self._sink(src, l.pq_conv1x1_blocks_k(src.rows, src.C, out.C, 1)), out.rows,
                                                      src.C, out.C, 1, 0, 0, 0, 0, transposed(conv, wsrc))
                                 self._op(self.bwd, abi.OP_CONV1X1_DGRAD, d)
                             elif src.needs_grad:

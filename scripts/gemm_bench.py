@@ -45,7 +45,7 @@ for (M, I, O) in SHAPES:
     flops = 2.0 * M * I * O; byts = 4.0 * (M * I + M * O + I * O)
     line = 'M=%8d I=%4d O=%4d ' % (M, I, O)
     if 'fwd' in which:
-        nb = l.pq_conv1x1_blocks(M, O); ldp = (O + 15) // 16 * 16
+        nb = l.pq_conv1x1_blocks_k(M, O, I, 0); ldp = (O + 15) // 16 * 16
         part = torch.empty(nb * 2 * ldp, device=dev)
         a = abi.Conv1x1Fwd(abi.Src(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), I, 2), w.data_ptr(), None, y.data_ptr(), part.data_ptr(),
                            M, I, O, ldo, ldp, 1, 0, 0, 0, 0)
@@ -58,7 +58,7 @@ for (M, I, O) in SHAPES:
         tot['fwd'] = tot.get('fwd', 0) + ms
         line += '| fwd %.3f ms %5.1f TF %6.0f GB/s ' % (ms, flops / ms / 1e9, byts / ms / 1e6)
     if 'dgrad' in which:
-        nb = l.pq_conv1x1_blocks(M, I); ldp = (I + 15) // 16 * 16
+        nb = l.pq_conv1x1_blocks_k(M, I, O, 1); ldp = (I + 15) // 16 * 16
         part = torch.empty(nb * 2 * ldp, device=dev)
         two = os.environ.get('DG_ONE') is None
         fin = 0 if os.environ.get('DG_NOFIN') else 1

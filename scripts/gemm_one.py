@@ -10,7 +10,7 @@ for k in range(0, len(args), 3):
     M, I, O = args[k:k + 3]
     x = torch.randn(M, I, device='cuda'); w = torch.randn(O, I, device='cuda') / math.sqrt(I)
     y = torch.empty(M, O, device='cuda'); sc = torch.rand(I + 32, device='cuda') + .5; sh = torch.rand(I + 32, device='cuda')
-    nb = l.pq_conv1x1_blocks(M, O); ldp = (O + 15) // 16 * 16
+    nb = l.pq_conv1x1_blocks_k(M, O, I, 0); ldp = (O + 15) // 16 * 16
     part = torch.empty(nb * 2 * ldp, device='cuda')
     a = abi.Conv1x1Fwd(abi.Src(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), I, 2), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), M, I, O, O, ldp, 1, 0, 0, 0, 0)
     for _ in range(5):

@@ -68,3 +68,21 @@ if os.environ.get('PER_OP'):
     for key, e in sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2]))[:40]:
         print('%-14s M=%-8d I=%-5d O=%-5d x%d  %.3f ms  bound %.3f  excess %.3f' % (key + (e[0], e[1], e[2], e[1] - e[2])))
     print('total %.3f ms, bound %.3f ms' % (sum(e[1] for e in agg.values()), sum(e[2] for e in agg.values())))
+
+# every op alone (hot caches), biggest first: name, shape hint, us, algorithmic GB/s
+if os.environ.get('PER_OP_ALL'):
+    rows = []
+    for arr, n, tag in ((plan.fwd_arr, nf, 'fwd'), (plan.bwd_arr, nb, 'bwd')):
+        for k in range(n):
+            code = arr[k].code
+            a = getattr(arr[k].u, abi.OP_FIELD[code])
+            sub = (abi.Op * 1)(arr[k])
+            ms = wall(lambda: abi.check(l.pq_run_ops(sub, 1, st)))
+            fl, by = bench.op_work(arr[k])
+            hint = ' '.join('%s=%s' % (f, getattr(a, f)) for f in ('M', 'I', 'O', 'B', 'IH', 'IW', 'OH', 'OW', 'H', 'W', 'C', 'stride', 'part', 'up')
+                            if hasattr(a, f))
+            rows.append((ms, tag, k, bench.KERNEL_CLASS.get(code, ('other',))[0][:28], hint, by, fl))
+    print('--- every op alone, >= 15 us')
+    for ms, tag, k, name, hint, by, fl in sorted(rows, key=lambda r: -r[0]):
+        if ms * 1e3 < 15: break
+        print('%s#%-3d %-28s %-70s %7.1f us %6.0f GB/s %5.1f TF' % (tag, k, name, hint, ms * 1e3, by / ms / 1e6, fl / ms / 1e9))

@@ -89,7 +89,7 @@ def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
     want = xin @ w.t() + (b if bias else 0)
     ldo = (O + 3) // 4 * 4 + 4
     out = torch.full((M, ldo), float('nan'), device=DEV)
-    nblk = abi.lib().pq_conv1x1_blocks(M, O)
+    nblk = abi.lib().pq_conv1x1_blocks_k(M, O, I, 0)
     ldp = (O + 15) // 16 * 16
     partial = torch.zeros(nblk * 2 * ldp, device=DEV) if stats else None
     xd, wd = x.to(DEV), w.to(DEV)
@@ -198,7 +198,7 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
     youtd[:, :O] = yout.to(DEV)
     wd, yind = w.to(DEV), yin.to(DEV)
     gdst = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
-    nblk = abi.lib().pq_conv1x1_blocks(M, I)
+    nblk = abi.lib().pq_conv1x1_blocks_k(M, I, O, 1)
     ldp = (I + 15) // 16 * 16
     partial = torch.zeros(nblk * 2 * ldp, device=DEV)
     vecs = [chan_vec(v) for v in ((p, q, mu, r) if two else ())]
@@ -361,7 +361,7 @@ def test_conv1x1_bwd_fused_matches_the_two_kernel_backward(M, I, O, two, act, ac
         close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=3e-2, what='sum g*xhat')
     # the two-kernel path on the same operands: same arithmetic up to summation order
     g2 = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
-    nb2 = l.pq_conv1x1_blocks(M, I)
+    nb2 = l.pq_conv1x1_blocks_k(M, I, O, 1)
     part2 = torch.zeros(nb2 * 2 * ldp, device=DEV)
     d = abi.Conv1x1Dgrad()
     d.dy, d.w, d.dx, d.M, d.I, d.O = dyarg, wd.data_ptr(), sink(g2, part2), M, I, O
@@ -411,7 +411,7 @@ def test_conv1x1_bwd_fused_with_qat_observers_matches_the_two_kernel_backward():
     a = abi.Conv1x1Bwd(dyarg, wd.data_ptr(), inarg, sink(g1, part1), dw1.data_ptr(), scratch.data_ptr(), M, I, O)
     abi.check(l.pq_conv1x1_bwd(C.byref(a), stream()))
     g2 = torch.full((M, I), float('nan'), device=DEV)
-    nb2 = l.pq_conv1x1_blocks(M, I)
+    nb2 = l.pq_conv1x1_blocks_k(M, I, O, 1)
     part2 = torch.zeros(nb2 * 2 * ldp, device=DEV)
     d = abi.Conv1x1Dgrad()
     d.dy, d.w, d.dx, d.M, d.I, d.O = dyarg, wd.data_ptr(), sink(g2, part2), M, I, O
