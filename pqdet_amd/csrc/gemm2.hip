@@ -336,6 +336,14 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad (TN)
+// C[o][i] = sum_m dY'[m][o] * X'[m][i] on a 128 x 128 output tile, 8 waves.  Both operands are row-major [m][channels], i.e.
+// the contraction index is the SLOW one: an MFMA operand register wants 32 consecutive channels of one row.  Read like that
+// (ds_read_b32) every MFMA needs two fresh LDS instructions and the LDS issue port, not the matrix pipe, sets the pace (78 TF
+// asymptote measured on gemm_tn and on a b32 ring kernel alike).  Here a lane OWNS adjacent channels instead -- 2 of dY'
+// (one ds_read_b64) and 4 of X' (one ds_read_b128) -- so one row pair feeds 2 x 4 = 8 MFMAs from three LDS reads; the MFMA
+// "row" index is just a label, so the C fragment of MFMA (a, b) holds o = 2*row + a, i = 4*col + b.  The 8 waves split the tile
+// as 2 halves of o x 4 row groups of the 32-row k-tile (each element of a staged tile is read from LDS by exactly one
+// wave); the four row groups add their 64 x 128 accumulators through LDS in fixed order at the end (deterministic).
 struct G2TP {
     const float* g; const float* y; const float* p; const float* q; const float* mu; const float* r; int ldg, ldy;
     const float* x; const float* scale; const float* shift; int ldx; float lo, hi;
@@ -344,23 +352,19 @@ struct G2TP {
 };
 
 // TWO: dy' = p*g + q*(y-mu) + r (else dy' = g).  XA: x' = clamp(scale*x + shift, lo, hi) (else x' = x).
-// 4 waves as WGO x (4 / WGO) over (O, I).  rows_per_split % 32 == 0 and M % 32 == 0.
-template <int BO, int BI, int WGO, bool TWO, bool XA, int S>
-__global__ __launch_bounds__(256) void gemm2_tn_kernel(G2TP p) {
-    constexpr int WGI = 4 / WGO;
-    constexpr int WO = BO / WGO, WI = BI / WGI, TO = WO / 32, TI = WI / 32;
+// rows_per_split % 32 == 0 and M % 32 == 0.
+template <bool TWO, bool XA, int S>
+__global__ __launch_bounds__(512) void gemm2_tn_kernel(G2TP p) {
+    constexpr int BO = 128, BI = 128;
     constexpr int NY = TWO ? 2 : 1;
     constexpr int Y_FL = 32 * BO, X_FL = 32 * BI;
     constexpr int STAGE = NY * Y_FL + X_FL;
-    constexpr int PY = BO / 32, PX = BI / 32;             // 1 KiB pieces per wave per k-tile (256 floats each)
-    constexpr int NL = NY * PY + PX;
+    constexpr int NL = 2 * NY + 2;                        // 1 KiB pieces per wave per k-tile: 16 per tensor over 8 waves
     constexpr int D = S - 1;
-    static_assert(WO % 32 == 0 && WI % 32 == 0, "wave tile");
-    static_assert(BO % 32 == 0 && BI % 32 == 0, "pieces per wave");
     static_assert(2 * NL <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wo = w / WGI, wi = w % WGI;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, og = w & 1, rg = w >> 1;
     const int lrow = lane & 31, lh = lane >> 5;
     const int tiles_i = (p.I + BI - 1) / BI;
     int btile, split;
@@ -372,38 +376,30 @@ __global__ __launch_bounds__(256) void gemm2_tn_kernel(G2TP p) {
     const int nk = (mend - mbeg) / 32;
     const int Opad = (p.O + 3) & ~3, Ipad = (p.I + 3) & ~3;
 
-    // ---- source pointers: piece q of a [32][BW] tile covers floats [256*q', 256*q'+256) of the row-major tile image
-    const float* py[NY][PY];
-    const float* px[PX];
+    // ---- source pointers: piece q of a [32][128] tile image covers two rows (256 floats)
+    const float* py[NY][2];
+    const float* px[2];
 #pragma unroll
-    for (int q = 0; q < PY; ++q) {
-        const int f = (w * PY + q) * 256 + lane * 4;
-        const int r = f / BO, c = min(o0 + f % BO, Opad - 4);
-        py[0][q] = p.g + (size_t)(mbeg + r) * (size_t)p.ldg + c;
-        if (TWO) py[NY - 1][q] = p.y + (size_t)(mbeg + r) * (size_t)p.ldy + c;
-    }
-#pragma unroll
-    for (int q = 0; q < PX; ++q) {
-        const int f = (w * PX + q) * 256 + lane * 4;
-        const int r = f / BI, c = min(i0 + f % BI, Ipad - 4);
-        px[q] = p.x + (size_t)(mbeg + r) * (size_t)p.ldx + c;
+    for (int q = 0; q < 2; ++q) {
+        const int f = (w * 2 + q) * 256 + lane * 4;
+        const int r = f / BO, co = min(o0 + f % BO, Opad - 4), ci = min(i0 + f % BI, Ipad - 4);
+        py[0][q] = p.g + (size_t)(mbeg + r) * (size_t)p.ldg + co;
+        if (TWO) py[NY - 1][q] = p.y + (size_t)(mbeg + r) * (size_t)p.ldy + co;
+        px[q] = p.x + (size_t)(mbeg + r) * (size_t)p.ldx + ci;
     }
     const size_t sg = (size_t)32 * p.ldg, sy = (size_t)32 * p.ldy, sx = (size_t)32 * p.ldx;
     const unsigned lbase = lds_addr(lds);
     auto issue = [&](int s) {
         const unsigned sb = lbase + (unsigned)(s * STAGE) * 4u;
 #pragma unroll
-        for (int q = 0; q < PY; ++q) {
-            glds16(py[0][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)((w * PY + q) * 256) * 4u));
+        for (int q = 0; q < 2; ++q) {
+            glds16(py[0][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)((w * 2 + q) * 256) * 4u));
             py[0][q] += sg;
             if (TWO) {
-                glds16(py[NY - 1][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(Y_FL + (w * PY + q) * 256) * 4u));
+                glds16(py[NY - 1][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(Y_FL + (w * 2 + q) * 256) * 4u));
                 py[NY - 1][q] += sy;
             }
-        }
-#pragma unroll
-        for (int q = 0; q < PX; ++q) {
-            glds16(px[q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NY * Y_FL + (w * PX + q) * 256) * 4u));
+            glds16(px[q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NY * Y_FL + (w * 2 + q) * 256) * 4u));
             px[q] += sx;
         }
     };
@@ -415,53 +411,53 @@ __global__ __launch_bounds__(256) void gemm2_tn_kernel(G2TP p) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < nk) issue(d);
-    float cp[TO], cq[TO], cm[TO], cr[TO], xs[TI], xh[TI];
+    float cp[2], cq[2], cm[2], cr[2], xs[4], xh[4];
 #pragma unroll
-    for (int a = 0; a < TO; ++a) {
-        const int o = min(o0 + wo * WO + 32 * a + lrow, p.O - 1);
+    for (int a = 0; a < 2; ++a) {
+        const int o = min(o0 + og * 64 + 2 * lrow + a, p.O - 1);
         cp[a] = TWO ? p.p[o] : 1.f; cq[a] = TWO ? p.q[o] : 0.f; cm[a] = TWO ? p.mu[o] : 0.f; cr[a] = TWO ? p.r[o] : 0.f;
     }
 #pragma unroll
-    for (int b = 0; b < TI; ++b) {
-        const int i = min(i0 + wi * WI + 32 * b + lrow, p.I - 1);
+    for (int b = 0; b < 4; ++b) {
+        const int i = min(i0 + 4 * lrow + b, p.I - 1);
         xs[b] = (XA && p.scale) ? p.scale[i] : 1.f; xh[b] = (XA && p.scale) ? p.shift[i] : 0.f;
     }
 #pragma unroll
-    for (int a = 0; a < TO; ++a) asm volatile("" : "+v"(cp[a]), "+v"(cq[a]), "+v"(cm[a]), "+v"(cr[a]));
+    for (int a = 0; a < 2; ++a) asm volatile("" : "+v"(cp[a]), "+v"(cq[a]), "+v"(cm[a]), "+v"(cr[a]));
 #pragma unroll
-    for (int b = 0; b < TI; ++b) asm volatile("" : "+v"(xs[b]), "+v"(xh[b]));
+    for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(xs[b]), "+v"(xh[b]));
     const float lo = p.lo, hi = p.hi;
 
-    f32x16 acc[TO][TI];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int a = 0; a < TO; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < TI; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     auto compute = [&](int s) {
-        const float* Gs = lds + s * STAGE + wo * WO + lrow;
-        const float* Xs = lds + s * STAGE + NY * Y_FL + wi * WI + lrow;
+        const float* Gs = lds + s * STAGE + (8 * rg + lh) * BO + og * 64 + 2 * lrow;
+        const float* Xs = lds + s * STAGE + NY * Y_FL + (8 * rg + lh) * BI + 4 * lrow;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const int row = 2 * kk + lh;
-            float av[TO], bv[TI];
+        for (int kk = 0; kk < 4; ++kk) {
+            const float2 g2 = *reinterpret_cast<const float2*>(&Gs[2 * kk * BO]);
+            float av[2] = {g2.x, g2.y};
+            if (TWO) {
+                const float2 y2 = *reinterpret_cast<const float2*>(&Gs[Y_FL + 2 * kk * BO]);
+                av[0] = fmaf(cp[0], av[0], fmaf(cq[0], y2.x - cm[0], cr[0]));
+                av[1] = fmaf(cp[1], av[1], fmaf(cq[1], y2.y - cm[1], cr[1]));
+            }
+            const float4 x4 = *reinterpret_cast<const float4*>(&Xs[2 * kk * BI]);
+            float bv[4] = {x4.x, x4.y, x4.z, x4.w};
+            if (XA) {
 #pragma unroll
-            for (int a = 0; a < TO; ++a) {
-                const float g = Gs[row * BO + 32 * a];
-                if (TWO) { const float y = Gs[Y_FL + row * BO + 32 * a]; av[a] = fmaf(cp[a], g, fmaf(cq[a], y - cm[a], cr[a])); }
-                else av[a] = g;
+                for (int b = 0; b < 4; ++b) bv[b] = __builtin_amdgcn_fmed3f(fmaf(xs[b], bv[b], xh[b]), lo, hi);
             }
 #pragma unroll
-            for (int b = 0; b < TI; ++b) {
-                const float x = Xs[row * BI + 32 * b];
-                bv[b] = XA ? __builtin_amdgcn_fmed3f(fmaf(xs[b], x, xh[b]), lo, hi) : x;
-            }
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int a = 0; a < TO; ++a)
-#pragma unroll
-                for (int b = 0; b < TI; ++b) acc[a][b] = mfma32x2(av[a], bv[b], acc[a][b]);
+                for (int b = 0; b < 4; ++b) acc[a][b] = mfma32x2(av[a], bv[b], acc[a][b]);
         }
     };
 
@@ -473,18 +469,39 @@ __global__ __launch_bounds__(256) void gemm2_tn_kernel(G2TP p) {
         compute(kt % S);
     }
 
-    float* dst = p.slab + (size_t)split * p.slab_stride;
+    // ---- the four row groups add up through one 128 x 128 LDS tile, in fixed order
+    float* T = lds;                                        // 64 KiB of the ring
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+        __syncthreads();                                   // round 0: every wave is done reading the ring
+        if (rg == round) {
 #pragma unroll
-    for (int a = 0; a < TO; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < TI; ++b) {
-            const int i = i0 + wi * WI + 32 * b + lrow;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + wo * WO + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (o < p.O && i < p.I) dst[(size_t)o * p.I + i] = acc[a][b][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int o = og * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;
+                    float4* dst = reinterpret_cast<float4*>(&T[o * BI + 4 * lrow]);
+                    float4 v = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+                    if (round > 0) v = f4add(v, *dst);
+                    *dst = v;
+                }
         }
+    }
+    __syncthreads();
+    float* dst = p.slab + (size_t)split * p.slab_stride;
+    const bool vec = (p.I & 3) == 0 && (((uintptr_t)dst) & 15) == 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx = t + 512 * u;
+        const int ro = idx >> 5, c4 = (idx & 31) * 4;
+        const int o = o0 + ro, i = i0 + c4;
+        if (o < p.O && i < p.I) {
+            const float4 v = *reinterpret_cast<const float4*>(&T[ro * BI + c4]);
+            float* d = dst + (size_t)o * p.I + i;
+            if (vec && i + 3 < p.I) stg4(d, v);
+            else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int b = 0; b < 4 && i + b < p.I; ++b) d[b] = e[b]; }
+        }
+    }
 }
 
 }  // namespace pq
@@ -496,8 +513,8 @@ static bool g2_enabled() {
     static const char* e = getenv("PQ_G2");
     return !(e && e[0] == '0');
 }
-static bool g2_raise_lds(const void* fn) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+static bool g2_raise_lds(const void* fn, size_t bytes) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
 template <int BM, int BN, int AMODE, int EMODE, int S>
@@ -507,7 +524,7 @@ static int g2_launch_nt(const G2P& p, hipStream_t st) {
     constexpr int STAGE = NA * BM * 32 + BN * 32 + 4 * CW;
     constexpr size_t ring = (size_t)S * STAGE * 4, epi = (size_t)(4 * 32 * 36 + 4 * BN) * 4;
     constexpr size_t bytes = ring > epi ? ring : epi;
-    static bool ok = g2_raise_lds((const void*)gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>);
+    static bool ok = g2_raise_lds((const void*)gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>, bytes);
     if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
     hipLaunchKernelGGL((gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>), grid, dim3(256), bytes, st, p);
@@ -579,47 +596,38 @@ int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st) {
 }
 
 // ---- wgrad
-struct G2WPlan { bool ok; int bo, bi, wgo, tiles, splits, rows; };
+struct G2WPlan { bool ok; int tiles, splits, rows; };
 static G2WPlan g2_wgrad_plan(int M, int I, int O) {
     G2WPlan pl{};
-    // measured (scripts/gemm_bench.py wgrad): the ring kernel ties the register-staged gemm_tn on the neck shapes (70 TF) and
-    // loses on the short-contraction mid layers, so it is opt-in (PQ_G2_TN=1) until its slab epilogue is reworked
     static const char* tn_env = getenv("PQ_G2_TN");
-    pl.ok = g2_enabled() && tn_env && tn_env[0] == '1' && (M % 32) == 0 && I >= 32 && O >= 32 && (I & 3) == 0 && (O & 3) == 0;
+    // 128 x 128 tiles: shapes that would leave more than a third of a tile empty stay on the 64 x 64 gemm_tn kernel
+    pl.ok = g2_enabled() && !(tn_env && tn_env[0] == '0') && (M % 32) == 0 && (I & 3) == 0 && (O & 3) == 0 &&
+            ((O - 1) % 128) >= 80 && ((I - 1) % 128) >= 80;
     if (!pl.ok) return pl;
-    pl.bo = O >= 96 ? 128 : 64;
-    pl.bi = I >= 112 ? 128 : (I > 64 ? 96 : 64);
-    if (pl.bo == 64 && pl.bi == 96) pl.bi = 128;
-    static const char* tile_env = getenv("PQ_G2_WG_TILE");          // "BOxBI" (A/B timing)
-    if (tile_env) { int a = 0, b = 0; if (sscanf(tile_env, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || b == 128)) { pl.bo = a; pl.bi = b; } }
-    pl.wgo = (pl.bi == 96) ? 4 : 2;
-    pl.tiles = ((O + pl.bo - 1) / pl.bo) * ((I + pl.bi - 1) / pl.bi);
+    pl.tiles = ((O + 127) / 128) * ((I + 127) / 128);
+    // one workgroup per CU (144 KiB of LDS): tiles x splits <= 256 in ONE round, and every workgroup must get a contraction
+    // of at least 256 rows (8 k-tiles) or the fixed costs (ring fill, row-group reduction, slab) dominate: shorter ones stay
+    // on gemm_tn
     static const char* tgt_env = getenv("PQ_G2_WG_TARGET");
     const int target = tgt_env ? atoi(tgt_env) : 256;
-    int want = (target + pl.tiles - 1) / pl.tiles;
-    const int maxs = M / 128 > 0 ? M / 128 : 1;                    // at least four k-tiles per workgroup
-    int splits = want < 1 ? 1 : (want > maxs ? maxs : want);
+    int splits = target / pl.tiles;
+    const int maxs = M / 256;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1 || (long)pl.tiles * splits < 200) { pl.ok = false; return pl; }
     pl.rows = (((M + splits - 1) / splits) + 31) / 32 * 32;
     pl.splits = (M + pl.rows - 1) / pl.rows;
     return pl;
 }
 int g2_wgrad_splits(int M, int I, int O) { const G2WPlan pl = g2_wgrad_plan(M, I, O); return pl.ok ? pl.splits : 0; }
 
-template <int BO, int BI, int WGO, bool TWO, bool XA, int S>
-static int g2_launch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
-    constexpr size_t bytes = (size_t)S * ((TWO ? 2 : 1) * 32 * BO + 32 * BI) * 4;
-    static bool ok = g2_raise_lds((const void*)gemm2_tn_kernel<BO, BI, WGO, TWO, XA, S>);
-    if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
-    hipLaunchKernelGGL((gemm2_tn_kernel<BO, BI, WGO, TWO, XA, S>), dim3(pl.tiles, pl.splits), dim3(256), bytes, st, p);
-    return PQ_OK;
-}
 template <bool TWO, bool XA>
-static int g2_dispatch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
-    if (pl.bo == 128 && pl.bi == 128) return g2_launch_tn<128, 128, 2, TWO, XA, 3>(p, pl, st);
-    if (pl.bo == 128 && pl.bi == 96) return g2_launch_tn<128, 96, 4, TWO, XA, 3>(p, pl, st);
-    if (pl.bo == 128 && pl.bi == 64) return g2_launch_tn<128, 64, 2, TWO, XA, 3>(p, pl, st);
-    if (pl.bo == 64 && pl.bi == 128) return g2_launch_tn<64, 128, 2, TWO, XA, 3>(p, pl, st);
-    return g2_launch_tn<64, 64, 2, TWO, XA, 3>(p, pl, st);
+static int g2_launch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
+    constexpr int S = 3;
+    constexpr size_t bytes = (size_t)S * ((TWO ? 2 : 1) * 32 * 128 + 32 * 128) * 4;        // 144 / 96 KiB (>= the 64 KiB epilogue tile)
+    static bool ok = g2_raise_lds((const void*)gemm2_tn_kernel<TWO, XA, S>, bytes);
+    if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
+    hipLaunchKernelGGL((gemm2_tn_kernel<TWO, XA, S>), dim3(pl.tiles, pl.splits), dim3(512), bytes, st, p);
+    return PQ_OK;
 }
 
 // the GEMM half of pq_conv1x1_wgrad (the caller runs the slab reduction); 1 = taken, 0 = not eligible
@@ -637,8 +645,8 @@ int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* st
     p.slab = a->scratch; p.slab_stride = (size_t)a->O * a->I + a->O;
     p.M = a->M; p.O = a->O; p.I = a->I; p.rows_per_split = pl.rows;
     int rc;
-    if (a->dy.y) rc = xa ? g2_dispatch_tn<true, true>(p, pl, st) : g2_dispatch_tn<true, false>(p, pl, st);
-    else rc = xa ? g2_dispatch_tn<false, true>(p, pl, st) : g2_dispatch_tn<false, false>(p, pl, st);
+    if (a->dy.y) rc = xa ? g2_launch_tn<true, true>(p, pl, st) : g2_launch_tn<true, false>(p, pl, st);
+    else rc = xa ? g2_launch_tn<false, true>(p, pl, st) : g2_launch_tn<false, false>(p, pl, st);
     if (rc != PQ_OK) return rc;
     *splits_out = pl.splits;
     *stride_out = p.slab_stride;

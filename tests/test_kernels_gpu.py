@@ -261,7 +261,12 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
 
 @pytest.mark.parametrize('M,I,O,two,bias', [(3000, 32, 16, True, False), (1000, 24, 144, True, False),
                                             (4096, 160, 960, True, False), (700, 1024, 75, False, True),
-                                            (5000, 96, 24, True, False)])
+                                            (5000, 96, 24, True, False),
+                                            # 128 x 128-tile LDS-DMA kernel (gemm2.hip): full tiles, ragged tiles in both
+                                            # directions, a single row split, the one-tensor gradient operand
+                                            (4096, 256, 512, True, False), (1024, 224, 120, True, False),
+                                            (2048, 128, 96, False, False), (160, 96, 576, True, False),
+                                            (16384, 352, 256, True, False)])
 def test_conv1x1_wgrad(M, I, O, two, bias):
     g = torch.Generator().manual_seed(M + I + O + 2)
     gy = rnd(M, O, g=g)
@@ -1139,3 +1144,4 @@ def test_create_label_matches_host_assignment_bit_exactly(B, S, ncls, seed):
     for s in range(3):
         m = got[3 + s].shape[1]
         assert torch.equal(full[3 + s][:, :m], got[3 + s]) and float(full[3 + s][:, m:].abs().sum()) == 0.0
+
