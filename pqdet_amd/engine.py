@@ -489,8 +489,12 @@ class Plan:
         # BatchNorms come from the running statistics in ONE launch at the start (slot filled in after the loop)
         bne_idx = self._op(self.fwd, abi.OP_BN_EVAL, abi.BnEval(None, 0)) if not self.bn_train else None
         bne_items = []
+        self.fwd_layer = [-1] * len(self.fwd)      # layer index of every forward op (-1: whole-net ops); tests replay single layers
+        cur_layer = -1
         for item in self._deferred:
             kind = item[0]
+            self.fwd_layer += [cur_layer] * (len(self.fwd) - len(self.fwd_layer))       # ops of the previous item
+            cur_layer = item[1] if len(item) > 1 and isinstance(item[1], int) else -1
             if kind == 'qimg':                                 # QuantStub: observe + fake-quantise the input batch
                 idx = self._qact_fwd(abi.Src(None, None, None, 0, 0), self.qimg, B * 3 * self.IH * self.IW, 1, 1, ('in',), flat=1)
                 self.patch_x.append(('fwd', idx, 'qa'))
@@ -564,6 +568,7 @@ class Plan:
                 a = abi.Copy(a_.src(), b_.src() if b_ is not None else none, ptr(out.raw), out.B, out.H, out.W, a_.C,
                              out.ld, coff, up)
                 self._op(self.fwd, abi.OP_COPY_FWD, a)
+        self.fwd_layer += [cur_layer] * (len(self.fwd) - len(self.fwd_layer))
         if bne_idx is not None:
             if bne_items:
                 table = (abi.BnEvalItem * len(bne_items))(*bne_items)

@@ -139,6 +139,34 @@ class AnyModel(nn.Module):
         self._plans.clear()
         return self
 
+    # A prepared QAT model presents its state under the REFERENCE's key layout (fused ``conv.bn.*`` + the observers'
+    # buffers), because that is what ``trainer.py:194-201`` stores with ``'type': 'qat'`` and what ``tools.build_model``
+    # (reference :236-238) loads back: checkpoints written by an unmodified trainer around this model resume, and they are
+    # interchangeable with checkpoints written by the reference itself.
+    def plain_state_dict(self):
+        """Parameters / buffers under this module's own names (``bn.*`` + ``_qat_state``)."""
+        return nn.Module.state_dict(self)
+
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        if not self._qat:
+            return nn.Module.state_dict(self, *args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        from .. import tools
+        if destination is None:
+            from collections import OrderedDict
+            destination = OrderedDict()
+        for k, v in tools.qat_state_dict(self).items():
+            destination[prefix + k] = v
+        return destination
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        if self._qat and '_qat_state' not in state_dict:
+            from .. import tools
+            tools.load_qat_state_dict(self, state_dict)
+            return torch.nn.modules.module._IncompatibleKeys([], [])
+        out = nn.Module.load_state_dict(self, state_dict, strict=strict, **kw)
+        self._plans.clear()
+        return out
+
     def qat_observers(self):
         """{reference-style module name: (min, max, scale, zero_point)} for checkpoints / inspection."""
         st = self._qat_state.detach().cpu()

@@ -155,7 +155,7 @@ def build_model(cfg_path: Optional[str], weight_path: Optional[str] = None, back
     model_info = {}
     state_dict_type = None
     if weight_path:
-        ckpt = torch.load(weight_path, map_location='cpu')
+        ckpt = torch.load(weight_path, map_location='cpu', weights_only=False)      # the file holds the trainer's AP record too
         state_dict_type = ckpt.get('type', 'normal')
         weight = ckpt['model']
         model_info = {k: v for k, v in ckpt.items() if k != 'model'}
@@ -165,10 +165,16 @@ def build_model(cfg_path: Optional[str], weight_path: Optional[str] = None, back
     if state_dict_type == 'quant' or quantized:
         raise NotImplementedError('converted int8 models (torch.quantization.convert, CPU-only in the reference) are not built')
     qat = qat or state_dict_type == 'qat'
+    if qat:                                   # reference :229-232: the recipe comes from the caller, else from the checkpoint
+        backend = backend or model_info.get('backend')
+        if backend in (None, 'none'):
+            backend = 'qnnpack'
+        if backend != 'qnnpack':
+            raise NotImplementedError("QAT backend %r: only the 'qnnpack' recipe (yamls/quant.yaml) is implemented" % (backend,))
     model = DetectionModel(cfg, qat, onnx)
     if backbone_path:
         print('loading backbone weights from {}'.format(backbone_path))
-        load_backbone(model, torch.load(backbone_path, map_location='cpu'))
+        load_backbone(model, torch.load(backbone_path, map_location='cpu', weights_only=False))
     if state_dict_type == 'normal':
         load_weight(model, weight)
         print('resumed at %d steps from %s' % (model_info['step'], weight_path))
@@ -176,7 +182,7 @@ def build_model(cfg_path: Optional[str], weight_path: Optional[str] = None, back
     if qat:                                   # reference :225-235: fuse conv+bn+relu, then attach observers / fake-quantisers
         model.train()
         fuse_model(model)
-        prepare_qat(model, backend or 'qnnpack')
+        prepare_qat(model, backend)
         if state_dict_type == 'qat':          # reference :236-238: a QAT checkpoint is loaded into the prepared model
             load_qat_state_dict(model, weight)
         return model, model_info              # QAT is single-GPU in the reference (trainer.py:148)
@@ -258,17 +264,21 @@ def load_qat_state_dict(model: nn.Module, state_dict: Dict[str, torch.Tensor]):
     if not getattr(m, '_qat', False):
         raise ValueError('call tools.prepare_qat(model) before loading a QAT checkpoint')
     sd = _strip(state_dict) if _state_dict_is_dp(state_dict) else state_dict
+    if '_qat_state' in sd:                    # this package's own layout (``plain_state_dict``): bn.* + the observer table
+        nn.Module.load_state_dict(m, sd)
+        m._plans.clear()
+        return
     plain = {}
     for k, v in sd.items():
         if '.conv.bn.' in k:
             plain[k.replace('.conv.bn.', '.bn.')] = v
         elif k.endswith('conv.weight') or k.endswith('conv.bias'):
             plain[k] = v
-    missing = [k for k in m.state_dict() if k != '_qat_state' and k not in plain]
+    missing = [k for k in m.plain_state_dict() if k != '_qat_state' and k not in plain]
     if missing:
         raise KeyError('QAT checkpoint lacks %d tensors, e.g. %s' % (len(missing), missing[:3]))
     with torch.no_grad():
-        own = m.state_dict()
+        own = m.plain_state_dict()
         for k, v in plain.items():
             own[k].copy_(v)
         st = m._qat_state

@@ -36,3 +36,20 @@ def g5_names():
 @pytest.fixture(scope='session')
 def golden_extra():
     return np.load(os.path.join(GOLDEN_DIR, 'golden_extra.npz'))
+
+
+@pytest.fixture(scope='session')
+def golden_r2():
+    return np.load(os.path.join(GOLDEN_DIR, 'golden_r2.npz'))
+
+
+@pytest.fixture(scope='session')
+def r2_names():
+    with open(os.path.join(GOLDEN_DIR, 'g_r2_names.json')) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def g12():
+    with open(os.path.join(GOLDEN_DIR, 'g12_checkpoints.json')) as f:
+        return json.load(f)

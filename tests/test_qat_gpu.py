@@ -215,7 +215,7 @@ def test_qat_plumbing_with_rounding_switched_off_matches_oracle():
     want_obs = qat_observers(ref)
     got_obs = net._qat_state.cpu().numpy()
     np.testing.assert_allclose(got_obs[:, :3], want_obs[:, :3], rtol=2e-3, atol=1e-5)
-    sd, rd = net.state_dict(), ref.float_net.state_dict()
+    sd, rd = net.plain_state_dict(), ref.float_net.state_dict()
     for k in rd:
         if 'running' in k:
             np.testing.assert_allclose(sd[k].cpu().numpy(), rd[k].numpy(), rtol=2e-3, atol=1e-5, err_msg=k)
@@ -283,3 +283,138 @@ def test_qat_small_shape_first_step_reproduces_reference_and_observer_switch():
     opt = optim.Adam(net.parameters(), lr=1e-4)
     opt.step()
     assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+# ------------------------------------------------------------------------------------------------- 4. fixed qparams (G9b)
+def _load_g9b_state(net, golden_r2, r2_names):
+    """BatchNorm running statistics + every observer's qparams as recorded from the reference before the G9b pass."""
+    own = net.plain_state_dict()
+    flat = torch.from_numpy(golden_r2['g9b_bn_stats'])
+    off = 0
+    want_obs = dict(zip(r2_names['g9b_observers'], golden_r2['g9b_observers']))
+    with torch.no_grad():
+        for k in r2_names['g9b_bn_keys']:                       # 'module_list.i.conv.bn.running_*' in the reference's fused layout
+            t = own[k.replace('.conv.bn.', '.bn.')]
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        assert off == flat.numel()
+        assert set(net.qat_observers()) == set(want_obs)
+        for key, row in net._qat_index.items():
+            if key[0] == 'in':
+                name = 'qstub.activation_post_process'
+            elif key[0] == 'w':
+                name = 'module_list.%d.conv.weight_fake_quant' % key[1]
+            else:
+                kind = 'conv' if net.module_list[key[1]]._type == 'convolutional' else 'ffunc'
+                name = 'module_list.%d.%s.activation_post_process' % (key[1], kind)
+            net._qat_state[row] = torch.tensor(want_obs[name], dtype=torch.float32)
+    tools.disable_observer(net)
+    net._plans.clear()
+    return want_obs
+
+
+def _oracle_at_g9b(golden_r2, r2_names):
+    """The QAT oracle in the same state; scripts/qat_fixed_probe.py shows it reproduces the reference's recorded activations
+    and losses EXACTLY on the machine that recorded them (same PyTorch CPU kernels), so its per-layer outputs stand in for the
+    reference's at every layer, not only the five sub-sampled ones of the fixture."""
+    ref = oqat.OracleQATNet(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
+    seeded_fill(ref.float_net, 0)
+    ref.train()
+    sd = ref.float_net.state_dict()
+    flat, off = torch.from_numpy(golden_r2['g9b_bn_stats']), 0
+    obs = dict(zip(r2_names['g9b_observers'], golden_r2['g9b_observers']))
+
+    def setfq(fq, row):
+        fq.min_val.fill_(row[0]); fq.max_val.fill_(row[1]); fq.scale.fill_(row[2]); fq.zero_point.fill_(int(row[3]))
+        fq.observer_enabled = False
+    with torch.no_grad():
+        for k in r2_names['g9b_bn_keys']:
+            t = sd[k.replace('.conv.bn.', '.bn.')]
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        setfq(ref.input_fq, obs['qstub.activation_post_process'])
+        for i, m in enumerate(ref.module_list):
+            if isinstance(ref.w_fq[i], oqat.FakeQuant):
+                setfq(ref.w_fq[i], obs['module_list.%d.conv.weight_fake_quant' % i])
+            if isinstance(ref.a_fq[i], oqat.FakeQuant):
+                setfq(ref.a_fq[i], obs['module_list.%d.%s.activation_post_process' % (i, 'conv' if m.kind == 'convolutional' else 'ffunc')])
+    return ref
+
+
+def test_qat_at_fixed_qparams_against_reference_g9b(golden_r2, r2_names, monkeypatch):
+    """G9b: the reference QAT model after two passes, observers DISABLED (trainer.py:299-300), one more train-mode pass; the
+    HIP model is loaded with exactly that state (BatchNorm running statistics + every observer's qparams; weights by the
+    seeded fill).
+
+    (a) Layer by layer, teacher-forced: every HIP layer is fed the reference's quantised input (the oracle's, which equals the
+        reference's bit for bit) and must reproduce its quantised output -- identical values except where a pre-rounding value
+        sits on a rounding boundary (<= 1e-3 of the elements), and those by exactly ONE quantisation step.
+    (b) End to end the same network is a chaotic map: one flipped rounding in layer k flips ~3 in layer k+1 (measured:
+        0, 5e-5, 1.4e-4, 4e-4, 3e-3 ... of the values moved after layers 1..5, scripts/qat_fixed_hip_probe.py), and the
+        reference implementation itself does not reproduce its own loss across two CPUs to better than 3.6e-3 (the oracle on
+        the GPU box's host vs the fixture).  So end to end the assertion is: the first layers agree as in (a), and the losses
+        stay within 5x the oracle's own cross-machine deviation on this very box (never below north_star's 1e-3)."""
+    monkeypatch.setenv('PQ_QAT_FUSE', '0')             # materialise the quantised tensors so that they can be read back / fed
+    from test_golden_r2 import _targets
+    net = _product(0)
+    want_obs = _load_g9b_state(net, golden_r2, r2_names)
+    ref = _oracle_at_g9b(golden_r2, r2_names)
+    taps = {}
+    ref.input_fq.register_forward_hook(lambda mod, inp, o: taps.__setitem__(-1, o.detach()))
+    for i in range(len(ref.module_list)):
+        if isinstance(ref.a_fq[i], oqat.FakeQuant):
+            ref.a_fq[i].register_forward_hook(lambda mod, inp, o, i=i: taps.__setitem__(i, o.detach()))
+    x, tgt = seeded_images(2, 256, 256, 2), _targets(2, 256, 20, 3)
+    want = ref(x, tgt)
+    out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    torch.cuda.synchronize()
+    plan = [p for p in net._plans.values() if p.with_loss][-1]
+
+    def step_of(i):
+        kind = 'conv' if net.module_list[i]._type == 'convolutional' else 'ffunc'
+        return float(want_obs['module_list.%d.%s.activation_post_process' % (i, kind)][2])
+
+    def nhwc(t):
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+
+    def moved(i):
+        t = plan.tensors[i]
+        d = (t.raw[:, :t.C].cpu() - nhwc(taps[i])).abs() / step_of(i)
+        assert (d - d.round()).abs().max().item() < 2e-2, (i, 'off the quantisation grid')
+        return (d > 0.5).float().mean().item(), d.max().item()
+
+    # ---- (b) free-running: the first layers, then the losses
+    free = {i: moved(i) for i in (0, 1, 2)}
+    assert all(f <= 1e-3 and m <= 1.01 for f, m in free.values()), free
+    # the five layers stored in the fixture are the oracle's, bit for bit, wherever this test runs on the recording machine;
+    # elsewhere the oracle drifts like any second evaluation: compare the fixture with the oracle at layer 1 only
+    w1 = torch.from_numpy(golden_r2['g9b_act1'])
+    s1 = int(golden_r2['g9b_act1_stride'][0])
+    assert ((nhwc(taps[1]).reshape(-1)[::s1] - w1).abs() > 0.5 * step_of(1)).float().mean().item() <= 1e-3
+    ref_loss = golden_r2['g9b_loss'][0]
+    band = max(1e-3, 5.0 * abs(want['loss'].item() - ref_loss) / ref_loss)
+    assert abs(out['loss'].item() - ref_loss) / ref_loss <= band, (out['loss'].item(), want['loss'].item(), ref_loss)
+
+    # ---- (a) teacher-forced, every conv layer that reads one materialised tensor
+    l = abi.lib()
+    ops_of = {}
+    for k, li in enumerate(plan.fwd_layer):
+        ops_of.setdefault(li, []).append(k)
+    worst = {}
+    mods = net.module_list
+    for i in range(1, len(mods)):
+        if mods[i]._type != 'convolutional' or i not in taps or (i - 1) not in taps or mods[i - 1]._type == 'yolo':
+            continue
+        src = plan.tensors[i - 1]
+        if src.raw.shape[0] != taps[i - 1].shape[0] * taps[i - 1].shape[2] * taps[i - 1].shape[3]:
+            continue
+        src.raw[:, :src.C].copy_(nhwc(taps[i - 1]).to(DEV))                  # the reference's quantised input
+        idx = ops_of[i]
+        sub = (abi.Op * len(idx))(*[plan.fwd_arr[k] for k in idx])
+        abi.check(l.pq_run_ops(sub, len(idx), _stream()), 'replay of layer %d' % i)
+        torch.cuda.synchronize()
+        worst[i] = moved(i)
+    assert len(worst) >= 60, len(worst)
+    bad = {i: v for i, v in worst.items() if v[0] > 1e-3 or v[1] > 1.01}
+    assert not bad, bad
+    print('teacher-forced layers: %d, worst moved fraction %.2e' % (len(worst), max(v[0] for v in worst.values())))
