@@ -353,13 +353,16 @@ struct G2TP {
 
 // TWO: dy' = p*g + q*(y-mu) + r (else dy' = g).  XA: x' = clamp(scale*x + shift, lo, hi) (else x' = x).
 // rows_per_split % 32 == 0 and M % 32 == 0.
-template <bool TWO, bool XA, int S>
-__global__ __launch_bounds__(512) void gemm2_tn_kernel(G2TP p) {
+template <bool TWO, bool XA, int S, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm2_tn_kernel(G2TP p) {
+    constexpr int RG = NW / 2;                            // row groups of a 32-row k-tile (the other factor 2: halves of o)
+    constexpr int KK = 16 / RG;                           // row pairs per row group and k-tile
+    constexpr int PPW = 16 / NW;                          // 1 KiB pieces per tensor, wave and k-tile
     constexpr int BO = 128, BI = 128;
     constexpr int NY = TWO ? 2 : 1;
     constexpr int Y_FL = 32 * BO, X_FL = 32 * BI;
     constexpr int STAGE = NY * Y_FL + X_FL;
-    constexpr int NL = 2 * NY + 2;                        // 1 KiB pieces per wave per k-tile: 16 per tensor over 8 waves
+    constexpr int NL = PPW * (NY + 1);                    // LDS-DMA instructions per wave per k-tile
     constexpr int D = S - 1;
     static_assert(2 * NL <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -377,11 +380,11 @@ __global__ __launch_bounds__(512) void gemm2_tn_kernel(G2TP p) {
     const int Opad = (p.O + 3) & ~3, Ipad = (p.I + 3) & ~3;
 
     // ---- source pointers: piece q of a [32][128] tile image covers two rows (256 floats)
-    const float* py[NY][2];
-    const float* px[2];
+    const float* py[NY][PPW];
+    const float* px[PPW];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int f = (w * 2 + q) * 256 + lane * 4;
+    for (int q = 0; q < PPW; ++q) {
+        const int f = (w * PPW + q) * 256 + lane * 4;
         const int r = f / BO, co = min(o0 + f % BO, Opad - 4), ci = min(i0 + f % BI, Ipad - 4);
         py[0][q] = p.g + (size_t)(mbeg + r) * (size_t)p.ldg + co;
         if (TWO) py[NY - 1][q] = p.y + (size_t)(mbeg + r) * (size_t)p.ldy + co;
@@ -392,14 +395,14 @@ __global__ __launch_bounds__(512) void gemm2_tn_kernel(G2TP p) {
     auto issue = [&](int s) {
         const unsigned sb = lbase + (unsigned)(s * STAGE) * 4u;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            glds16(py[0][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)((w * 2 + q) * 256) * 4u));
+        for (int q = 0; q < PPW; ++q) {
+            glds16(py[0][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)((w * PPW + q) * 256) * 4u));
             py[0][q] += sg;
             if (TWO) {
-                glds16(py[NY - 1][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(Y_FL + (w * 2 + q) * 256) * 4u));
+                glds16(py[NY - 1][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(Y_FL + (w * PPW + q) * 256) * 4u));
                 py[NY - 1][q] += sy;
             }
-            glds16(px[q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NY * Y_FL + (w * 2 + q) * 256) * 4u));
+            glds16(px[q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NY * Y_FL + (w * PPW + q) * 256) * 4u));
             px[q] += sx;
         }
     };
@@ -437,10 +440,10 @@ __global__ __launch_bounds__(512) void gemm2_tn_kernel(G2TP p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     auto compute = [&](int s) {
-        const float* Gs = lds + s * STAGE + (8 * rg + lh) * BO + og * 64 + 2 * lrow;
-        const float* Xs = lds + s * STAGE + NY * Y_FL + (8 * rg + lh) * BI + 4 * lrow;
+        const float* Gs = lds + s * STAGE + (2 * KK * rg + lh) * BO + og * 64 + 2 * lrow;
+        const float* Xs = lds + s * STAGE + NY * Y_FL + (2 * KK * rg + lh) * BI + 4 * lrow;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KK; ++kk) {
             const float2 g2 = *reinterpret_cast<const float2*>(&Gs[2 * kk * BO]);
             float av[2] = {g2.x, g2.y};
             if (TWO) {
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(512) void gemm2_tn_kernel(G2TP p) {
     // ---- the four row groups add up through one 128 x 128 LDS tile, in fixed order
     float* T = lds;                                        // 64 KiB of the ring
 #pragma unroll 1
-    for (int round = 0; round < 4; ++round) {
+    for (int round = 0; round < RG; ++round) {
         __syncthreads();                                   // round 0: every wave is done reading the ring
         if (rg == round) {
 #pragma unroll
@@ -491,8 +494,8 @@ __global__ __launch_bounds__(512) void gemm2_tn_kernel(G2TP p) {
     float* dst = p.slab + (size_t)split * p.slab_stride;
     const bool vec = (p.I & 3) == 0 && (((uintptr_t)dst) & 15) == 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int idx = t + 512 * u;
+    for (int u = 0; u < 4096 / (NW * 64); ++u) {
+        const int idx = t + NW * 64 * u;
         const int ro = idx >> 5, c4 = (idx & 31) * 4;
         const int o = o0 + ro, i = i0 + c4;
         if (o < p.O && i < p.I) {
@@ -620,14 +623,20 @@ static G2WPlan g2_wgrad_plan(int M, int I, int O) {
 }
 int g2_wgrad_splits(int M, int I, int O) { const G2WPlan pl = g2_wgrad_plan(M, I, O); return pl.ok ? pl.splits : 0; }
 
-template <bool TWO, bool XA>
-static int g2_launch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
+template <bool TWO, bool XA, int NW>
+static int g2_launch_tn_nw(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
     constexpr int S = 3;
     constexpr size_t bytes = (size_t)S * ((TWO ? 2 : 1) * 32 * 128 + 32 * 128) * 4;        // 144 / 96 KiB (>= the 64 KiB epilogue tile)
-    static bool ok = g2_raise_lds((const void*)gemm2_tn_kernel<TWO, XA, S>, bytes);
+    static bool ok = g2_raise_lds((const void*)gemm2_tn_kernel<TWO, XA, S, NW>, bytes);
     if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
-    hipLaunchKernelGGL((gemm2_tn_kernel<TWO, XA, S>), dim3(pl.tiles, pl.splits), dim3(512), bytes, st, p);
+    hipLaunchKernelGGL((gemm2_tn_kernel<TWO, XA, S, NW>), dim3(pl.tiles, pl.splits), dim3(NW * 64), bytes, st, p);
     return PQ_OK;
+}
+template <bool TWO, bool XA>
+static int g2_launch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
+    static const char* e = getenv("PQ_G2_TN_WAVES");             // 4 | 8 (A/B timing)
+    if (e && e[0] == '8') return g2_launch_tn_nw<TWO, XA, 8>(p, pl, st);
+    return g2_launch_tn_nw<TWO, XA, 4>(p, pl, st);
 }
 
 // the GEMM half of pq_conv1x1_wgrad (the caller runs the slab reduction); 1 = taken, 0 = not eligible
