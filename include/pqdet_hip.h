@@ -94,8 +94,6 @@ typedef struct pq_conv1x1_fwd_args {
     float* partial;      /* [pq_conv1x1_blocks_k(M, O, I, 0)][2][ldp] or NULL */
     int32_t M, I, O, ldo, ldp;
     int32_t sub, OH, OW, IH, IW;   /* sub==1: plain; else strided gather of input rows */
-    float* scratch;      /* optional, >= pq_conv1x1_splitk_scratch_bytes(M, O, I): enables split-K where pq_conv1x1_splitk(M, O, I) > 1;
-                            `partial` then has pq_ew_blocks(M, O) rows instead of pq_conv1x1_blocks(M, O) */
 } pq_conv1x1_fwd_args;
 int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream);
 /* row-blocks (partial-sum rows) a GEMM with M rows and N output columns uses: fwd N=O, dgrad sink N=I */
@@ -105,9 +103,6 @@ int32_t pq_conv1x1_blocks(int32_t M, int32_t N);
  * (data gradient) must be sized with it.  pq_conv1x1_blocks(M, N) == pq_conv1x1_blocks_k(M, N, 0, 0) only describes
  * contractions that are not multiples of 32. */
 int32_t pq_conv1x1_blocks_k(int32_t M, int32_t N, int32_t K, int32_t kind);
-/* split-K factor the GEMM with M rows, N output columns and a K-long contraction uses when given scratch (1 = none) */
-int32_t pq_conv1x1_splitk(int32_t M, int32_t N, int32_t K);
-int64_t pq_conv1x1_splitk_scratch_bytes(int32_t M, int32_t N, int32_t K);
 
 typedef struct pq_conv1x1_dgrad_args {
     pq_gsrc dy;
@@ -118,8 +113,6 @@ typedef struct pq_conv1x1_dgrad_args {
                                       sink must then be accumulate-only (finalize==0) -- untouched pixels keep their value */
     const float* wt;     /* optional transposed copy of w, [I][ceil4(O)] with zero pad columns (pq_transpose_batch writes that
                             layout): K-contiguous B operand, faster LDS path */
-    float* scratch;      /* optional, >= pq_conv1x1_splitk_scratch_bytes(M, I, O): enables split-K where pq_conv1x1_splitk(M, I, O) > 1
-                            (and I % 4 == 0); the sink's statistics then have pq_ew_blocks(M, I) rows */
 } pq_conv1x1_dgrad_args;
 int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream);
 

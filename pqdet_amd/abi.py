@@ -38,12 +38,12 @@ class GSink(C.Structure):
 class Conv1x1Fwd(C.Structure):
     _fields_ = [('inp', Src), ('w', c_fp), ('bias', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('M', i32), ('I', i32), ('O', i32), ('ldo', i32), ('ldp', i32),
-                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('scratch', c_fp)]
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32)]
 
 
 class Conv1x1Dgrad(C.Structure):
     _fields_ = [('dy', GSrc), ('w', c_fp), ('dx', GSink), ('M', i32), ('I', i32), ('O', i32),
-                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('wt', c_fp), ('scratch', c_fp)]
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('wt', c_fp)]
 
 
 class Conv1x1Wgrad(C.Structure):
@@ -255,8 +255,6 @@ SIGNATURES = {
     'pq_conv1x1_fwd': (C.c_int, [C.POINTER(Conv1x1Fwd), C.c_void_p]),
     'pq_conv1x1_blocks': (i32, [i32, i32]),
     'pq_conv1x1_blocks_k': (i32, [i32, i32, i32, i32]),
-    'pq_conv1x1_splitk': (i32, [i32, i32, i32]),
-    'pq_conv1x1_splitk_scratch_bytes': (C.c_int64, [i32, i32, i32]),
     'pq_conv1x1_dgrad': (C.c_int, [C.POINTER(Conv1x1Dgrad), C.c_void_p]),
     'pq_conv1x1_wgrad': (C.c_int, [C.POINTER(Conv1x1Wgrad), C.c_void_p]),
     'pq_conv1x1_wgrad_scratch_bytes': (i64, [i32, i32, i32]),

@@ -30,8 +30,6 @@ struct GemmP {
     float* out; const float* bias; float* partial; int ldo, ldp;
     // epilogue 2
     pq_gsink sink;
-    // split-K (EMODE 0 only): gridDim.z slices of `ksplit` contraction columns, slice z stores to out + z*slab
-    int ksplit; size_t slab;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -58,16 +56,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     int bnx, bmy;              // XCD-aware numbering: one L2 serves all column tiles of a row panel
     xcd_block(bnx, bmy);
     const int m0 = bmy * BM, n0 = bnx * BN;
-    if (EMODE == 0 && p.ksplit > 0) {          // split-K: shift every operand base to this slice; indices stay relative
-        const int kbeg = blockIdx.z * p.ksplit;
-        p.a0 += kbeg;
-        if (AMODE == 2) p.a1 += kbeg;
-        if (AMODE != 0 && p.c0) { p.c0 += kbeg; p.c1 += kbeg; }
-        if (AMODE == 2) { p.c2 += kbeg; p.c3 += kbeg; }
-        p.b += BKN ? (size_t)kbeg * p.ldb : (size_t)kbeg;
-        p.K = min(p.K - kbeg, p.ksplit);
-        p.out += (size_t)blockIdx.z * p.slab;
-    }
     const int M = p.M, N = p.N, K = p.K;
     const ActParam aact = act_param(p.act);
     const bool aq = AMODE == 1 && p.qstate != nullptr;          // uniform
@@ -245,22 +233,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         }
     };
 
-    // Scheduling hint for the region (MFMA half, LDS writes of the next tile, MFMA half): spread the VALU transform and the
-    // ds_write_b128 of the next tile between the MFMAs instead of one block in the middle -- with one or two waves per SIMD the
-    // matrix pipe otherwise idles while that block issues.
-    auto interleave = [&]() {
-#ifdef PQ_SCHED_GROUPS
-        constexpr int NW = AI + BI;                       // ds_write_b128 per thread per k-tile
-        constexpr int MF = TI * TJ * 4 * (BK / 8);        // MFMAs per wave per k-tile
-#pragma unroll
-        for (int g = 0; g < NW; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, MF / NW, 0);     // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);          // VALU (operand transform, masks, addresses)
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);           // DS write
-        }
-#endif
-    };
-
     // AMODE 2 with y == NULL never reaches this kernel (host dispatches AMODE 0 instead).
     const int nk = (K + BK - 1) / BK;
     RegSet r0, r1;
@@ -274,22 +246,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         store_tiles(0, r0, 0);
         __syncthreads();
         for (int kt = 0; kt < nk; kt += 2) {
-#ifndef PQ_ABLATE_LOADS
             if (kt + 2 < nk) load_tiles((kt + 2) * BK, r0);
-#endif
             compute(0, 0);
             if (kt + 1 < nk) store_tiles((kt + 1) * BK, r1, 1);
             compute(0, 1);
-            interleave();
             __syncthreads();
             if (kt + 1 < nk) {
-#ifndef PQ_ABLATE_LOADS
                 if (kt + 3 < nk) load_tiles((kt + 3) * BK, r1);
-#endif
                 compute(1, 0);
                 if (kt + 2 < nk) store_tiles((kt + 2) * BK, r0, 0);
                 compute(1, 1);
-                interleave();
                 __syncthreads();
             }
         }
@@ -300,9 +266,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
-#ifndef PQ_ABLATE_LOADS
             if (more) load_tiles((kt + 1) * BK, r0);
-#endif
             // pinned phase order (the scheduler otherwise sinks the loads behind half of the MFMAs and the LDS writes behind all
             // of them, which drains the MFMA pipe before every barrier): loads -> MFMA half -> LDS writes -> MFMA half -> barrier
             __builtin_amdgcn_sched_barrier(0);
@@ -319,20 +283,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             __syncthreads();
             store_tiles(kt * BK, r0, 0);
             __syncthreads();
-#ifndef PQ_ABLATE_LOADS
             if (kt + 1 < nk) load_tiles((kt + 1) * BK, r0);
-#endif
             compute(0);
         }
     }
 
     // ---------------------------------------------------------------- epilogue
-#ifdef PQ_ABLATE_EPILOGUE
-    { float keep = 0.f;
-      for (int i = 0; i < TI; ++i) for (int j = 0; j < TJ; ++j) for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
-      if (keep == 123.456f) p.out[0] = keep;
-      return; }
-#endif
     float s1[TJ], s2[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) s1[j] = s2[j] = 0.f;
@@ -739,52 +695,6 @@ __global__ __launch_bounds__(256) void slab_reduce_cols_kernel(const float* slab
     if (j < n0) out0[j] = s; else out1[j - n0] = s;
 }
 
-// ------------------------------------------------------------------------------------------------ split-K reduction
-// out[m][n] = sum_z slab[z][m][n] (+ bias) with the BatchNorm statistics (forward), or the same sum handed to the gradient
-// sink (data gradient).  (CX channel-quad lanes, PY row lanes) like the elementwise kernels; statistics rows = gridDim.x.
-struct SkP {
-    const float* slab; size_t sstride; int S, M, N, lds;
-    float* out; int ldo; const float* bias; float* partial; int ldp;
-    pq_gsink sink;
-};
-template <bool SINK>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(SkP p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    int bx, by;
-    xcd_block(bx, by);
-    const int c4 = by * blockDim.x + threadIdx.x, c0 = c4 * 4;
-    const bool cok = c0 < p.N;
-    const SinkCoef4 sk = sink_coef4(p.sink, c0, p.N);
-    float4 b4 = f4zero();
-    if (!SINK && p.bias && cok)
-        b4 = make_float4(p.bias[c0], c0 + 1 < p.N ? p.bias[c0 + 1] : 0.f, c0 + 2 < p.N ? p.bias[c0 + 2] : 0.f, c0 + 3 < p.N ? p.bias[c0 + 3] : 0.f);
-    float4 s1 = f4zero(), s2 = f4zero();
-    for (int r = bx * blockDim.y + threadIdx.y; r < p.M && cok; r += gridDim.x * blockDim.y) {
-        float4 v[8];
-#pragma unroll
-        for (int z = 0; z < 8; ++z) v[z] = z < p.S ? ldg4(p.slab + (size_t)z * p.sstride + (size_t)r * p.lds + c0) : f4zero();
-        float4 a = f4add(f4add(f4add(v[0], v[1]), f4add(v[2], v[3])), f4add(f4add(v[4], v[5]), f4add(v[6], v[7])));
-        if (SINK) {
-            sink_emit4(p.sink, sk, (size_t)r, c0, a, s1, s2);
-        } else {
-            a = f4add(a, b4);
-            float e[4] = {a.x, a.y, a.z, a.w};
-            float* dst = p.out + (size_t)r * p.ldo + c0;
-            if (c0 + 3 < p.N) {
-                stg4(dst, a);
-            } else {                       // last quad of a channel count that is not a multiple of 4: the pad stays untouched
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { if (c0 + j < p.N) dst[j] = e[j]; else e[j] = 0.f; }
-                a = make_float4(e[0], e[1], e[2], e[3]);
-            }
-            s1 = f4add(s1, a);
-            s2 = f4fma(a, a, s2);
-        }
-    }
-    float* part = SINK ? ((p.sink.finalize && p.sink.mean) ? p.sink.partial : nullptr) : p.partial;
-    if (part) block_reduce_store_stats<256>(s1, s2, part, SINK ? p.sink.ldp : p.ldp, c0, p.N, lds, bx);
-}
-
 }  // namespace pq
 
 using namespace pq;
@@ -883,45 +793,6 @@ static void launch_nt(const GemmP& p, hipStream_t st, int bm) {
     }
 }
 
-// Split-K for GEMMs whose 64x64 tiling leaves more than half of the chip's 768 workgroup slots empty while the contraction is
-// long (the 4096-row neck / head layers): S slices of the contraction, one slab each, summed by splitk_reduce_kernel (which
-// also carries bias + statistics / the gradient sink).  PQ_SPLITK=0 disables.
-struct SplitK { int S, ksplit; };
-static SplitK splitk_plan(int M, int N, int K) {
-    static const char* env = getenv("PQ_SPLITK");
-    if ((env && env[0] == '0') || K < 512) return {1, 0};
-    const long blocks = (long)((M + 63) / 64) * ((N + 63) / 64);
-    if (pick_tile(M, N).kind != 0 || blocks * 2 > 768) return {1, 0};
-    long S = 768 / blocks;
-    if (S > K / 128) S = K / 128;
-    if (S > 8) S = 8;
-    if (S < 2) return {1, 0};
-    const int ks = (int)(((K + S - 1) / S + 31) / 32 * 32);
-    const int S2 = (K + ks - 1) / ks;
-    if (S2 < 2) return {1, 0};
-    return {S2, ks};
-}
-extern "C" int32_t pq_conv1x1_splitk(int32_t M, int32_t N, int32_t K) { return splitk_plan(M, N, K).S; }
-extern "C" int64_t pq_conv1x1_splitk_scratch_bytes(int32_t M, int32_t N, int32_t K) {
-    const SplitK sp = splitk_plan(M, N, K);
-    return sp.S > 1 ? (int64_t)sp.S * M * ((N + 3) & ~3) * 4 : 0;
-}
-template <int AMODE, bool BKN>
-static void launch_nt_split(GemmP p, const SplitK& sp, float* scratch, hipStream_t st) {
-    p.ksplit = sp.ksplit;
-    p.ldo = (p.N + 3) & ~3;
-    p.slab = (size_t)p.M * p.ldo;
-    p.out = scratch; p.bias = nullptr; p.partial = nullptr;
-    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, sp.S);
-    hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, 32, AMODE, BKN, 0, true, 2>), grid, dim3(256), 0, st, p);
-}
-static void launch_splitk_reduce(bool sink, const SkP& q, hipStream_t st) {
-    EwGeom g = ew_geom((long)q.M, q.N);
-    const size_t sh = (size_t)g.cx * g.py * 8 * sizeof(float);
-    if (sink) hipLaunchKernelGGL((splitk_reduce_kernel<true>), dim3(g.gx, g.gy), dim3(g.cx, g.py), sh, st, q);
-    else hipLaunchKernelGGL((splitk_reduce_kernel<false>), dim3(g.gx, g.gy), dim3(g.cx, g.py), sh, st, q);
-}
-
 extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->in.x && a->w && a->out, "null pointer");
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
@@ -937,17 +808,6 @@ extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
     p.out = a->out; p.bias = a->bias; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     hipStream_t st = (hipStream_t)stream;
     const bool xform = a->in.scale != nullptr || a->in.act != PQ_ACT_LINEAR || a->in.qstate != nullptr;
-    const SplitK sp = (a->scratch && a->sub <= 1) ? splitk_plan(a->M, a->O, a->I) : SplitK{1, 0};
-    if (sp.S > 1) {        // statistics rows then come from the reduction: pq_ew_blocks(M, O) of them
-        if (xform) launch_nt_split<1, false>(p, sp, a->scratch, st); else launch_nt_split<0, false>(p, sp, a->scratch, st);
-        PQ_CHECK_LAUNCH();
-        SkP q{};
-        q.slab = a->scratch; q.lds = (a->O + 3) & ~3; q.sstride = (size_t)a->M * q.lds; q.S = sp.S; q.M = a->M; q.N = a->O;
-        q.out = a->out; q.ldo = a->ldo; q.bias = a->bias; q.partial = a->partial; q.ldp = a->ldp;
-        launch_splitk_reduce(false, q, st);
-        PQ_CHECK_LAUNCH();
-        return PQ_OK;
-    }
     const int bm = row_bm(a->M, a->O, a->I, 0);
     {
         const int rc = g2_conv1x1_fwd(a, bm, st);
@@ -981,21 +841,6 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->I; p.K = a->O;
     p.sink = a->dx;
     hipStream_t st = (hipStream_t)stream;
-    const SplitK sp = (a->scratch && a->sub <= 1 && (a->I & 3) == 0) ? splitk_plan(a->M, a->I, a->O) : SplitK{1, 0};
-    if (sp.S > 1) {        // slices -> slabs -> one pass through the sink (statistics rows: pq_ew_blocks(M, I))
-        if (a->wt) {
-            p.b = a->wt; p.ldb = (a->O + 3) & ~3;
-            if (a->dy.y) launch_nt_split<2, false>(p, sp, a->scratch, st); else launch_nt_split<0, false>(p, sp, a->scratch, st);
-        } else {
-            if (a->dy.y) launch_nt_split<2, true>(p, sp, a->scratch, st); else launch_nt_split<0, true>(p, sp, a->scratch, st);
-        }
-        PQ_CHECK_LAUNCH();
-        SkP q{};
-        q.slab = a->scratch; q.lds = a->I; q.sstride = (size_t)a->M * q.lds; q.S = sp.S; q.M = a->M; q.N = a->I; q.sink = a->dx;
-        launch_splitk_reduce(true, q, st);
-        PQ_CHECK_LAUNCH();
-        return PQ_OK;
-    }
     const int bm = row_bm(a->M, a->I, a->O, 1);
     {
         const int rc = g2_conv1x1_dgrad(a, bm, st);
@@ -1015,9 +860,8 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
 static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, int& rows) {
     // 64x64 output tiles everywhere: four times more tiles than 128x128 means four times fewer row splits for the same
     // number of workgroups, i.e. longer contraction loops per workgroup and a quarter of the slab traffic; measured equal
-    // or faster on every layer shape of the nets (PQ_WG_BIG=1 restores the 128x128 rule for A/B timing)
-    static const char* big_env = getenv("PQ_WG_BIG");
-    big = (O >= 96 && I >= 96) && (big_env && big_env[0] == '1');
+    // or faster on every layer shape of the nets
+    big = false;
     const int b = big ? 128 : 64;
     tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
     static const char* tgt_env = getenv("PQ_WG_TARGET");

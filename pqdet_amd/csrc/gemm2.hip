@@ -567,7 +567,7 @@ static bool act_clamp(int act, float& lo, float& hi) {
 // returns 1 when the launch was taken, 0 when the shape / operands are outside this kernel family (caller falls back),
 // < 0 on error
 int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st) {
-    if (!g2_enabled() || a->sub > 1 || a->in.qstate || (a->I & 31) || a->I < 128 || a->O < 64 || a->scratch) return 0;
+    if (!g2_enabled() || a->sub > 1 || a->in.qstate || (a->I & 31) || a->I < 128 || a->O < 64) return 0;
     if ((a->in.ld & 3) || (((uintptr_t)a->in.x) & 15) || (((uintptr_t)a->w) & 15)) return 0;
     G2P p{};
     if (!act_clamp(a->in.act, p.lo, p.hi)) return 0;
@@ -583,7 +583,7 @@ int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st) {
 }
 
 int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st) {
-    if (!g2_enabled() || a->sub > 1 || !a->wt || a->scratch || (a->O & 31) || a->O < 64 || a->I < 64 || a->dx.qstate) return 0;
+    if (!g2_enabled() || a->sub > 1 || !a->wt || (a->O & 31) || a->O < 64 || a->I < 64 || a->dx.qstate) return 0;
     const pq_gsink& sk = a->dx;
     const bool stats = sk.mean != nullptr && sk.partial != nullptr;
     const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);

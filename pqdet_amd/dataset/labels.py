@@ -19,33 +19,43 @@ STRIDES = np.array([8, 16, 32])
 def create_label(bboxes: Sequence[np.ndarray], output_sizes: np.ndarray, num_classes: int, strides=STRIDES,
                  anchors=ANCHORS, gt_per_grid: int = 3, anchors_iou_threshold: float = 0.3):
     """bboxes rows = [x1, y1, x2, y2, class, mixup weight]; output_sizes (3, 2) = (h, w) of the three heads.
-    -> (label_s, label_m, label_l, boxes_s, boxes_m, boxes_l); labels are (h, w, gt_per_grid, 6 + C) float32."""
+    -> (label_s, label_m, label_l, boxes_s, boxes_m, boxes_l); labels are (h, w, gt_per_grid, 6 + C) float32.
+
+    One pass over ALL boxes of the image: cells, the 9 anchor IoUs and the threshold / arg-max choice are computed as
+    (n, 9) arrays; only the final writes run in (box, anchor) order, because a later ground truth overwrites an earlier one
+    in the same cell slot (reference semantics, pinned by fixture G8 and by the device kernel ``pq_create_label``).  The
+    integer / float32 / float64 promotions of the reference's NumPy expressions are kept (cells from float32 // int64,
+    cell centres in float64 through the int64 strides), so the grids are bit-identical."""
     grids = [np.zeros((output_sizes[i][0], output_sizes[i][1], gt_per_grid, 6 + num_classes), dtype=np.float32)
              for i in range(3)]
     for gmap in grids:
         gmap[..., -1] = 1.0                                       # mix-up weight defaults to 1
     lists: List[List[np.ndarray]] = [[], [], []]
-    uniform = np.full(num_classes, 1.0 / num_classes)
-    for box in bboxes:
-        corners = box[:4]
-        cls_id, mix = int(box[4]), box[5]
-        centre_size = np.concatenate([(corners[2:] + corners[:2]) * 0.5, corners[2:] - corners[:2]], axis=-1)
-        target_prob = np.zeros(num_classes, dtype=np.float64)
-        target_prob[cls_id] = 1.0
-        target_prob = target_prob * (1 - 0.01) + 0.01 * uniform    # label smoothing, delta = 0.01
-        cells = (centre_size[:2][:, None] // strides).astype(np.int32).T          # (3, 2): (x, y) per scale
-        cell_centres = (cells.astype(np.float32) + 0.5) * strides[:, None]
-        anchor_boxes = np.concatenate([np.repeat(cell_centres, 3, axis=0), anchors], axis=-1)
-        overlap = iou_xywh_numpy(centre_size, anchor_boxes)
-        chosen = overlap > anchors_iou_threshold
-        if not chosen.any():
-            chosen[overlap.argmax()] = 1
-        row = np.concatenate([corners, [1.0], target_prob, [mix]], axis=-1)
-        for k in chosen.nonzero()[0]:
-            scale, slot = k // 3, k % 3
-            cx, cy = cells[scale]
-            grids[scale][cy, cx, slot, :] = row
-            lists[scale].append(corners)
+    boxes = np.asarray(bboxes, dtype=np.float32).reshape(-1, 6)
+    n = boxes.shape[0]
+    if n == 0:
+        return (*grids, *lists)
+    strides = np.asarray(strides)
+    corners = boxes[:, :4]
+    centre_size = np.concatenate([(corners[:, 2:] + corners[:, :2]) * 0.5, corners[:, 2:] - corners[:, :2]], axis=-1)   # (n, 4) f32
+    cells = (centre_size[:, :2, None] // strides).astype(np.int32).transpose(0, 2, 1)                 # (n, 3, 2): (x, y) per scale
+    cell_centres = (cells.astype(np.float32) + 0.5) * strides[None, :, None]                         # float64 via int64 strides
+    anchor_boxes = np.concatenate([np.repeat(cell_centres, gt_per_grid, axis=1),
+                                   np.broadcast_to(anchors, (n,) + anchors.shape)], axis=-1)          # (n, 9, 4)
+    overlap = iou_xywh_numpy(centre_size[:, None, :], anchor_boxes)                                   # (n, 9)
+    chosen = overlap > anchors_iou_threshold
+    none = ~chosen.any(axis=1)
+    chosen[none, overlap[none].argmax(axis=1)] = True                                                 # fallback: the best anchor
+    # rows to write: [corners, 1, smoothed one-hot (float64 arithmetic, stored as float32), mix]
+    prob = np.zeros((n, num_classes), dtype=np.float64)
+    prob[np.arange(n), boxes[:, 4].astype(np.int64)] = 1.0
+    prob = prob * (1 - 0.01) + 0.01 * np.full(num_classes, 1.0 / num_classes)                         # label smoothing, delta = 0.01
+    rows = np.concatenate([corners, np.ones((n, 1)), prob, boxes[:, 5:6]], axis=-1).astype(np.float32)
+    for b, k in zip(*np.nonzero(chosen)):                                                             # box-major, anchor-minor order
+        scale, slot = k // gt_per_grid, k % gt_per_grid
+        cx, cy = cells[b, scale]
+        grids[scale][cy, cx, slot, :] = rows[b]
+        lists[scale].append(corners[b])
     return (*grids, *lists)
 
 

@@ -68,7 +68,9 @@ class AnyModel(nn.Module):
         self.module_list = nn.ModuleList(Parser(cfg).torch_layers(quant, onnx))
         cfg.close()
         self._flat = None
-        self._plans = {}
+        self._plans = {}               # (shape, mode) -> compiled Plan, in least-recently-used order
+        self._buffer_ptrs = None
+        self.max_plans = int(__import__('os').environ.get('PQ_MAX_PLANS', '12'))
         self._reducer = None          # set by pqdet_amd.parallel.DistributedModel
         self._nan_event = None
         self._nan_host = None
@@ -104,16 +106,26 @@ class AnyModel(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError('expected (B, 3, H, W) with H, W multiples of 32, got %s' % (tuple(x.shape),))
         self._ensure_flat(x.device)
+        ptrs = []
         for b in self.buffers():
             if b.device != x.device:
                 raise abi.PQError('model buffers live on %s but the input is on %s' % (b.device, x.device))
+            ptrs.append(b.data_ptr())
+        ptrs = tuple(ptrs)
+        if ptrs != self._buffer_ptrs:          # a buffer was re-assigned (bn.running_mean = t): compiled plans hold its old address
+            self._plans.clear()
+            self._buffer_ptrs = ptrs
         bn_train = bool(self.training) and not self.bn_frozen
         key = (tuple(x.shape), bn_train, bool(with_loss), bool(self._qat), bool(self.qat_observer_enabled),
                bool(self.qat_fake_quant_enabled))
-        plan = self._plans.get(key)
+        plan = self._plans.pop(key, None)
         if plan is None:
+            # a plan owns every activation / gradient buffer of its shape (nothing is shared or recomputed); multi-scale
+            # training (reference: 10 input sizes) therefore keeps `max_plans` of them, least recently used first out
+            while len(self._plans) >= max(1, int(self.max_plans)):
+                self._plans.pop(next(iter(self._plans)))
             plan = Plan(self, tuple(x.shape), bn_train, bool(with_loss))
-            self._plans[key] = plan
+        self._plans[key] = plan                  # most recently used last
         return plan
 
     # ---- quantisation-aware training ----------------------------------------------------------------------

@@ -13,11 +13,24 @@ from . import ops
 
 
 class Adam(torch.optim.Optimizer):
+    """Per-parameter state lives in ``self.state[p]`` under torch.optim.Adam's names (``step``, ``exp_avg``, ``exp_avg_sq``),
+    so ``state_dict()`` / ``load_state_dict()`` save and restore the moments and are interchangeable with
+    ``torch.optim.Adam``.  On the flat path the moment tensors are VIEWS into two flat buffers laid out like the parameter
+    buffer; whenever they are not (first step, after ``load_state_dict``, after the model was re-flattened by ``.to()`` /
+    ``.float()``) they are copied into place first, so the moments survive all of these."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.grad_scale = grad_scale
-        self._flat_state = {}
+        self._flat_bufs = {}          # group index -> (FlatParams, flat m, flat v)
+        self._was_flat = set()
+        self._linked = {}             # group index -> (id(FlatParams), state generation) of the last link
+        self._state_gen = 0
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._state_gen += 1          # the loaded moment tensors are copies: re-link them on the next step
 
     def _group_flat(self, group):
         ps = group['params']
@@ -29,6 +42,29 @@ class Adam(torch.optim.Optimizer):
             return None
         return flat
 
+    def _link_flat_state(self, gi, flat):
+        """Flat moment buffers for this group with every ``state[p]`` entry a view into them; returns (m, v, step)."""
+        cur = self._flat_bufs.get(gi)
+        if cur is None or cur[0] is not flat or cur[1].device != flat.flat.device:
+            cur = (flat, torch.zeros_like(flat.flat), torch.zeros_like(flat.flat))
+            self._flat_bufs[gi] = cur
+        _, m, v = cur
+        tag = (id(flat), self._state_gen)
+        if self._linked.get(gi) == tag:                 # steady state: nothing moved since the last step
+            return m, v, int(self.state[flat.params[0]]['step'])
+        self._linked[gi] = tag
+        step = 0
+        for p, o in zip(flat.params, flat.offsets):
+            st = self.state[p]
+            mv, vv = m[o:o + p.numel()].view(p.shape), v[o:o + p.numel()].view(p.shape)
+            old_m, old_v = st.get('exp_avg'), st.get('exp_avg_sq')
+            if old_m is not None and old_m.data_ptr() != mv.data_ptr():       # loaded / carried over from another layout
+                mv.copy_(old_m.to(mv.device, mv.dtype).view(p.shape))
+                vv.copy_(old_v.to(vv.device, vv.dtype).view(p.shape))
+            st['exp_avg'], st['exp_avg_sq'] = mv, vv
+            step = max(step, int(st.get('step', 0)))
+        return m, v, step
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -37,25 +73,34 @@ class Adam(torch.optim.Optimizer):
             flat = self._group_flat(group)
             if flat is not None and all(p.grad is not None and p.grad.data_ptr() == gv.data_ptr()
                                         for p, gv in zip(flat.params, flat.grad_views)):
-                st = self._flat_state.get(gi)
-                if st is None or st['m'].numel() != flat.flat.numel() or st['m'].device != flat.flat.device:
-                    st = {'step': 0, 'm': torch.zeros_like(flat.flat), 'v': torch.zeros_like(flat.flat)}
-                    self._flat_state[gi] = st
-                st['step'] += 1
-                ops.adam_step(flat.flat, flat.grad, st['m'], st['v'], float(group['lr']), b1, b2, group['eps'],
-                              group['weight_decay'], st['step'], self.grad_scale)
+                m, v, step = self._link_flat_state(gi, flat)
+                step += 1
+                for p in flat.params:
+                    self.state[p]['step'] = step
+                self._was_flat.add(gi)
+                ops.adam_step(flat.flat, flat.grad, m, v, float(group['lr']), b1, b2, group['eps'],
+                              group['weight_decay'], step, self.grad_scale)
                 continue
+            if gi in self._was_flat:
+                import warnings
+                warnings.warn('pqdet_amd.optim.Adam: parameter group %d left the fused flat-buffer path (parameters or gradients '
+                              'were re-allocated); continuing per tensor with the same moments' % gi)
+                self._was_flat.discard(gi)
+                self._flat_bufs.pop(gi, None)
             for p in group['params']:           # generic path: one launch per tensor, same kernel
                 if p.grad is None:
                     continue
                 st = self.state[p]
-                if not st:
+                if 'exp_avg' not in st:
                     st['step'] = 0
-                    st['m'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st['v'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st['step'] += 1
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if not st['exp_avg'].is_contiguous() or st['exp_avg'].device != p.device:
+                    st['exp_avg'] = st['exp_avg'].to(p.device).contiguous()
+                    st['exp_avg_sq'] = st['exp_avg_sq'].to(p.device).contiguous()
+                st['step'] = int(st['step']) + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                ops.adam_step(p.data, g, st['m'], st['v'], float(group['lr']), b1, b2, group['eps'],
+                ops.adam_step(p.data, g, st['exp_avg'], st['exp_avg_sq'], float(group['lr']), b1, b2, group['eps'],
                               group['weight_decay'], st['step'], self.grad_scale)
         return loss
 

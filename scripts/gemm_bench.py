@@ -49,11 +49,6 @@ for (M, I, O) in SHAPES:
         part = torch.empty(nb * 2 * ldp, device=dev)
         a = abi.Conv1x1Fwd(abi.Src(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), I, 2), w.data_ptr(), None, y.data_ptr(), part.data_ptr(),
                            M, I, O, ldo, ldp, 1, 0, 0, 0, 0)
-        if os.environ.get('SPLITK') and l.pq_conv1x1_splitk(M, O, I) > 1:
-            skf = torch.empty(l.pq_conv1x1_splitk_scratch_bytes(M, O, I) // 4, device=dev)
-            part = torch.empty(l.pq_ew_blocks(M, O) * 2 * ldp, device=dev)
-            a.partial, a.scratch = part.data_ptr(), skf.data_ptr()
-            line += '[S=%d] ' % l.pq_conv1x1_splitk(M, O, I)
         ms = timeit(lambda: abi.check(l.pq_conv1x1_fwd(C.byref(a), st)))
         tot['fwd'] = tot.get('fwd', 0) + ms
         line += '| fwd %.3f ms %5.1f TF %6.0f GB/s ' % (ms, flops / ms / 1e9, byts / ms / 1e6)
@@ -68,11 +63,6 @@ for (M, I, O) in SHAPES:
         if os.environ.get('DG_WT'):
             wt = torch.zeros(I, ldo, device=dev); wt[:, :O] = w.t()
             a.wt = wt.data_ptr()
-        if os.environ.get('SPLITK') and l.pq_conv1x1_splitk(M, I, O) > 1:
-            skd = torch.empty(l.pq_conv1x1_splitk_scratch_bytes(M, I, O) // 4, device=dev)
-            part = torch.empty(l.pq_ew_blocks(M, I) * 2 * ldp, device=dev)
-            a.dx.partial, a.scratch = part.data_ptr(), skd.data_ptr()
-            line += '[S=%d] ' % l.pq_conv1x1_splitk(M, I, O)
         ms = timeit(lambda: abi.check(l.pq_conv1x1_dgrad(C.byref(a), st)))
         tot['dgrad'] = tot.get('dgrad', 0) + ms
         line += '| dgrad %.3f ms %5.1f TF %6.0f GB/s ' % (ms, flops / ms / 1e9, byts / ms / 1e6)

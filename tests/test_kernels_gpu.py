@@ -74,7 +74,7 @@ def reduce_partial(partial, nblk, ldp, C_):
     (512, 1024, 75, 2, True, True, False),
     (130, 16, 96, 0, False, False, True),
     (64, 320, 1280, 1, True, False, True),
-    (4096, 512, 256, 2, True, False, True),       # split-K shapes (few tiles, long contraction)
+    (4096, 512, 256, 2, True, False, True),       # few tiles, long contraction (LDS-DMA ring kernels)
     (4096, 1024, 75, 2, True, True, False),
     (4000, 960, 160, 0, False, False, True),
 ])
@@ -112,23 +112,6 @@ def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
         s1, s2 = reduce_partial(partial, nblk, ldp, O)
         close(s1.float(), want.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum')
         close(s2.float(), (want.double() ** 2).sum(0).float(), rt=1e-3, at=1e-2, what='sumsq')
-    if M >= 4000:
-        # same layer through split-K: slices of the contraction into slabs, one reduction pass with bias + statistics
-        l = abi.lib()
-        assert l.pq_conv1x1_splitk(M, O, I) > 1
-        scratch = torch.full((l.pq_conv1x1_splitk_scratch_bytes(M, O, I) // 4,), float('nan'), device=DEV)
-        out2 = torch.full((M, ldo), float('nan'), device=DEV)
-        nb2 = l.pq_ew_blocks(M, O)
-        part2 = torch.zeros(nb2 * 2 * ldp, device=DEV) if stats else None
-        a.out, a.partial, a.scratch = out2.data_ptr(), abi.ptr(part2), scratch.data_ptr()
-        abi.check(l.pq_conv1x1_fwd(C.byref(a), stream()))
-        torch.cuda.synchronize()
-        close(out2[:, :O], want, what='conv1x1 out (split-K)')
-        assert torch.isnan(out2[:, O:]).all(), 'split-K wrote outside the logical channels'
-        if stats:
-            s1, s2 = reduce_partial(part2, nb2, ldp, O)
-            close(s1.float(), want.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum (split-K)')
-            close(s2.float(), (want.double() ** 2).sum(0).float(), rt=1e-3, at=1e-2, what='sumsq (split-K)')
 
 
 def test_conv1x1_fwd_strided_rows():
@@ -236,27 +219,6 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
         abi.check(abi.lib().pq_conv1x1_dgrad(C.byref(a), stream()))
         torch.cuda.synchronize()
         close(g2, gout, what='dgrad sink (transposed weights)')
-        if M >= 4000:
-            # split-K: slabs of the slices, one pass through the sink (statistics rows: pq_ew_blocks)
-            l = abi.lib()
-            assert l.pq_conv1x1_splitk(M, I, O) > 1
-            scratch = torch.full((l.pq_conv1x1_splitk_scratch_bytes(M, I, O) // 4,), float('nan'), device=DEV)
-            g3 = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
-            nb3 = l.pq_ew_blocks(M, I)
-            part3 = torch.zeros(nb3 * 2 * ldp, device=DEV)
-            for use_wt in (True, False):
-                a.dx.g, a.dx.partial, a.scratch = g3.data_ptr(), (part3.data_ptr() if stats else None), scratch.data_ptr()
-                a.wt = wt.data_ptr() if use_wt else None
-                if accum:
-                    g3.copy_(old.to(DEV))
-                abi.check(l.pq_conv1x1_dgrad(C.byref(a), stream()))
-                torch.cuda.synchronize()
-                close(g3, gout, what='dgrad sink (split-K, wt=%s)' % use_wt)
-                if stats:
-                    s1, s2 = reduce_partial(part3, nb3, ldp, I)
-                    xh = (yin.double() - mean_in.double()) * inv_in.double()
-                    close(s1.float(), gout.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum g (split-K)')
-                    close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat (split-K)')
 
 
 @pytest.mark.parametrize('M,I,O,two,bias', [(3000, 32, 16, True, False), (1000, 24, 144, True, False),
@@ -1145,3 +1107,50 @@ def test_create_label_matches_host_assignment_bit_exactly(B, S, ncls, seed):
         m = got[3 + s].shape[1]
         assert torch.equal(full[3 + s][:, :m], got[3 + s]) and float(full[3 + s][:, m:].abs().sum()) == 0.0
 
+
+
+def test_adam_state_survives_state_dict_round_trip_and_reflatten():
+    """the fused path's moments live in Optimizer.state (torch.optim.Adam's names), so state_dict() /
+    load_state_dict() carry them, and re-flattening the model (``.float()`` / ``.to()``) keeps them."""
+    import io as _io
+    from pqdet_amd import optim
+    from pqdet_amd.model import zoo
+    from pqdet_amd.model.interpreter import DetectionModel
+    from pqdet_amd.dataset import labels
+    torch.manual_seed(0)
+    cfg = zoo.cfg_text('mobilenetv2-fpn')
+    x = torch.randn(2, 3, 64, 64, device=DEV)
+    tgt = tuple(t.to(DEV) for t in labels.synthetic_targets(2, 64, 20, seed=3))
+
+    def make():
+        torch.manual_seed(1)
+        return DetectionModel(_io.StringIO(cfg)).to(DEV).train()
+
+    def one(net, opt):
+        opt.zero_grad()
+        net(x, tgt)['loss'].mean().backward()
+        opt.step()
+
+    a, b = make(), make()
+    oa, ob = optim.Adam(a.parameters(), lr=1e-3), optim.Adam(b.parameters(), lr=1e-3)
+    for _ in range(2):
+        one(a, oa), one(b, ob)
+    sd = oa.state_dict()
+    st0 = sd['state'][0]
+    assert set(st0) == {'step', 'exp_avg', 'exp_avg_sq'} and int(st0['step']) == 2 and float(st0['exp_avg'].abs().sum()) > 0
+    # (1) a fresh optimiser loaded from the state dict continues exactly like the original
+    oa2 = optim.Adam(a.parameters(), lr=1e-3)
+    oa2.load_state_dict(sd)
+    one(a, oa2), one(b, ob)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+    # (2) re-flatten model a (new flat buffers): the moments are carried over, training stays in lock-step with b
+    a._flat = None
+    a._plans.clear()
+    for p in a.parameters():
+        p.data = p.data.clone()
+        p.grad = None
+    one(a, oa2), one(b, ob)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+    assert int(oa2.state_dict()['state'][0]['step']) == 4

@@ -457,3 +457,26 @@ def test_no_cpu_fallback():
     net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
     with pytest.raises(abi.PQError):
         net(torch.zeros(1, 3, 64, 64))
+
+
+def test_plan_cache_is_bounded_and_follows_reassigned_buffers():
+    """plans are evicted least-recently-used first beyond ``max_plans``; assigning a new tensor to a BatchNorm
+    buffer (as opposed to copy_) rebuilds the plans instead of leaving them on the freed address."""
+    net, ref = _pair(seed=4)
+    net.max_plans = 2
+    net.eval()
+    outs = {}
+    with torch.no_grad():
+        for s in (64, 96, 128, 64):
+            outs[s] = net(seeded_images(1, s, s, 1).to(DEV))
+            assert len(net._plans) <= 2
+    assert [k[0][2] for k in net._plans] == [128, 64]                    # 96 was evicted, 64 re-used last
+    bn = net.module_list[0].bn
+    bn.running_mean = bn.running_mean.clone() * 0 + 0.25                 # re-assignment: new storage
+    ref.module_list[0].bn.running_mean.fill_(0.25)
+    ref.eval()
+    with torch.no_grad():
+        got = net(seeded_images(1, 64, 64, 1).to(DEV))
+        want = ref(seeded_images(1, 64, 64, 1))
+    assert _relerr(got, want) < 1e-4
+    assert _relerr(got, outs[64]) > 1e-3                                  # the new statistics were really used

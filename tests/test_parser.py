@@ -91,3 +91,26 @@ def test_product_label_assignment_matches_golden(golden):
         np.testing.assert_array_equal(out[i], golden['g8_label%d' % i])
         np.testing.assert_array_equal(np.asarray(out[3 + i], np.float32).reshape(-1, 4), golden['g8_list%d' % i])
     np.testing.assert_array_equal(labels.pad_box_lists([[], out[3], out[4]]), golden['g8_padded'])
+
+
+def test_vectorised_label_assignment_equals_oracle_on_random_images():
+    """labels.create_label treats all boxes of an image at once; the oracle keeps the box-by-box restatement pinned by G8:
+    both must produce bit-identical grids and box lists (overwrite order, arg-max fallback, float promotions)."""
+    import numpy as np
+    from oracle import postprocess as opost
+    from pqdet_amd.dataset import labels
+    rng = np.random.RandomState(0)
+    for trial in range(120):
+        S, ncls, n = rng.choice([64, 128, 320, 512, 608]), rng.choice([1, 5, 20, 80]), rng.randint(0, 12)
+        bl = []
+        for _ in range(n):
+            w, h = rng.uniform(2, S * 0.9, 2)
+            x1, y1 = rng.uniform(0, max(S - w, 1e-3)), rng.uniform(0, max(S - h, 1e-3))
+            bl.append(np.array([x1, y1, min(x1 + w, S - 1e-3), min(y1 + h, S - 1e-3), rng.randint(0, ncls),
+                                rng.choice([1.0, 0.6, 0.4])], dtype=np.float32))
+        hw = np.array([[S // s, S // s] for s in (8, 16, 32)])
+        a = labels.create_label(bl, hw, ncls)
+        b = opost.create_label(np.asarray(bl, dtype=np.float32).reshape(-1, 6), hw, ncls)
+        for i in range(3):
+            np.testing.assert_array_equal(a[i], b[i])
+            np.testing.assert_array_equal(np.asarray(a[3 + i], np.float32).reshape(-1, 4), np.asarray(b[3 + i], np.float32).reshape(-1, 4))
