@@ -7,17 +7,17 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r1 -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r2 -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r1 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/fetch.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r2 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/fetch.log
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r1 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/write.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r2 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/write.log
 echo "write pass done"
 cd $ROOT
-S=$(dirname $(find $OUT/stats -name 'r1*kernel_stats.csv' | head -1))
-F=$(dirname $(find $OUT/fetch -name 'r1*counter_collection.csv' | head -1))
-W=$(dirname $(find $OUT/write -name 'r1*counter_collection.csv' | head -1))
-python3 scripts/pmc_summary.py $S $F $W r1 > $OUT/r1_pmc_summary.csv
-cp $(find $OUT/stats -name 'r1*kernel_stats.csv' | head -1) $OUT/r1_kernel_stats.csv
+S=$(dirname $(find $OUT/stats -name 'r2*kernel_stats.csv' | head -1))
+F=$(dirname $(find $OUT/fetch -name 'r2*counter_collection.csv' | head -1))
+W=$(dirname $(find $OUT/write -name 'r2*counter_collection.csv' | head -1))
+python3 scripts/pmc_summary.py $S $F $W r2 > $OUT/r2_pmc_summary.csv
+cp $(find $OUT/stats -name 'r2*kernel_stats.csv' | head -1) $OUT/r2_kernel_stats.csv
 rm -rf $OUT/fetch $OUT/write $OUT/stats
 echo "summary done"
