@@ -160,7 +160,7 @@ def op_work(op):
 def profile_kernels(plan, x, tgt, side=None, passes=3):
     """Per-kernel-class device time of one step: HIP events around every op on the stream it is launched on, replayed
     exactly as in the timed steps (weight-gradient kernels overlap the data-gradient chain on the side stream), so the
-    averages are directly comparable with a rocprofv3 kernel trace of this command (profiles/r1_kernel_stats.csv)."""
+    averages are directly comparable with a rocprofv3 kernel trace of this command (profiles/r2_kernel_stats.csv)."""
     l = abi.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     sd = C.c_void_p(side.cuda_stream) if side is not None else None
@@ -184,19 +184,22 @@ def profile_kernels(plan, x, tgt, side=None, passes=3):
 # kernel class -> (regex of the class's main kernel, regex of helper kernels launched by the same op) over the kernel
 # names of profiles/r1_pmc_summary.csv (gemm_nt template args: BM,BN,WM,WN,AMODE,BKN,EMODE,..)
 PMC_PATTERN = {
-    'conv1x1_dgrad (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, 2, ', None),
-    'conv1x1_fwd (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], ', None),
-    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<', r'pq::slab_reduce'),
+    # gemm_nt template args: BM,BN,WM,WN,AMODE,BKN,EMODE,..;  gemm2_nt: BM,BN,AMODE,EMODE,S  (EMODE 2 = gradient sink)
+    'conv1x1_dgrad (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, 2, |gemm2_nt_kernel<\d+, \d+, \d, 2, ', None),
+    'conv1x1_fwd (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], |gemm2_nt_kernel<\d+, \d+, \d, [01], ', None),
+    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<|gemm2_tn_kernel<', r'pq::slab_reduce'),
     'conv1x1_bwd narrow layers (fused dgrad+wgrad, one pass over dy)': (r'pw_bwd_kernel<', r'pw_slab_reduce_kernel'),
 }
+PMC_FILE = 'r2_pmc_summary.csv'
 
 
 def measured_traffic(kernel_class, model_name):
     """HBM bytes per launch of a kernel class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs of this command, gfx950 read correction applied -- scripts/pmc_summary.py).  None if unavailable."""
+    separate runs of this command, gfx950 read correction applied -- scripts/pmc_summary.py), averaged over the launches of
+    the class's kernels (both kernel generations) with the helper launches of the same op added in.  None if unavailable."""
     import csv
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc_summary.csv')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', PMC_FILE)
     main, extra = PMC_PATTERN.get(kernel_class, (None, None))
     if model_name != 'mobilenetv2-fpn' or main is None or not os.path.exists(path):
         return None
@@ -331,7 +334,7 @@ def main(args, world, rank, local):
         total_ms = sum(v['ms'] for v in prof.values())
         roofline = {'bound': dom['bound'], 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
                     'frac': round(achieved / peak, 4), 'traffic': measured_traffic(dom_name, args.model),
-                    'traffic_unit': 'HBM bytes per launch (profiles/r1_pmc_summary.csv)',
+                    'traffic_unit': 'HBM bytes per launch (profiles/%s)' % PMC_FILE,
                     'algorithmic_per_launch': round((dom['flops'] if dom['bound'] == 'mfma' else dom['bytes']) / dom['launches']),
                     'algorithmic_bytes_per_launch': round(dom['bytes'] / dom['launches']), 'kernel': dom_name,
                     'kernel_avg_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
