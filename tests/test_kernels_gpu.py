@@ -735,7 +735,7 @@ def test_bn_finalize_matches_batchnorm2d():
     close(y.to(DEV) * sc + sh, bn(yin).detach().view(N, Cc), what='eval normalised')
 
 
-@pytest.mark.parametrize('nblk,Cc', [(1, 16), (64, 40), (65, 100), (700, 96), (8192, 24), (5000, 1280)])
+@pytest.mark.parametrize('nblk,Cc', [(1, 16), (64, 40), (65, 100), (700, 96), (4096, 32), (8192, 24), (5000, 1280)])
 def test_bn_finalize_long_partial_lists(nblk, Cc):
     """Several blocks per channel group (ticketed, scratch) give the same sums as one block (no scratch) and as fp64
     math, twice in a row (the tickets re-arm themselves)."""
