@@ -17,6 +17,13 @@ extern "C" const char* pq_last_error(void) { return g_err; }
 extern "C" int pq_last_failed_op(void) { return g_failed_op; }
 extern "C" const char* pq_version(void) { return "pqdet_hip 0.1 (gfx950)"; }
 
+static thread_local hipEvent_t g_stop_event = nullptr;
+hipEvent_t pq_take_stop_event() {
+    hipEvent_t e = g_stop_event;
+    g_stop_event = nullptr;
+    return e;
+}
+
 static int run_one(const pq_op& op, void* stream) {
     switch (op.code) {
         case PQ_OP_CONV1X1_FWD: return pq_conv1x1_fwd(&op.u.c1f, stream);
@@ -57,9 +64,18 @@ static int run_one(const pq_op& op, void* stream) {
 extern "C" int pq_run_ops(const pq_op* ops, int32_t n, void* stream) {
     g_failed_op = -1;
     if (!ops || n < 0) { pq_set_error("pq_run_ops: bad arguments"); return PQ_EINVAL; }
+    // PQ_DEBUG_RECORD=1|2: measurement aid -- an event record after (1) / bound to (2) every BatchNorm-backward finalize, as
+    // the two-stream executor issues them, to price the records alone (scripts/phase_wall.py, "backward 1 stream")
+    static const char* dbg = getenv("PQ_DEBUG_RECORD");
+    static hipEvent_t dbg_ev = nullptr;
+    if (dbg && !dbg_ev && hipEventCreateWithFlags(&dbg_ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) dbg = nullptr;
     for (int i = 0; i < n; ++i) {
+        const bool rec = dbg && ops[i].code == PQ_OP_BN_BWD_FIN;
+        if (rec && dbg[0] == '2') g_stop_event = dbg_ev;
         const int rc = run_one(ops[i], stream);
         if (rc != PQ_OK) { g_failed_op = i; return rc; }
+        if (rec && dbg[0] == '1') (void)hipEventRecord(dbg_ev, (hipStream_t)stream);
+        g_stop_event = nullptr;
     }
     return PQ_OK;
 }
@@ -77,6 +93,11 @@ static unsigned event_flags() {
     static const char* e = getenv("PQ_EVENT_FLAGS");
     const int m = e ? atoi(e) : 2;
     return hipEventDisableTiming | (m == 1 ? hipEventReleaseToDevice : m == 2 ? hipEventDisableSystemFence : 0u);
+}
+// PQ_BIND_EVENTS=0 goes back to a hipEventRecord after the op (A/B timing)
+static bool bind_events() {
+    static const char* e = getenv("PQ_BIND_EVENTS");
+    return !(e && e[0] == '0');
 }
 static int side_group() {
     static int g = -1;
@@ -105,12 +126,15 @@ extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side
     int parked[64];
     int nparked = 0;
     bool used_side = false;
+    hipEvent_t bound = nullptr;          // fork event already bound to the last main-stream kernel (no record needed)
     auto flush = [&]() -> int {          // one fork event, then every parked op in issue order
         if (nparked == 0) return PQ_OK;
-        hipEvent_t e = ev[next]; next = (next + 1) & 63;
-        if (hipEventRecord(e, main_s) != hipSuccess || hipStreamWaitEvent(side_s, e, 0) != hipSuccess) {
+        hipEvent_t e = bound;
+        if (!e) { e = ev[next]; next = (next + 1) & 63; }
+        if ((!bound && hipEventRecord(e, main_s) != hipSuccess) || hipStreamWaitEvent(side_s, e, 0) != hipSuccess) {
             pq_set_error("pq_run_ops2: fork failed"); g_failed_op = parked[0]; return PQ_ELAUNCH;
         }
+        bound = nullptr;
         for (int k = 0; k < nparked; ++k) {
             const int rc = run_one(ops[parked[k]], side_stream);
             if (rc != PQ_OK) { g_failed_op = parked[k]; return rc; }
@@ -119,13 +143,22 @@ extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side
         used_side = true;
         return PQ_OK;
     };
+    const bool bind = bind_events();
     for (int i = 0; i < n; ++i) {
         if (ops[i].flags & PQ_OPF_SIDE) {
             parked[nparked++] = i;
             if (nparked >= group) { const int rc = flush(); if (rc != PQ_OK) return rc; }
             continue;
         }
+        // the op after this one releases the parked group: offer the fork event to this op's kernel launch
+        const bool forks_next = bind && i + 1 < n && (ops[i + 1].flags & PQ_OPF_SIDE) && nparked + 1 >= group;
+        bound = nullptr;
+        if (forks_next) g_stop_event = ev[next];
         const int rc = run_one(ops[i], stream);
+        if (forks_next) {
+            if (g_stop_event == nullptr) { bound = ev[next]; next = (next + 1) & 63; }      // taken: the kernel carries it
+            g_stop_event = nullptr;
+        }
         if (rc != PQ_OK) { g_failed_op = i; return rc; }
     }
     { const int rc = flush(); if (rc != PQ_OK) return rc; }

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of libpqdet_hip.so.  wave = 64 lanes everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/pqdet_hip.h"
 
@@ -261,6 +262,16 @@ inline EwGeom ew_geom(long items, int C) {
 
 // host-side error plumbing (api.hip)
 void pq_set_error(const char* fmt, ...);
+// The two-stream executor (api.hip) can ask the next single-kernel op to BIND its fork event to the kernel dispatch itself
+// (hipExtLaunchKernelGGL stopEvent) instead of recording it afterwards: a separate hipEventRecord is a barrier packet that
+// delays the next kernel of the same queue by 5-8 us.  pq_take_stop_event() returns that event once (nullptr otherwise).
+hipEvent_t pq_take_stop_event();
+#define PQ_LAUNCH_BINDABLE(kernel, grid, block, shmem, st, ...)                                              \
+    do {                                                                                                      \
+        hipEvent_t stop_ = pq_take_stop_event();                                                              \
+        if (stop_) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, nullptr, stop_, 0, __VA_ARGS__);     \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                 \
+    } while (0)
 #define PQ_CHECK_ARG(cond, msg)                         \
     do {                                                \
         if (!(cond)) {                                  \

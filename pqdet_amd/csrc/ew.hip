@@ -404,7 +404,7 @@ extern "C" int pq_bn_eval_batch(const pq_bn_eval_args* a, void* stream) {
 extern "C" int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->partial && a->gamma && a->invstd && a->dgamma && a->dbeta && a->p && a->q && a->r, "null pointer");
     PQ_CHECK_ARG(a->C > 0 && a->nblk > 0 && a->count > 0.f, "empty");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, bn_row_groups(a->nblk, a->scratch && a->tickets)),
+    PQ_LAUNCH_BINDABLE(bn_bwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, bn_row_groups(a->nblk, a->scratch && a->tickets)),
                        dim3(BNF_CH * BNF_RL), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;

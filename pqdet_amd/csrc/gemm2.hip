@@ -20,28 +20,16 @@
 //
 // mirrors: nn.Conv2d(k=1) forward / backward inside the conv blocks of the reference, model/parser.py:389-410.
 #include "common.h"
+#include "ldsdma.h"
 
 namespace pq {
 
-__device__ __forceinline__ void glds16(const void* g, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte) : "memory", "m0");
-}
-__device__ __forceinline__ void glds4(const void* g, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_byte) : "memory", "m0");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 // wait until at most `tiles` k-tiles (NL loads each) of this wave are still in flight; tiles in 0..2
 template <int NL>
 __device__ __forceinline__ void wait_tiles(int tiles) {
     if (tiles >= 2) wait_vmcnt<2 * NL>();
     else if (tiles == 1) wait_vmcnt<NL>();
     else wait_vmcnt<0>();
-}
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }
 __device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 

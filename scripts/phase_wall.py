@@ -75,6 +75,8 @@ if os.environ.get('PER_OP_ALL'):
     for arr, n, tag in ((plan.fwd_arr, nf, 'fwd'), (plan.bwd_arr, nb, 'bwd')):
         for k in range(n):
             code = arr[k].code
+            if os.environ.get('ONLY') and os.environ['ONLY'] not in bench.KERNEL_CLASS.get(code, ('other',))[0]:
+                continue
             a = getattr(arr[k].u, abi.OP_FIELD[code])
             sub = (abi.Op * 1)(arr[k])
             ms = wall(lambda: abi.check(l.pq_run_ops(sub, 1, st)))
@@ -84,5 +86,5 @@ if os.environ.get('PER_OP_ALL'):
             rows.append((ms, tag, k, bench.KERNEL_CLASS.get(code, ('other',))[0][:28], hint, by, fl))
     print('--- every op alone, >= 15 us')
     for ms, tag, k, name, hint, by, fl in sorted(rows, key=lambda r: -r[0]):
-        if ms * 1e3 < 15: break
+        if ms * 1e3 < float(os.environ.get('MIN_US', 15)): break
         print('%s#%-3d %-28s %-70s %7.1f us %6.0f GB/s %5.1f TF' % (tag, k, name, hint, ms * 1e3, by / ms / 1e6, fl / ms / 1e9))
