@@ -31,6 +31,9 @@ __device__ __forceinline__ void wait_tiles(int tiles) {
     else if (tiles == 1) wait_vmcnt<NL>();
     else wait_vmcnt<0>();
 }
+// B operand of the half k-tile at the end of a contraction that is 16 modulo 32 (see gemm2_nt_kernel)
+__device__ __attribute__((aligned(16))) float g2_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 struct G2P {
@@ -45,7 +48,9 @@ struct G2P {
 };
 
 // AMODE 0: A as stored; 1: clamp(c0*a + c1, lo, hi); 2: c0*g + c1*(y - c2) + c3.   EMODE 0: store(+bias); 1: + statistics;
-// 2: gradient sink (16-byte rows only: the host checks alignment).   K % 32 == 0.
+// 2: gradient sink (16-byte rows only: the host checks alignment).   K % 32 == 0, or K % 32 == 16 (RegNetX widths 48 / 80 /
+// 176 / 240 / 528): the last k-tile is then half valid -- its upper four chunks of B come from g2_zero, those of A and of the
+// coefficient vectors repeat the lower four (finite values times zero), so the loop itself is unchanged.
 template <int BM, int BN, int AMODE, int EMODE, int S>
 __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
@@ -68,18 +73,21 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
     xcd_block(bnx, bmy);
     const int m0 = bmy * BM, n0 = bnx * BN;
     const int M = p.M, N = p.N, K = p.K;
-    const int nk = K / 32;
+    const int nk = (K + 31) / 32;
+    const bool tail = (K & 31) != 0;
 
     // ---- source pointers of this lane's share of a k-tile (advanced by 32 floats per issued tile)
     const float* pa[NA][PA];
     const float* pb[PB];
     const float* pc[NC > 0 ? NC : 1];
+    unsigned hiA = 0, hiB = 0;                    // bit q: this lane's chunk of piece q is one of the upper four of a k-tile
     {
         const int sl = lane & 7;
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
             const int r = 8 * (w * PA + q) + (lane >> 3);
             const int c = sl ^ ((r >> 1) & 7);
+            if (c >= 4) hiA |= 1u << q;
             const size_t row = (size_t)min(m0 + r, M - 1);
             pa[0][q] = p.a0 + row * (size_t)p.lda0 + 4 * c;
             if (AMODE == 2) pa[NA - 1][q] = p.a1 + row * (size_t)p.lda1 + 4 * c;
@@ -88,29 +96,34 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
         for (int q = 0; q < PB; ++q) {
             const int r = 8 * (w * PB + q) + (lane >> 3);
             const int c = sl ^ ((r >> 1) & 7);
+            if (c >= 4) hiB |= 1u << q;
             pb[q] = p.b + (size_t)min(n0 + r, N - 1) * (size_t)p.ldb + 4 * c;
         }
         if (AMODE == 1) pc[0] = (lane < 32 ? p.c0 : p.c1) + (lane & 31);
         if (AMODE == 2) { pc[0] = (lane < 32 ? p.c0 : p.c1) + (lane & 31); pc[NC - 1] = (lane < 32 ? p.c2 : p.c3) + (lane & 31); }
     }
     const unsigned lbase = lds_addr(lds);
-    auto issue = [&](int s) {
+    auto issue = [&](int s, int t) {              // k-tile t into stage s
         const unsigned sb = lbase + (unsigned)(s * STAGE) * 4u;
+        const bool half = tail && t == nk - 1;    // uniform
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int q = 0; q < PA; ++q) {
-                glds16(pa[a][q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(a * A_FL + (w * PA + q) * 256) * 4u));
+                const float* src = pa[a][q] - ((half && ((hiA >> q) & 1u)) ? 16 : 0);
+                glds16(src, __builtin_amdgcn_readfirstlane(sb + (unsigned)(a * A_FL + (w * PA + q) * 256) * 4u));
                 pa[a][q] += 32;
             }
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
-            glds16(pb[q], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NA * A_FL + (w * PB + q) * 256) * 4u));
+            const float* src = (half && ((hiB >> q) & 1u)) ? g2_zero : pb[q];
+            glds16(src, __builtin_amdgcn_readfirstlane(sb + (unsigned)(NA * A_FL + (w * PB + q) * 256) * 4u));
             pb[q] += 32;
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            glds4(pc[c], __builtin_amdgcn_readfirstlane(sb + (unsigned)(NA * A_FL + B_FL + w * CW + 64 * c) * 4u));
+            const float* src = pc[c] - ((half && (lane & 16)) ? 16 : 0);
+            glds4(src, __builtin_amdgcn_readfirstlane(sb + (unsigned)(NA * A_FL + B_FL + w * CW + 64 * c) * 4u));
             pc[c] += 32;
         }
     };
@@ -179,12 +192,12 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
     // ---- main loop: ring of S stages, D tiles in flight
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (d < nk) issue(d);
+        if (d < nk) issue(d, d);
     for (int kt = 0; kt < nk; ++kt) {
         const int issued = min(nk, kt + D);
         wait_tiles<NL>(issued - kt - 1);
         __builtin_amdgcn_s_barrier();
-        if (kt + D < nk) issue((kt + D) % S);
+        if (kt + D < nk) issue((kt + D) % S, kt + D);
         compute(kt % S);
     }
     __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring: it becomes epilogue scratch
@@ -555,7 +568,7 @@ static bool act_clamp(int act, float& lo, float& hi) {
 // returns 1 when the launch was taken, 0 when the shape / operands are outside this kernel family (caller falls back),
 // < 0 on error
 int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st) {
-    if (!g2_enabled() || a->sub > 1 || a->in.qstate || (a->I & 31) || a->I < 128 || a->O < 64) return 0;
+    if (!g2_enabled() || a->sub > 1 || a->in.qstate || (a->I & 15) || a->I < 128 || a->O < 64) return 0;
     if ((a->in.ld & 3) || (((uintptr_t)a->in.x) & 15) || (((uintptr_t)a->w) & 15)) return 0;
     G2P p{};
     if (!act_clamp(a->in.act, p.lo, p.hi)) return 0;
@@ -571,7 +584,7 @@ int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st) {
 }
 
 int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st) {
-    if (!g2_enabled() || a->sub > 1 || !a->wt || (a->O & 31) || a->O < 64 || a->I < 64 || a->dx.qstate) return 0;
+    if (!g2_enabled() || a->sub > 1 || !a->wt || (a->O & 15) || a->O < 64 || a->I < 64 || a->dx.qstate) return 0;
     const pq_gsink& sk = a->dx;
     const bool stats = sk.mean != nullptr && sk.partial != nullptr;
     const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
@@ -580,7 +593,7 @@ int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st) {
     G2P p{};
     p.a0 = a->dy.g; p.a1 = a->dy.y; p.lda0 = a->dy.ldg; p.lda1 = a->dy.ldy;
     p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
-    p.b = a->wt; p.ldb = a->O; p.M = a->M; p.N = a->I; p.K = a->O;      // O % 32 == 0: the transposed rows have no pad
+    p.b = a->wt; p.ldb = a->O; p.M = a->M; p.N = a->I; p.K = a->O;      // O % 16 == 0: the transposed rows have no pad
     p.sink = a->dx;
     const int rc = a->dy.y ? g2_dispatch_nt<2, 2>(p, bm, st) : g2_dispatch_nt<0, 2>(p, bm, st);
     return rc == PQ_OK ? 1 : rc;

@@ -77,6 +77,9 @@ def reduce_partial(partial, nblk, ldp, C_):
     (4096, 512, 256, 2, True, False, True),       # few tiles, long contraction (LDS-DMA ring kernels)
     (4096, 1024, 75, 2, True, True, False),
     (4000, 960, 160, 0, False, False, True),
+    (4096, 528, 528, 2, True, False, True),       # contraction 16 modulo 32 (RegNetX widths): half k-tile at the end
+    (1000, 240, 240, 1, True, True, True),
+    (515, 176, 80, 0, False, False, True),        # ... with the raw operand (no transform to hide behind)
 ])
 def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
     g = torch.Generator().manual_seed(M + I + O)
@@ -153,6 +156,9 @@ def _bn_bwd_coeffs(g_, y, gamma, eps=1e-5):
     (130, 96, 576, True, 0, True, False),
     (4096, 160, 960, True, 2, False, True),       # split-K shapes
     (4000, 320, 1280, True, 0, True, True),
+    (4096, 528, 528, True, 2, False, True),       # contraction (O) 16 modulo 32
+    (1000, 240, 80, True, 0, True, True),
+    (515, 176, 240, False, 1, False, True),       # ... one-tensor gradient operand
 ])
 def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
     g = torch.Generator().manual_seed(M + I + O + 1)
