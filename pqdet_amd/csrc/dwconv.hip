@@ -476,6 +476,40 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemP p) {
     if (p.partial) block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, lds, bx);
 }
 
+// Image patch [CI][PH][PW] of an LDS-tiled stem kernel: thread `tid` stages elements e = tid + u * nthr, u < NE.  Which (channel,
+// row, column) of the patch an element is does not depend on the tile, so it is decoded once (three integer divisions per element
+// were 40 % of the VALU instructions of these kernels); per tile only the clamped address and the bounds test remain.
+template <int NE> struct StemPatch {
+    int dst[NE];          // LDS offset in the padded patch; -1 beyond the patch
+    int pyx[NE];          // row << 16 | column inside the patch
+    int cio[NE];          // channel * IH * IW
+    __device__ __forceinline__ void init(int tid, int nthr, int CI, int PH, int PW, int PWp, int IH, int IW) {
+        const int npatch = CI * PH * PW;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + u * nthr, ec = min(e, npatch - 1);
+            const int ci = ec / (PH * PW), rem = ec - ci * PH * PW;
+            const int py = rem / PW, px = rem - py * PW;
+            dst[u] = e < npatch ? (ci * PH + py) * PWp + px : -1;
+            pyx[u] = (py << 16) | px;
+            cio[u] = ci * IH * IW;
+        }
+    }
+    __device__ __forceinline__ void stage(const float* img, int iy0, int ix0, int IH, int IW, float* patch) const {
+        float v[NE];
+        bool ok[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int iy = iy0 + (pyx[u] >> 16), ix = ix0 + (pyx[u] & 0xffff);
+            ok[u] = iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+            v[u] = img[cio[u] + min(max(iy, 0), IH - 1) * IW + min(max(ix, 0), IW - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u)
+            if (dst[u] >= 0) patch[dst[u]] = ok[u] ? v[u] : 0.f;
+    }
+};
+
 // LDS-tiled forward: a workgroup walks 4x32-pixel output tiles (tile = bx, bx + gridDim.x, ...; one statistics row per
 // workgroup as before), stages the CI x PH x PW image patch once with coalesced row loads and every lane reads its 27
 // taps from LDS (the 8 channel-quad lanes of a pixel hit the same word: broadcast).  The streaming version above issued 27
@@ -502,31 +536,15 @@ __global__ __launch_bounds__(256) void stem_fwd_tiled_kernel(StemP p) {
     }
     const int tilesH = (p.OH + TH - 1) / TH, tilesW = (p.OW + TW - 1) / TW, ntiles = p.B * tilesH * tilesW;
     const int tid = ty * blockDim.x + tx, nthr = blockDim.x * blockDim.y;
-    const int npatch = CI * PH * PW;
+    StemPatch<8> sp;
+    sp.init(tid, nthr, CI, PH, PW, PWp, p.IH, p.IW);
     float4 s1 = f4zero(), s2 = f4zero();
     for (int tile = bx; tile < ntiles; tile += gridDim.x) {
         const int tw = tile % tilesW, th = (tile / tilesW) % tilesH, b = tile / (tilesW * tilesH);
         const int oy0 = th * TH, ox0 = tw * TW;
         const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
         __syncthreads();                                // the previous tile's taps have been read
-        for (int e0 = tid; e0 < npatch; e0 += 4 * nthr) {
-            float v[4];
-            int dst[4];
-            bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + u * nthr, npatch - 1);
-                const int ci = e / (PH * PW), rem = e - ci * PH * PW;
-                const int py = rem / PW, px = rem - py * PW;
-                const int iy = iy0 + py, ix = ix0 + px;
-                ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                dst[u] = (ci * PH + py) * PWp + px;
-                v[u] = p.img[(((size_t)b * CI + ci) * p.IH + min(max(iy, 0), p.IH - 1)) * p.IW + min(max(ix, 0), p.IW - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (e0 + u * nthr < npatch) patch[dst[u]] = ok[u] ? v[u] : 0.f;
-        }
+        sp.stage(p.img + (size_t)b * CI * p.IH * p.IW, iy0, ix0, p.IH, p.IW, patch);
         __syncthreads();
         if (cok) {
             for (int pi = ty; pi < TH * TW; pi += blockDim.y) {
@@ -644,40 +662,39 @@ __global__ __launch_bounds__(256) void stem_wgrad_tiled_kernel(StemP p) {
     for (int t = 0; t < CI * 9; ++t) acc[t] = f4zero();
     const int tilesH = (p.OH + TH - 1) / TH, tilesW = (p.OW + TW - 1) / TW, ntiles = p.B * tilesH * tilesW;
     const int tid = ty * nx + tx, nthr = nx * ny;
-    const int npatch = CI * PH * PW;
+    StemPatch<8> sp;
+    sp.init(tid, nthr, CI, PH, PW, PWp, p.IH, p.IW);
     for (int tile = bx; tile < ntiles; tile += gridDim.x) {
         const int tw = tile % tilesW, th = (tile / tilesW) % tilesH, b = tile / (tilesW * tilesH);
         const int oy0 = th * TH, ox0 = tw * TW;
         const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-        __syncthreads();
-        for (int e0 = tid; e0 < npatch; e0 += 4 * nthr) {
-            float v[4];
-            int dst[4];
-            bool ok[4];
+        // the gradient operands of this lane's first NPX pixels are requested BEFORE the patch is staged: their latency then
+        // overlaps the patch loads (the kernel was one exposed load latency per pixel: 136 us for 318 MB)
+        constexpr int NPX = 4;
+        float4 gq[NPX], yq[NPX];
+        auto fetch = [&](int pi0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + u * nthr, npatch - 1);
-                const int ci = e / (PH * PW), rem = e - ci * PH * PW;
-                const int py = rem / PW, px = rem - py * PW;
-                const int iy = iy0 + py, ix = ix0 + px;
-                ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                dst[u] = (ci * PH + py) * PWp + px;
-                v[u] = p.img[(((size_t)b * CI + ci) * p.IH + min(max(iy, 0), p.IH - 1)) * p.IW + min(max(ix, 0), p.IW - 1)];
+            for (int u = 0; u < NPX; ++u) {
+                const int pi = min(pi0 + u * ny, TH * TW - 1);
+                const int oyl = pi / TW, oxl = pi - oyl * TW;
+                const size_t row = ((size_t)b * p.OH + min(oy0 + oyl, p.OH - 1)) * p.OW + min(ox0 + oxl, p.OW - 1);
+                gq[u] = ldg4(p.dy.g + row * p.dy.ldg + (cok ? c0 : 0));
+                yq[u] = gk.two ? ldg4(p.dy.y + row * p.dy.ldy + (cok ? c0 : 0)) : f4zero();
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (e0 + u * nthr < npatch) patch[dst[u]] = ok[u] ? v[u] : 0.f;
-        }
+        };
+        fetch(ty);
         __syncthreads();
-        if (cok) {
-            for (int pi = ty; pi < TH * TW; pi += ny) {
+        sp.stage(p.img + (size_t)b * CI * p.IH * p.IW, iy0, ix0, p.IH, p.IW, patch);
+        __syncthreads();
+        for (int pi0 = ty; pi0 < TH * TW; pi0 += NPX * ny) {
+            if (pi0 != ty) fetch(pi0);                  // wide outputs (O > 32): fewer pixel lanes, more rounds
+#pragma unroll
+            for (int u = 0; u < NPX; ++u) {
+                const int pi = pi0 + u * ny;
                 const int oyl = pi / TW, oxl = pi - oyl * TW;
                 const int oy = oy0 + oyl, ox = ox0 + oxl;
-                if (oy < p.OH && ox < p.OW) {
-                    const size_t row = ((size_t)b * p.OH + oy) * p.OW + ox;
-                    const float4 g = ldg4(p.dy.g + row * p.dy.ldg + c0);
-                    const float4 y = gk.two ? ldg4(p.dy.y + row * p.dy.ldy + c0) : f4zero();
-                    const float4 dy = gsrc_apply4(g, y, gk);
+                if (cok && pi < TH * TW && oy < p.OH && ox < p.OW) {
+                    const float4 dy = gsrc_apply4(gq[u], yq[u], gk);
                     const float* pp = patch + (oyl * S) * PWp + oxl * S;
 #pragma unroll
                     for (int ci = 0; ci < CI; ++ci)
@@ -822,7 +839,8 @@ extern "C" int pq_stem3x3_fwd(const pq_stem3x3_fwd_args* a, void* stream) {
     EwGeom g = ew_geom((long)a->B * a->OH * a->OW, a->O);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     static const char* senv = getenv("PQ_STEM");                  // "stream": the per-pixel global-load version (A/B timing)
-    if (senv && senv[0] == 's') {
+    const int npatch_f = 3 * (3 * a->stride + 3) * (31 * a->stride + 3);
+    if ((senv && senv[0] == 's') || npatch_f > 8 * g.cx * g.py) {
         hipLaunchKernelGGL((stem_fwd_kernel<3>), grid, blk, (size_t)g.cx * g.py * 8 * sizeof(float), (hipStream_t)stream, p);
     } else {
         const int PH = 3 * a->stride + 3, PW = 31 * a->stride + 3;
@@ -854,7 +872,8 @@ extern "C" int pq_stem3x3_wgrad(const pq_stem3x3_wgrad_args* a, void* stream) {
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     hipStream_t st = (hipStream_t)stream;
     static const char* senv = getenv("PQ_STEM");                  // "stream": the per-pixel global-load version (A/B timing)
-    if (senv && senv[0] == 's') {
+    const int npatch_w = 3 * (3 * a->stride + 3) * (31 * a->stride + 3);
+    if ((senv && senv[0] == 's') || npatch_w > 8 * g.cx * g.py) {
         hipLaunchKernelGGL((stem_wgrad_kernel<3>), grid, blk, (size_t)g.cx * g.py * 4 * sizeof(float), st, p);
     } else {
         const int PH = 3 * a->stride + 3, PW = 31 * a->stride + 3;
