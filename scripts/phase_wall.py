@@ -11,6 +11,8 @@ from pqdet_amd.model.interpreter import DetectionModel
 B, S = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 torch.manual_seed(0)
+if os.environ.get('OWN_STREAM'):          # a non-default stream (stream capture refuses the legacy default stream)
+    torch.cuda.set_stream(torch.cuda.Stream())
 model = DetectionModel(io.StringIO(zoo.cfg_text(os.environ.get('MODEL', 'mobilenetv2-fpn')))).cuda(); model.train()
 x = torch.randn(B, 3, S, S).cuda()
 tgt = tuple(t.cuda() for t in labels.synthetic_targets(B, S, 20, seed=1))
