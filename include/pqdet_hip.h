@@ -91,9 +91,12 @@ typedef struct pq_conv1x1_fwd_args {
     const float* w;      /* [O][I] */
     const float* bias;   /* [O] or NULL */
     float* out;          /* [M][ldo] raw */
-    float* partial;      /* [pq_conv1x1_blocks_k(M, O, I, 0)][2][ldp] or NULL */
+    float* partial;      /* [pq_conv1x1_blocks_k(M, O, I, 0)][2][ldp] or NULL ([..][4][ldp] with minmax) */
     int32_t M, I, O, ldo, ldp;
     int32_t sub, OH, OW, IH, IW;   /* sub==1: plain; else strided gather of input rows */
+    int32_t minmax;      /* != 0: `partial` rows have 4 planes: sum, sum of squares, per-channel MIN and MAX of the outputs of the
+                          * row block (QAT: pq_bn_fwd_finalize turns them into the activation observer's update, no pass over
+                          * the tensor) */
 } pq_conv1x1_fwd_args;
 int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream);
 /* row-blocks (partial-sum rows) a GEMM with M rows and N output columns uses: fwd N=O, dgrad sink N=I */
@@ -154,8 +157,9 @@ typedef struct pq_dw3x3_fwd_args {
     pq_src in;
     const float* w;
     float* out;          /* raw, pitch ldo */
-    float* partial;      /* [nblk][2][ldp] or NULL; nblk = pq_dw3x3_fwd_blocks(B, OH, OW, C, stride) */
+    float* partial;      /* [nblk][2][ldp] or NULL; nblk = pq_dw3x3_fwd_blocks(B, OH, OW, C, stride); [nblk][4][ldp] with minmax */
     int32_t B, IH, IW, OH, OW, C, stride, ldo, ldp;
+    int32_t minmax;      /* as in pq_conv1x1_fwd_args */
 } pq_dw3x3_fwd_args;
 int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream);
 int32_t pq_dw3x3_fwd_blocks(int32_t B, int32_t OH, int32_t OW, int32_t C, int32_t stride);   /* statistics rows written by pq_dw3x3_fwd */
@@ -243,6 +247,7 @@ typedef struct pq_stem3x3_fwd_args {
     float* out;          /* NHWC raw, pitch ldo */
     float* partial;
     int32_t B, CI, IH, IW, OH, OW, O, stride, ldo, ldp;
+    int32_t minmax;      /* as in pq_conv1x1_fwd_args */
 } pq_stem3x3_fwd_args;
 int pq_stem3x3_fwd(const pq_stem3x3_fwd_args* a, void* stream);
 
@@ -275,6 +280,15 @@ typedef struct pq_bn_fwd_finalize_args {
     double* scratch;        /* >= pq_bn_finalize_scratch_bytes(C), or NULL: one block per 64 channels walks all rows */
     uint32_t* tickets;      /* pq_bn_finalize_tickets(C) counters, zero before the first use (self re-arming), or NULL */
     const float* sf;        /* QAT (fused conv-BN): the conv ran with weights scaled by sf[c]; BatchNorm acts on out/sf.  NULL otherwise */
+    /* QAT, activation observer folded into the finalize (train only): `partial` rows have 4 planes (the producer ran with
+     * minmax != 0); the per-channel extremes of act(scale*raw + shift) follow from the raw ones (monotone per channel), the
+     * tensor's min / max go into the moving-average observer `qstate` = {min, max, scale, zero_point} exactly as
+     * pq_qact_fwd(out == NULL) would after a pass over the tensor.  planes == 0 means 2. */
+    int32_t planes;         /* 2 | 4 */
+    int32_t act;            /* activation of the tensor (PQ_ACT_*) */
+    float* qstate;          /* observer state to update, or NULL */
+    uint32_t* mm;           /* 3 words {0xffffffff, 0, 0} before the first use (self re-arming) */
+    float avg_const;        /* moving-average constant (0.01) */
 } pq_bn_fwd_finalize_args;
 int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream);
 

@@ -38,7 +38,7 @@ class GSink(C.Structure):
 class Conv1x1Fwd(C.Structure):
     _fields_ = [('inp', Src), ('w', c_fp), ('bias', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('M', i32), ('I', i32), ('O', i32), ('ldo', i32), ('ldp', i32),
-                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32)]
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('minmax', i32)]
 
 
 class Conv1x1Dgrad(C.Structure):
@@ -76,7 +76,7 @@ class GconvWgrad(C.Structure):
 class DwFwd(C.Structure):
     _fields_ = [('inp', Src), ('w', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('stride', i32),
-                ('ldo', i32), ('ldp', i32)]
+                ('ldo', i32), ('ldp', i32), ('minmax', i32)]
 
 
 class DwDgrad(C.Structure):
@@ -97,7 +97,7 @@ class DwBwd(C.Structure):
 class StemFwd(C.Structure):
     _fields_ = [('image', c_fp), ('w', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('B', i32), ('CI', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('O', i32),
-                ('stride', i32), ('ldo', i32), ('ldp', i32)]
+                ('stride', i32), ('ldo', i32), ('ldp', i32), ('minmax', i32)]
 
 
 class StemWgrad(C.Structure):
@@ -109,7 +109,8 @@ class BnFwdFin(C.Structure):
     _fields_ = [('partial', c_fp), ('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp),
                 ('num_batches_tracked', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp), ('shift', c_fp),
                 ('nblk', i32), ('ldp', i32), ('C', i32), ('train', i32), ('count', f32), ('eps', f32), ('momentum', f32),
-                ('scratch', c_fp), ('tickets', c_fp), ('sf', c_fp)]
+                ('scratch', c_fp), ('tickets', c_fp), ('sf', c_fp),
+                ('planes', i32), ('act', i32), ('qstate', c_fp), ('mm', c_fp), ('avg_const', f32)]
 
 
 class BnEvalItem(C.Structure):

@@ -209,9 +209,11 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by) {
 // ---- 2-D thread layout used by the NHWC elementwise / depthwise kernels ----------------------------------------
 // blockDim = (CX, PY): CX lanes walk channel quads (float4), PY walks rows / pixel groups.
 // Reduce two float4 accumulators over threadIdx.y and store to partial[bx][0|1][ldp] (bx = logical row-block).
+// planes = 2 (sum, sum of squares) or 4 (+ per-channel min, max of the stored values: QAT observers, written by
+// block_reduce_store_minmax): the row pitch of `partial` is planes * ldp.
 template <int MAXT>
 __device__ __forceinline__ void block_reduce_store_stats(float4 s1, float4 s2, float* partial, int ldp, int c0, int C,
-                                                         float* lds /* >= MAXT*8 floats */, int bx) {
+                                                         float* lds /* >= MAXT*8 floats */, int bx, int planes = 2) {
     const int tx = threadIdx.x, ty = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
     float* slot = lds + (size_t)(ty * nx + tx) * 8;
     slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
@@ -226,12 +228,39 @@ __device__ __forceinline__ void block_reduce_store_stats(float4 s1, float4 s2, f
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += o[j];
         }
-        float* dst = partial + (size_t)bx * 2 * ldp;
+        float* dst = partial + (size_t)bx * planes * ldp;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (c0 + j < C) { dst[c0 + j] = acc[j]; dst[ldp + c0 + j] = acc[4 + j]; }
     }
 }
+// same layout, planes 2 / 3 of a 4-plane row: per-channel minimum / maximum over the block (call after the sums: it reuses lds)
+template <int MAXT>
+__device__ __forceinline__ void block_reduce_store_minmax(float4 mn, float4 mx, float* partial, int ldp, int c0, int C,
+                                                          float* lds /* >= MAXT*8 floats */, int bx) {
+    const int tx = threadIdx.x, ty = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
+    __syncthreads();
+    float* slot = lds + (size_t)(ty * nx + tx) * 8;
+    slot[0] = mn.x; slot[1] = mn.y; slot[2] = mn.z; slot[3] = mn.w;
+    slot[4] = mx.x; slot[5] = mx.y; slot[6] = mx.z; slot[7] = mx.w;
+    __syncthreads();
+    if (ty == 0 && c0 < C) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] = __builtin_huge_valf(); acc[4 + j] = -__builtin_huge_valf(); }
+        for (int y = 0; y < ny; ++y) {
+            const float* o = lds + (size_t)(y * nx + tx) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] = fminf(acc[j], o[j]); acc[4 + j] = fmaxf(acc[4 + j], o[4 + j]); }
+        }
+        float* dst = partial + (size_t)bx * 4 * ldp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < C) { dst[2 * ldp + c0 + j] = acc[j]; dst[3 * ldp + c0 + j] = acc[4 + j]; }
+    }
+}
+__device__ __forceinline__ float4 f4min(float4 a, float4 b) { return make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)); }
+__device__ __forceinline__ float4 f4max(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
 
 // Largest divisor of c4 that is <= 64 (channel-quad lanes per block row).
 inline int pick_cx(int c4) {

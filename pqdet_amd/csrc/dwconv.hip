@@ -18,6 +18,7 @@ struct DwP {
     pq_gsink sink;
     int B, IH, IW, OH, OW, C, C4;
     float* wpartial;  // wgrad: [gridDim.x][C][9]
+    int minmax;       // forward: `partial` rows have 4 planes (+ per-channel min, max of the outputs)
 };
 
 __device__ __forceinline__ void load_w9(const float* w, int c0, int C, float4 (&wk)[9], bool flip) {
@@ -50,6 +51,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
     const GsrcCoef4 gk = gsrc_coef4(p.dy, c0, p.C);
     const SinkCoef4 sk = sink_coef4(p.sink, c0, p.C);
     float4 s1 = f4zero(), s2 = f4zero();
+    const float inf = __builtin_huge_valf();
+    float4 mn = make_float4(inf, inf, inf, inf), mx = make_float4(-inf, -inf, -inf, -inf);
+    const bool mm = !GRAD && p.minmax != 0;
 
     for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int oxg = (int)(it % OWG);
@@ -102,11 +106,13 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
                 stg4(p.out + (orow + t) * p.ldo + c0, acc[t]);
                 s1 = f4add(s1, acc[t]);
                 s2 = f4fma(acc[t], acc[t], s2);
+                if (mm) { mn = f4min(mn, acc[t]); mx = f4max(mx, acc[t]); }
             }
         }
     }
     float* part = GRAD ? ((p.sink.finalize && p.sink.mean) ? p.sink.partial : nullptr) : p.partial;
-    if (part) block_reduce_store_stats<256>(s1, s2, part, GRAD ? p.sink.ldp : p.ldp, c0, p.C, lds, bx);
+    if (part) block_reduce_store_stats<256>(s1, s2, part, GRAD ? p.sink.ldp : p.ldp, c0, p.C, lds, bx, mm ? 4 : 2);
+    if (part && mm) block_reduce_store_minmax<256>(mn, mx, part, p.ldp, c0, p.C, lds, bx);
 }
 
 // ---- dgrad, generic stride (used for stride 2): one input pixel per thread step, predicated taps.
@@ -415,6 +421,7 @@ struct StemP {
     const float* img; const float* w; float* out; float* partial;
     pq_gsrc dy; float* wpartial;
     int B, CI, IH, IW, OH, OW, O, O4, S, ldo, ldp;
+    int minmax;       // forward: `partial` rows have 4 planes (+ per-channel min, max of the outputs)
 };
 
 template <int CI>
@@ -436,6 +443,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemP p) {
     const int items = p.B * p.OH * p.OW;
     const size_t plane = (size_t)p.IH * p.IW;
     float4 s1 = f4zero(), s2 = f4zero();
+    const float inf = __builtin_huge_valf();
+    float4 mn = make_float4(inf, inf, inf, inf), mx = make_float4(-inf, -inf, -inf, -inf);
     for (int it = bx * blockDim.y + ty; it < items && cok; it += gridDim.x * blockDim.y) {
         const int ox = (int)(it % p.OW);
         const int t2 = it / p.OW;
@@ -472,8 +481,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemP p) {
         stg4(p.out + (size_t)it * p.ldo + c0, acc);
         s1 = f4add(s1, acc);
         s2 = f4fma(acc, acc, s2);
+        if (p.minmax) { mn = f4min(mn, acc); mx = f4max(mx, acc); }
     }
-    if (p.partial) block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, lds, bx);
+    if (p.partial) block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, lds, bx, p.minmax ? 4 : 2);
+    if (p.partial && p.minmax) block_reduce_store_minmax<256>(mn, mx, p.partial, p.ldp, c0, p.O, lds, bx);
 }
 
 // Image patch [CI][PH][PW] of an LDS-tiled stem kernel: thread `tid` stages elements e = tid + u * nthr, u < NE.  Which (channel,
@@ -539,6 +550,8 @@ __global__ __launch_bounds__(256) void stem_fwd_tiled_kernel(StemP p) {
     StemPatch<8> sp;
     sp.init(tid, nthr, CI, PH, PW, PWp, p.IH, p.IW);
     float4 s1 = f4zero(), s2 = f4zero();
+    const float inf = __builtin_huge_valf();
+    float4 mn = make_float4(inf, inf, inf, inf), mx = make_float4(-inf, -inf, -inf, -inf);
     for (int tile = bx; tile < ntiles; tile += gridDim.x) {
         const int tw = tile % tilesW, th = (tile / tilesW) % tilesH, b = tile / (tilesW * tilesH);
         const int oy0 = th * TH, ox0 = tw * TW;
@@ -565,13 +578,15 @@ __global__ __launch_bounds__(256) void stem_fwd_tiled_kernel(StemP p) {
                     stg4(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.ldo + c0, acc);
                     s1 = f4add(s1, acc);
                     s2 = f4fma(acc, acc, s2);
+                    if (p.minmax) { mn = f4min(mn, acc); mx = f4max(mx, acc); }
                 }
             }
         }
     }
     if (p.partial) {
         __syncthreads();
-        block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, red, bx);
+        block_reduce_store_stats<256>(s1, s2, p.partial, p.ldp, c0, p.O, red, bx, p.minmax ? 4 : 2);
+        if (p.minmax) block_reduce_store_minmax<256>(mn, mx, p.partial, p.ldp, c0, p.O, red, bx);
     }
 }
 
@@ -751,6 +766,7 @@ int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream) {
     DwP p{};
     p.in = a->in; p.w = a->w; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
+    p.minmax = (a->partial && a->minmax) ? 1 : 0;
     EwGeom g = ew_geom((long)a->B * a->OH * a->OW, a->C);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     size_t sh = (size_t)g.cx * g.py * 8 * sizeof(float);
@@ -835,7 +851,7 @@ extern "C" int pq_stem3x3_fwd(const pq_stem3x3_fwd_args* a, void* stream) {
     StemP p{};
     p.img = a->image; p.w = a->w; p.out = a->out; p.partial = a->partial;
     p.B = a->B; p.CI = a->CI; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.O = a->O; p.O4 = (a->O + 3) / 4;
-    p.S = a->stride; p.ldo = a->ldo; p.ldp = a->ldp;
+    p.S = a->stride; p.ldo = a->ldo; p.ldp = a->ldp; p.minmax = (a->partial && a->minmax) ? 1 : 0;
     EwGeom g = ew_geom((long)a->B * a->OH * a->OW, a->O);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     static const char* senv = getenv("PQ_STEM");                  // "stream": the per-pixel global-load version (A/B timing)

@@ -32,6 +32,7 @@ struct DwTP {
     float* out; float* partial; int ldo, ldp;
     pq_gsink sink; float* wpartial;
     int B, IH, IW, OH, OW, C, C4, tilesH, tilesW;
+    int minmax;       // forward: `partial` rows have 4 planes (+ per-channel min, max of the outputs)
 };
 
 __device__ __forceinline__ float4 lds_px(const float4* tile, int pix, int q) { return tile[pix * PQP + q]; }
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
             }
     }
     float4 s1 = f4zero(), s2 = f4zero();
+    const float inf = __builtin_huge_valf();
+    float4 mn = make_float4(inf, inf, inf, inf), mx = make_float4(-inf, -inf, -inf, -inf);
     const int oy = oy0 + orow;
 #pragma unroll
     for (int u = 0; u < T::TW; ++u) {
@@ -115,9 +118,11 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
             stg4(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.ldo + c0, acc[u]);
             s1 = f4add(s1, acc[u]);
             s2 = f4fma(acc[u], acc[u], s2);
+            mn = f4min(mn, acc[u]); mx = f4max(mx, acc[u]);
         }
     }
     if (p.partial) {      // uniform
+        const int planes = p.minmax ? 4 : 2;
         float* slot = red + (pl * 8 + q) * 8;
         slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
         slot[4] = s2.x; slot[5] = s2.y; slot[6] = s2.z; slot[7] = s2.w;
@@ -128,7 +133,21 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
             const int c = (cq0 + qq) * 4 + (comp & 3);
-            if (c < p.C) p.partial[(size_t)tIdx * 2 * p.ldp + (comp >> 2) * p.ldp + c] = a;
+            if (c < p.C) p.partial[(size_t)tIdx * planes * p.ldp + (comp >> 2) * p.ldp + c] = a;
+        }
+        if (p.minmax) {   // planes 2 / 3: per-channel extremes of the tile (QAT observers)
+            __syncthreads();
+            slot[0] = mn.x; slot[1] = mn.y; slot[2] = mn.z; slot[3] = mn.w;
+            slot[4] = mx.x; slot[5] = mx.y; slot[6] = mx.z; slot[7] = mx.w;
+            __syncthreads();
+            if (t < 64) {
+                const int qq = t >> 3, comp = t & 7;
+                float a = comp < 4 ? inf : -inf;
+#pragma unroll
+                for (int l = 0; l < 32; ++l) { const float v = red[(l * 8 + qq) * 8 + comp]; a = comp < 4 ? fminf(a, v) : fmaxf(a, v); }
+                const int c = (cq0 + qq) * 4 + (comp & 3);
+                if (c < p.C) p.partial[(size_t)tIdx * 4 * p.ldp + (2 + (comp >> 2)) * p.ldp + c] = a;
+            }
         }
     }
 }
@@ -629,6 +648,7 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     DwTP p{};
     p.in = a->in; p.w = a->w; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
+    p.minmax = (a->partial && a->minmax) ? 1 : 0;
     fwd_tiles(a->OH, a->OW, a->stride, p.tilesH, p.tilesW);
     dim3 grid(a->B * p.tilesH * p.tilesW, (p.C4 + CBQ - 1) / CBQ), blk(256);
     hipStream_t st = (hipStream_t)stream;

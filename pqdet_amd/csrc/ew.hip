@@ -1,6 +1,7 @@
 // Elementwise / reduction kernels: BatchNorm statistics finalisation (fwd + bwd), shortcut / route / upsample
 // forward copy and backward routing, Adam, fill.  All HBM-bound; float4 per lane, rows contiguous across lanes.
 #include "common.h"
+#include "qatmath.h"
 
 namespace pq {
 
@@ -14,7 +15,7 @@ namespace pq {
 constexpr int BNF_CH = 16, BNF_RL = 16, BNF_UNROLL = 8, BNF_MAXR = 64;
 
 __device__ __forceinline__ bool bn_reduce_partials(const float* partial, int nblk, int ldp, int C, double* scratch,
-                                                    unsigned* tickets, double& t1, double& t2) {
+                                                    unsigned* tickets, double& t1, double& t2, int planes = 2) {
     __shared__ double sh[2][BNF_RL][BNF_CH];
     __shared__ unsigned s_ticket;
     const int cl = threadIdx.x & (BNF_CH - 1), rl = threadIdx.x / BNF_CH;
@@ -29,7 +30,7 @@ __device__ __forceinline__ bool bn_reduce_partials(const float* partial, int nbl
             float a[BNF_UNROLL], b[BNF_UNROLL];
 #pragma unroll
             for (int u = 0; u < BNF_UNROLL; ++u) {
-                const float* row = partial + (size_t)(k + u * BNF_RL) * 2 * ldp;
+                const float* row = partial + (size_t)(k + u * BNF_RL) * planes * ldp;
                 a[u] = row[c];
                 b[u] = row[ldp + c];
             }
@@ -37,7 +38,7 @@ __device__ __forceinline__ bool bn_reduce_partials(const float* partial, int nbl
             for (int u = 0; u < BNF_UNROLL; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
         }
         for (; k < k1; k += BNF_RL) {
-            const float* row = partial + (size_t)k * 2 * ldp;
+            const float* row = partial + (size_t)k * planes * ldp;
             s1 += (double)row[c];
             s2 += (double)row[ldp + c];
         }
@@ -94,31 +95,110 @@ __device__ __forceinline__ bool bn_reduce_partials(const float* partial, int nbl
     return rl == 0 && c < C;
 }
 
+// QAT: per-channel extremes of the raw conv outputs from planes 2 / 3 of 4-plane partial rows (one block walks all rows; a
+// separate walk after the sums: one combined walk with four loads per row measured 1.39 against 1.07 ms per step).
+__device__ __forceinline__ void bn_reduce_minmax(const float* partial, int nblk, int ldp, int C, float& lo, float& hi) {
+    __shared__ float shm2[2][BNF_RL][BNF_CH];
+    const int cl = threadIdx.x & (BNF_CH - 1), rl = threadIdx.x / BNF_CH;
+    const int c = blockIdx.x * BNF_CH + cl;
+    float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+    if (c < C) {
+        int k = rl;
+        for (; k + (BNF_UNROLL - 1) * BNF_RL < nblk; k += BNF_UNROLL * BNF_RL) {
+            float a[BNF_UNROLL], b[BNF_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BNF_UNROLL; ++u) {
+                const float* row = partial + (size_t)(k + u * BNF_RL) * 4 * ldp;
+                a[u] = row[2 * ldp + c];
+                b[u] = row[3 * ldp + c];
+            }
+#pragma unroll
+            for (int u = 0; u < BNF_UNROLL; ++u) { mn = fminf(mn, a[u]); mx = fmaxf(mx, b[u]); }
+        }
+        for (; k < nblk; k += BNF_RL) {
+            const float* row = partial + (size_t)k * 4 * ldp;
+            mn = fminf(mn, row[2 * ldp + c]);
+            mx = fmaxf(mx, row[3 * ldp + c]);
+        }
+    }
+    shm2[0][rl][cl] = mn;
+    shm2[1][rl][cl] = mx;
+    __syncthreads();
+    lo = __builtin_huge_valf(); hi = -__builtin_huge_valf();
+    if (rl == 0) {
+#pragma unroll
+        for (int q = 0; q < BNF_RL; ++q) { lo = fminf(lo, shm2[0][q][cl]); hi = fmaxf(hi, shm2[1][q][cl]); }
+    }
+}
+// float <-> unsigned key with the same order (atomicMin / atomicMax on the keys = min / max of the floats, any arrival order)
+__device__ __forceinline__ unsigned f2key(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
 __global__ __launch_bounds__(BNF_CH * BNF_RL) void bn_fwd_finalize_kernel(pq_bn_fwd_finalize_args a) {
     const int c = blockIdx.x * BNF_CH + (threadIdx.x & (BNF_CH - 1));
     if (a.train) {
         double t1, t2;
-        if (!bn_reduce_partials(a.partial, a.nblk, a.ldp, a.C, a.scratch, a.tickets, t1, t2)) return;
-        const double n = (double)a.count;
-        const double mean = t1 / n;
-        double var = t2 / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        // QAT: the statistics are those of out = conv_orig * sf.  BatchNorm on conv_orig = out / sf equals BatchNorm on `out`
-        // with eps scaled by sf^2 (and the sign of sf), so everything downstream keeps working on the raw tensor.
-        const double sf = a.sf ? (double)a.sf[c] : 1.0;
-        const float inv = (float)((sf < 0.0 ? -1.0 : 1.0) / sqrt(var + (double)a.eps * sf * sf));
-        const float g = a.gamma[c], b = a.beta[c];
-        a.mean[c] = (float)mean;
-        a.invstd[c] = inv;
-        const float sc = g * inv;
-        a.scale[c] = sc;
-        a.shift[c] = b - (float)mean * sc;
-        if (a.running_mean) {
-            const double unb = (n > 1.0 ? var * n / (n - 1.0) : var) / (sf * sf);
-            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)(mean / sf);
-            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+        // QAT with the observer folded in (4-plane rows, gridDim.y == 1): raw per-channel extremes first, by every lane
+        const bool mmode = a.planes == 4 && a.qstate != nullptr;
+        float rlo = 0.f, rhi = 0.f;
+        if (mmode) bn_reduce_minmax(a.partial, a.nblk, a.ldp, a.C, rlo, rhi);
+        const bool owner = bn_reduce_partials(a.partial, a.nblk, a.ldp, a.C, a.scratch, a.tickets, t1, t2, a.planes == 4 ? 4 : 2);
+        if (!owner && !mmode) return;
+        float vlo = __builtin_huge_valf(), vhi = -__builtin_huge_valf();
+        if (owner) {
+            const double n = (double)a.count;
+            const double mean = t1 / n;
+            double var = t2 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            // QAT: the statistics are those of out = conv_orig * sf.  BatchNorm on conv_orig = out / sf equals BatchNorm on `out`
+            // with eps scaled by sf^2 (and the sign of sf), so everything downstream keeps working on the raw tensor.
+            const double sf = a.sf ? (double)a.sf[c] : 1.0;
+            const float inv = (float)((sf < 0.0 ? -1.0 : 1.0) / sqrt(var + (double)a.eps * sf * sf));
+            const float g = a.gamma[c], b = a.beta[c];
+            a.mean[c] = (float)mean;
+            a.invstd[c] = inv;
+            const float sc = g * inv;
+            const float sh = b - (float)mean * sc;
+            a.scale[c] = sc;
+            a.shift[c] = sh;
+            if (a.running_mean) {
+                const double unb = (n > 1.0 ? var * n / (n - 1.0) : var) / (sf * sf);
+                a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)(mean / sf);
+                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+            }
+            if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+            if (mmode) {
+                // the observed tensor is act(sc * raw + sh): monotone per channel, so its extremes are the images of the raw ones
+                // (same fmaf + activation as every consumer and as qact_minmax4_kernel: bit-identical to a pass over the tensor)
+                const ActParam act = act_param(a.act);
+                const float e0 = act_fwd(fmaf(sc, rlo, sh), act), e1 = act_fwd(fmaf(sc, rhi, sh), act);
+                vlo = fminf(e0, e1); vhi = fmaxf(e0, e1);
+            }
         }
-        if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+        if (mmode) {
+            // block extremes -> two order-preserving atomics on the layer's scratch; the last block of the launch (ticket) feeds the
+            // moving-average observer and re-arms the scratch.  mm = {key of the minimum, key of the maximum, ticket}
+            __shared__ float sv[2][BNF_CH];
+            __shared__ unsigned s_last;
+            __syncthreads();
+            if (threadIdx.x < BNF_CH) { sv[0][threadIdx.x] = vlo; sv[1][threadIdx.x] = vhi; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float lo = sv[0][0], hi = sv[1][0];
+#pragma unroll
+                for (int q = 1; q < BNF_CH; ++q) { lo = fminf(lo, sv[0][q]); hi = fmaxf(hi, sv[1][q]); }
+                atomicMin(&a.mm[0], f2key(lo));
+                atomicMax(&a.mm[1], f2key(hi));
+                __threadfence();
+                s_last = atomicAdd(&a.mm[2], 1u);
+                if (s_last == gridDim.x - 1) {
+                    __threadfence();
+                    const float tlo = key2f(atomicMax(&a.mm[0], 0xffffffffu)), thi = key2f(atomicMin(&a.mm[1], 0u));   // read + re-arm
+                    a.mm[2] = 0u;
+                    qat_observe(a.qstate, tlo, thi, 0, 255, false, a.avg_const);
+                }
+            }
+        }
     } else if (threadIdx.x < BNF_CH && blockIdx.y == 0 && c < a.C) {
         const float inv = 1.f / sqrtf(a.running_var[c] + a.eps);
         const float sf = a.sf ? a.sf[c] : 1.f;              // QAT: the raw tensor is conv_orig * sf
@@ -388,7 +468,10 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
     PQ_CHECK_ARG(a->C > 0, "empty");
     PQ_CHECK_ARG(!a->train || (a->partial && a->nblk > 0 && a->count > 0.f), "train mode needs partial sums");
     PQ_CHECK_ARG(a->train || (a->running_mean && a->running_var), "eval mode needs running statistics");
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, a->train ? bn_row_groups(a->nblk, a->scratch && a->tickets) : 1),
+    const bool mmode = a->train && a->planes == 4 && a->qstate != nullptr;
+    PQ_CHECK_ARG(a->planes == 0 || a->planes == 2 || a->planes == 4, "planes must be 2 or 4");
+    PQ_CHECK_ARG(!mmode || a->mm, "the folded observer needs its 3-word scratch");
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, (a->train && !mmode) ? bn_row_groups(a->nblk, a->scratch && a->tickets) : 1),
                        dim3(BNF_CH * BNF_RL), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;

@@ -36,7 +36,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// AMODE: 0 plain, 1 forward affine+act, 2 gradient pair.  BKN: B stored [k][n].  EMODE: 0 store(+bias), 1 store+stats, 2 sink
+// AMODE: 0 plain, 1 forward affine+act, 2 gradient pair.  BKN: B stored [k][n].  EMODE: 0 store(+bias), 1 store+stats, 2 sink,
+// 3 store + stats + per-channel min / max of the outputs (4-plane statistic rows: QAT observers)
 // DB: double-buffered LDS + loads two k-tiles ahead (compute-bound shapes); !DB: one buffer (full-N streaming tiles).
 template <int BM, int BN, int WM, int WN, int AMODE, bool BKN, int EMODE, bool DB, int PF = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     static_assert((BM / WM) * NWN == 4, "4 waves per block");
     __shared__ __attribute__((aligned(16))) float As2[NB * BM * LDT];
     __shared__ __attribute__((aligned(16))) float Bs2[NB * BN * LDT];
-    __shared__ float red[2 * 4 * 192];
+    __shared__ float red[(EMODE == 3 ? 4 : 2) * 4 * 192];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w / NWN, wn = w % NWN;
@@ -290,8 +291,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 
     // ---------------------------------------------------------------- epilogue
     float s1[TJ], s2[TJ];
+    float mn[TJ], mx[TJ];                        // EMODE 3 only
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) s1[j] = s2[j] = 0.f;
+    for (int j = 0; j < TJ; ++j) { s1[j] = s2[j] = 0.f; mn[j] = __builtin_huge_valf(); mx[j] = -__builtin_huge_valf(); }
     bool want_stats = false;
     bool sums_in_red = false;          // the row-major sink already left its column sums in `red`
 
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             }
         }
     } else {
-        want_stats = (EMODE == 1) && p.partial != nullptr;
+        want_stats = (EMODE == 1 || EMODE == 3) && p.partial != nullptr;
         // Output tiles leave through LDS: a wave parks one 32x32 accumulator tile in its own 32x36 patch (lane = column, as the
         // MFMA delivers it) and reads it back as rows, so the tile is written with 4 x 16-byte-per-lane stores (8 full 128-byte
         // row segments each) instead of 16 dword stores.  Same-wave LDS traffic is ordered, no barrier inside the loop.
@@ -439,7 +441,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                     const float v = acc[i][j][r] + bias;
                     if (vec_out) patch[row * 36 + lrow] = v;
                     else if (mb + row < M && nok) p.out[(size_t)(mb + row) * p.ldo + n] = v;
-                    if (EMODE == 1 && mb + row < M && nok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                    if ((EMODE == 1 || EMODE == 3) && mb + row < M && nok) {
+                        s1[j] += v; s2[j] = fmaf(v, v, s2[j]);
+                        if (EMODE == 3) { mn[j] = fminf(mn[j], v); mx[j] = fmaxf(mx[j], v); }
+                    }
                 }
                 if (vec_out) {
 #pragma unroll
@@ -472,16 +477,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                 }
             }
         }
+        if (EMODE == 3) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                mn[j] = fminf(mn[j], __shfl_xor(mn[j], 32));
+                mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32));
+                if (lh == 0) {
+                    red[(2 * 4 + wm) * 192 + wn * WN + 32 * j + lrow] = mn[j];
+                    red[(3 * 4 + wm) * 192 + wn * WN + 32 * j + lrow] = mx[j];
+                }
+            }
+        }
         __syncthreads();
         if (t < BN) {
+            constexpr int PLANES = EMODE == 3 ? 4 : 2;
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int q = 0; q < BM / WM; ++q) { a += red[(0 * 4 + q) * 192 + t]; b += red[(1 * 4 + q) * 192 + t]; }
             const int n = n0 + t;
             if (n < N) {
-                float* dst = part + (size_t)bmy * 2 * ldp;
+                float* dst = part + (size_t)bmy * PLANES * ldp;
                 dst[n] = a;
                 dst[ldp + n] = b;
+                if (EMODE == 3) {
+                    float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+#pragma unroll
+                    for (int q = 0; q < BM / WM; ++q) { lo = fminf(lo, red[(2 * 4 + q) * 192 + t]); hi = fmaxf(hi, red[(3 * 4 + q) * 192 + t]); }
+                    dst[2 * ldp + n] = lo;
+                    dst[3 * ldp + n] = hi;
+                }
             }
         }
     }
@@ -809,15 +833,18 @@ extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool xform = a->in.scale != nullptr || a->in.act != PQ_ACT_LINEAR || a->in.qstate != nullptr;
     const int bm = row_bm(a->M, a->O, a->I, 0);
-    {
+    const bool minmax = a->partial != nullptr && a->minmax != 0;      // QAT only: the round-1 kernels carry the 4-plane epilogue
+    if (!minmax) {
         const int rc = g2_conv1x1_fwd(a, bm, st);
         if (rc < 0) return rc;
         if (rc == 1) { PQ_CHECK_LAUNCH(); return PQ_OK; }
     }
     if (xform) {
-        if (a->partial) launch_nt<1, false, 1>(p, st, bm); else launch_nt<1, false, 0>(p, st, bm);
+        if (minmax) launch_nt<1, false, 3>(p, st, bm);
+        else if (a->partial) launch_nt<1, false, 1>(p, st, bm); else launch_nt<1, false, 0>(p, st, bm);
     } else {
-        if (a->partial) launch_nt<0, false, 1>(p, st, bm); else launch_nt<0, false, 0>(p, st, bm);
+        if (minmax) launch_nt<0, false, 3>(p, st, bm);
+        else if (a->partial) launch_nt<0, false, 1>(p, st, bm); else launch_nt<0, false, 0>(p, st, bm);
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;

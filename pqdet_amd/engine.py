@@ -465,6 +465,15 @@ class Plan:
                         and inner.C % 4 == 0 and os.environ.get('PQ_QAT_FUSE', '1') != '0':
                     qout.fuse_inner, qout.fuse_key = inner, ('a', i_)
                     qout.fuse_qptr = self._qstate(('a', i_)) if self.q_quant else None
+                    # ... and the observer needs no pass over the tensor either: the producer's epilogue adds per-channel min / max
+                    # to its statistic rows (4 planes) and pq_bn_fwd_finalize feeds the moving-average observer from them
+                    kinds = {it[0] for it in self._deferred if len(it) > 1 and it[1] == i_}
+                    if self.q_observe and self.bn_train and inner.bn is not None and kinds & {'c1_fwd', 'dw_fwd', 'stem_fwd'} \
+                            and os.environ.get('PQ_QAT_FOLD', '1') != '0':
+                        inner.fold_obs = True
+                        inner.bn.fwd_partial = self._new(inner.bn.fwd_nblk * 4 * inner.bn.ldp)
+                        inner.fold_mm = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=self.device)   # {0xffffffff, 0, 0}
+                        self.keep.append(inner.fold_mm)
 
         coef.commit()
         self.keep.append(coef.buf)
@@ -501,7 +510,7 @@ class Plan:
             elif kind == 'qact':
                 _, i, inner, qout = item
                 if getattr(qout, 'fuse_inner', None) is not None:
-                    if self.q_observe:                     # observer only; nobody reads a materialised copy
+                    if self.q_observe and not getattr(inner, 'fold_obs', False):    # observer only; nobody reads a materialised copy
                         self._qact_fwd(inner.src(), None, inner.rows, inner.C, qout.ld, ('a', i))
                 else:
                     self._qact_fwd(inner.src(), qout.raw, inner.rows, inner.C, qout.ld, ('a', i))
@@ -510,7 +519,8 @@ class Plan:
                 conv = mods[i].conv
                 part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
                 a = abi.StemFwd(ptr(self.qimg) if self.qat else None, wptr(i), ptr(out.raw), ptr(part), B, 3, self.IH, self.IW,
-                                out.H, out.W, out.C, conv.stride[0], out.ld, out.bn.ldp if out.bn else 0)
+                                out.H, out.W, out.C, conv.stride[0], out.ld, out.bn.ldp if out.bn else 0,
+                                int(getattr(out, 'fold_obs', False)))
                 idx = self._op(self.fwd, abi.OP_STEM_FWD, a)
                 if not self.qat:
                     self.patch_x.append(('fwd', idx, 'stf'))
@@ -520,14 +530,14 @@ class Plan:
                 part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
                 a = abi.Conv1x1Fwd(src.src(), wptr(i), ptr(conv.bias) if conv.bias is not None else None,
                                    ptr(out.raw), ptr(part), out.rows, src.C, out.C, out.ld, out.bn.ldp if out.bn else 0,
-                                   s, out.H, out.W, src.H, src.W)
+                                   s, out.H, out.W, src.H, src.W, int(getattr(out, 'fold_obs', False)))
                 self._op(self.fwd, abi.OP_CONV1X1_FWD, a)
             elif kind == 'dw_fwd':
                 _, i, out, nblk, src, s = item
                 conv = mods[i].conv
                 part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
                 a = abi.DwFwd(src.src(), wptr(i), ptr(out.raw), ptr(part), B, src.H, src.W, out.H, out.W, out.C, s,
-                              out.ld, out.bn.ldp if out.bn else 0)
+                              out.ld, out.bn.ldp if out.bn else 0, int(getattr(out, 'fold_obs', False)))
                 self._op(self.fwd, abi.OP_DW_FWD, a)
             elif kind == 'gc_fwd':
                 _, i, out, nblk, src, s = item
@@ -552,6 +562,8 @@ class Plan:
                                  ptr(b.invstd), ptr(b.scale), ptr(b.shift), b.fwd_nblk, b.ldp, b.C, int(train), b.count,
                                  float(bm.eps), float(bm.momentum if bm.momentum is not None else 0.1), sc, tk,
                                  ptr(self._wq[i][1]) if self.qat else None)
+                if getattr(out, 'fold_obs', False):
+                    a.planes, a.act, a.qstate, a.mm, a.avg_const = 4, out.act, self._qstate(('a', i)), out.fold_mm.data_ptr(), 0.01
                 self._op(self.fwd, abi.OP_BN_FWD_FIN, a)
             elif kind == 'pool':
                 _, i, out, a_ = item

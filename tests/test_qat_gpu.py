@@ -285,6 +285,112 @@ def test_qat_small_shape_first_step_reproduces_reference_and_observer_switch():
     assert all(torch.isfinite(p).all() for p in net.parameters())
 
 
+@pytest.mark.parametrize('kind,shape', [('c1', (700, 32, 24)), ('c1', (513, 96, 200)), ('dw', (2, 9, 13, 32, 1)),
+                                        ('dw', (1, 80, 72, 24, 2)), ('stem', (2, 16, 20, 32, 2))])
+def test_min_max_planes_of_the_producers_and_the_folded_observer_against_the_oracle(kind, shape):
+    """minmax != 0: the statistic rows of pq_conv1x1_fwd / pq_dw3x3_fwd (streaming and LDS-tiled) / pq_stem3x3_fwd carry the
+    per-channel minimum and maximum of the outputs in planes 2 / 3; pq_bn_fwd_finalize(planes = 4, qstate) then leaves the
+    observer state that oracle.qat.FakeQuant computes from a pass over act(bn(out)) -- twice (first batch, moving average)."""
+    import torch.nn.functional as F
+    l = abi.lib()
+    g = torch.Generator().manual_seed(sum(shape))
+    ACT = 1                                                    # ReLU (QAT nets are ReLU everywhere, model/parser.py:408-409)
+    fq = oqat.FakeQuant(0, 255, False)
+    state = torch.tensor([float('inf'), float('-inf'), 1.0, 0.0], device=DEV)
+    mm = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=DEV)
+    for rep in range(2):
+        if kind == 'c1':
+            M, I, O = shape
+            x = torch.randn(M, I, generator=g) * (1 + rep)
+            w = torch.randn(O, I, generator=g) / I ** 0.5
+            Cn, rows, ldo = O, M, (O + 3) // 4 * 4
+            nblk = l.pq_conv1x1_blocks_k(M, O, I, 0)
+            ldp = (O + 15) // 16 * 16
+            part = torch.full((nblk * 4 * ldp,), float('nan'), device=DEV)
+            out = torch.zeros(M, ldo, device=DEV)
+            xd, wd = x.to(DEV), w.to(DEV)
+            a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, 0), wd.data_ptr(), None, out.data_ptr(), part.data_ptr(),
+                               M, I, O, ldo, ldp, 1, 0, 0, 0, 0, 1)
+            abi.check(l.pq_conv1x1_fwd(C.byref(a), _stream()))
+        elif kind == 'dw':
+            B, H, W, Cn, s = shape
+            x = torch.randn(B, H, W, Cn, generator=g) * (1 + rep)
+            w = torch.randn(Cn, 3, 3, generator=g) * 0.3
+            OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+            rows, ldo = B * OH * OW, Cn
+            nblk = l.pq_dw3x3_fwd_blocks(B, OH, OW, Cn, s)
+            ldp = (Cn + 15) // 16 * 16
+            part = torch.full((nblk * 4 * ldp,), float('nan'), device=DEV)
+            out = torch.zeros(rows, ldo, device=DEV)
+            xd, wd = x.to(DEV), w.to(DEV)
+            a = abi.DwFwd(abi.Src(xd.data_ptr(), None, None, Cn, 0), wd.data_ptr(), out.data_ptr(), part.data_ptr(),
+                          B, H, W, OH, OW, Cn, s, ldo, ldp, 1)
+            abi.check(l.pq_dw3x3_fwd(C.byref(a), _stream()))
+        else:
+            B, H, W, Cn, s = shape
+            x = torch.randn(B, 3, H, W, generator=g) * (1 + rep)
+            w = torch.randn(Cn, 3, 3, 3, generator=g) * 0.3
+            OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+            rows, ldo = B * OH * OW, Cn
+            nblk = l.pq_ew_blocks(rows, Cn)
+            ldp = (Cn + 15) // 16 * 16
+            part = torch.full((nblk * 4 * ldp,), float('nan'), device=DEV)
+            out = torch.zeros(rows, ldo, device=DEV)
+            xd, wd = x.to(DEV), w.to(DEV)
+            a = abi.StemFwd(xd.data_ptr(), wd.data_ptr(), out.data_ptr(), part.data_ptr(), B, 3, H, W, OH, OW, Cn, s, ldo, ldp, 1)
+            abi.check(l.pq_stem3x3_fwd(C.byref(a), _stream()))
+        torch.cuda.synchronize()
+        raw = out[:, :Cn].cpu()
+        pp = part.cpu().view(nblk, 4, ldp)
+        assert torch.equal(pp[:, 2, :Cn].min(0).values, raw.min(0).values), 'plane 2: per-channel minimum'
+        assert torch.equal(pp[:, 3, :Cn].max(0).values, raw.max(0).values), 'plane 3: per-channel maximum'
+        gam, bet = (torch.rand(Cn, generator=g) + 0.5) * (1 - 2 * (torch.rand(Cn, generator=g) < 0.2).float()), torch.randn(Cn, generator=g) * 0.3
+        gd, bd = gam.to(DEV), bet.to(DEV)
+        rm, rv = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+        mean, inv, sc, sh = (torch.empty(Cn, device=DEV) for _ in range(4))
+        f = abi.BnFwdFin(part.data_ptr(), gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr(), None, mean.data_ptr(),
+                         inv.data_ptr(), sc.data_ptr(), sh.data_ptr(), nblk, ldp, Cn, 1, float(rows), 1e-5, 0.1, None, None, None,
+                         4, ACT, state.data_ptr(), mm.data_ptr(), 0.01)
+        abi.check(l.pq_bn_fwd_finalize(C.byref(f), _stream()))
+        torch.cuda.synchronize()
+        # fmaf(scale, raw, shift) (one rounding: product and sum in fp64, then narrowed), then the activation
+        post = torch.relu(torch.from_numpy(np.float32(sc.cpu().numpy()).astype(np.float64) * raw.numpy().astype(np.float64)
+                                           + sh.cpu().numpy().astype(np.float64)).float())
+        fq(post)
+        got = state.cpu().tolist()
+        want = [fq.min_val.item(), fq.max_val.item(), fq.scale.item(), float(fq.zero_point.item())]
+        assert got == want, (rep, got, want)
+        assert mm.cpu().tolist()[:3] == [-1, 0, 0], 're-armed'
+
+
+def test_observer_folded_into_the_batchnorm_finalize_is_bit_identical_to_the_pass_over_the_tensor(monkeypatch):
+    """Conv outputs that are never materialised in quantised form get their activation observer from per-channel min / max
+    rows of the producer's epilogue + pq_bn_fwd_finalize (PQ_QAT_FOLD, default) instead of a pass over the tensor
+    (pq_qact_fwd with out == NULL).  act(scale * x + shift) is monotone per channel, so both see exactly the same extremes:
+    every observer state {min, max, scale, zero_point}, the losses and the gradients agree BIT FOR BIT over two steps."""
+    runs = {}
+    for fold in ('1', '0'):
+        monkeypatch.setenv('PQ_QAT_FOLD', fold)
+        net = _product()
+        rec = []
+        for step in range(2):
+            x, tgt = qat_batch(step)
+            net.zero_grad()
+            out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+            out['loss'].mean().backward()
+            rec.append((out['loss'].detach().clone(), net._qat_state.clone(), net._flat.grad.clone()))
+        plan = list(net._plans.values())[0]
+        n_obs = sum(1 for op in plan.fwd if op.code == abi.OP_QACT_FWD)
+        n_fold = sum(1 for op in plan.fwd if op.code == abi.OP_BN_FWD_FIN and op.u.bnf.planes == 4)
+        runs[fold] = (rec, n_obs, n_fold)
+    (a, obs_a, fold_a), (b, obs_b, fold_b) = runs['1'], runs['0']
+    assert fold_a >= 60 and fold_b == 0 and obs_b - obs_a == fold_a, (obs_a, fold_a, obs_b, fold_b)
+    for (la, qa, ga), (lb, qb, gb) in zip(a, b):
+        assert torch.equal(qa, qb), (qa - qb).abs().max()
+        assert torch.equal(la, lb)
+        assert torch.equal(ga, gb)
+
+
 # ------------------------------------------------------------------------------------------------- 4. fixed qparams (G9b)
 def _load_g9b_state(net, golden_r2, r2_names):
     """BatchNorm running statistics + every observer's qparams as recorded from the reference before the G9b pass."""
