@@ -211,7 +211,11 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
         const bool affine = sk.scale != nullptr;
         const bool stats = sk.mean != nullptr && sk.partial != nullptr;
         const ActParam sact = act_param(sk.act);
-        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
+        // QAT: the tensor is consumed as fake_quant(act(...)): straight-through mask of its activation observer (arithmetic of
+        // qat.hip / sink_apply4: the multiply sits inside rintf, nothing here can contract)
+        const bool qmask = sk.finalize && sk.qstate != nullptr;
+        const float qinv = qmask ? 1.f / sk.qstate[2] : 0.f, qzp = qmask ? sk.qstate[3] : 0.f;
+        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats || qmask);
         want_stats = sk.finalize && stats;
         const int c4 = (lane & 7) * 4;
 #pragma unroll
@@ -246,7 +250,11 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
                     const float yy[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w};
                     if (need_y) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) dz[u] *= act_bwd(fmaf(ca[u], yy[u], cb[u]), sact);
+                        for (int u = 0; u < 4; ++u) {
+                            const float uu = fmaf(ca[u], yy[u], cb[u]);
+                            dz[u] *= act_bwd(uu, sact);
+                            if (qmask) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz[u] = (qv >= 0.f && qv <= 255.f) ? dz[u] : 0.f; }
+                        }
                     }
                     if (m < M && nok) {
                         stg4(sk.g + (size_t)m * sk.ldg + nn, make_float4(dz[0], dz[1], dz[2], dz[3]));
@@ -584,10 +592,10 @@ int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st) {
 }
 
 int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st) {
-    if (!g2_enabled() || a->sub > 1 || !a->wt || (a->O & 15) || a->O < 64 || a->I < 64 || a->dx.qstate) return 0;
+    if (!g2_enabled() || a->sub > 1 || !a->wt || (a->O & 15) || a->O < 64 || a->I < 64) return 0;
     const pq_gsink& sk = a->dx;
     const bool stats = sk.mean != nullptr && sk.partial != nullptr;
-    const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats);
+    const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats || sk.qstate != nullptr);
     if ((a->I & 3) || (sk.ldg & 3) || (((uintptr_t)sk.g) & 15) || (need_y && ((sk.ldy & 3) || (((uintptr_t)sk.y) & 15)))) return 0;
     if ((((uintptr_t)a->dy.g) & 15) || (a->dy.y && (((uintptr_t)a->dy.y) & 15)) || (((uintptr_t)a->wt) & 15)) return 0;
     G2P p{};
