@@ -95,6 +95,13 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
         Ws[o * LDX + i] = p.w[idx];
     }
 
+    // The sink's y is normally the layer input itself (dx.y == in.x in every engine plan): the RAW input values a thread stages
+    // stay in registers across the MFMA phase and serve the sink, instead of a second (L2-hit, but exposed) load per tile.
+    constexpr int NIT = TD <= 2 ? 1 : (TD <= 6 ? 2 : 4);      // staging rounds of PW_NB rows a thread needs at most (64 rows)
+    constexpr bool KEEP = TD <= 6;                             // the 12-tile flavour (I up to 192) has no registers to spare
+    float4 xraw[KEEP ? NIT * PW_NB : 1];
+    const bool same_y = KEEP && need_y && p.dx.y == p.x.x && p.dx.ldy == p.x.ld;
+
     f32x4 aw[3][2];      // [tile of the wide side: w, w+4, w+8][tile of the narrow side: 0, 1]
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -128,20 +135,25 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
         }
         if (iact) {
             const SrcCoef4 xk = xcoef();
-            for (int r0 = iy; r0 < PW_BM; r0 += PW_NB * PYi) {
-                float4 xv[PW_NB];
 #pragma unroll
-                for (int u = 0; u < PW_NB; ++u) {
-                    const int m = min(m0 + min(r0 + u * PYi, PW_BM - 1), p.M - 1);
-                    xv[u] = ldg4(p.x.x + (size_t)m * p.x.ld + 4 * ix);
-                }
+            for (int it = 0; it < NIT; ++it) {
+                const int r0 = iy + it * PW_NB * PYi;
+                if (r0 < PW_BM) {
+                    float4 xv[PW_NB];
 #pragma unroll
-                for (int u = 0; u < PW_NB; ++u) {
-                    const int r = r0 + u * PYi;
-                    if (r < PW_BM) {
-                        float4 v = src_apply4(xv[u], xk);
-                        if (m0 + r >= p.M) v = f4zero();
-                        *reinterpret_cast<float4*>(&xs[r * LDX + 4 * ix]) = v;
+                    for (int u = 0; u < PW_NB; ++u) {
+                        const int m = min(m0 + min(r0 + u * PYi, PW_BM - 1), p.M - 1);
+                        xv[u] = ldg4(p.x.x + (size_t)m * p.x.ld + 4 * ix);
+                        if (KEEP) xraw[it * PW_NB + u] = xv[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < PW_NB; ++u) {
+                        const int r = r0 + u * PYi;
+                        if (r < PW_BM) {
+                            float4 v = src_apply4(xv[u], xk);
+                            if (m0 + r >= p.M) v = f4zero();
+                            *reinterpret_cast<float4*>(&xs[r * LDX + 4 * ix]) = v;
+                        }
                     }
                 }
             }
@@ -221,20 +233,24 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
         __syncthreads();
         if (iact) {
             const SinkCoef4 sk = scoef();
-            for (int r0 = iy; r0 < PW_BM; r0 += PW_NB * PYi) {
-                float4 go[PW_NB], yv[PW_NB];
 #pragma unroll
-                for (int u = 0; u < PW_NB; ++u) {
-                    const int m = min(m0 + min(r0 + u * PYi, PW_BM - 1), p.M - 1);
-                    go[u] = p.dx.accumulate ? ldg4(p.dx.g + (size_t)m * p.dx.ldg + 4 * ix) : f4zero();
-                    yv[u] = need_y ? ldg4(p.dx.y + (size_t)m * p.dx.ldy + 4 * ix) : f4zero();
-                }
+            for (int it = 0; it < NIT; ++it) {
+                const int r0 = iy + it * PW_NB * PYi;
+                if (r0 < PW_BM) {
+                    float4 go[PW_NB], yv[PW_NB];
 #pragma unroll
-                for (int u = 0; u < PW_NB; ++u) {
-                    const int r = r0 + u * PYi, m = m0 + r;
-                    if (r < PW_BM && m < p.M) {
-                        float4 dz = f4add(*reinterpret_cast<const float4*>(&xs[r * LDX + 4 * ix]), go[u]);
-                        stg4(p.dx.g + (size_t)m * p.dx.ldg + 4 * ix, sink_apply4(p.dx, sk, dz, yv[u], s1, s2));
+                    for (int u = 0; u < PW_NB; ++u) {
+                        const int m = min(m0 + min(r0 + u * PYi, PW_BM - 1), p.M - 1);
+                        go[u] = p.dx.accumulate ? ldg4(p.dx.g + (size_t)m * p.dx.ldg + 4 * ix) : f4zero();
+                        yv[u] = same_y ? xraw[KEEP ? it * PW_NB + u : 0] : (need_y ? ldg4(p.dx.y + (size_t)m * p.dx.ldy + 4 * ix) : f4zero());
+                    }
+#pragma unroll
+                    for (int u = 0; u < PW_NB; ++u) {
+                        const int r = r0 + u * PYi, m = m0 + r;
+                        if (r < PW_BM && m < p.M) {
+                            float4 dz = f4add(*reinterpret_cast<const float4*>(&xs[r * LDX + 4 * ix]), go[u]);
+                            stg4(p.dx.g + (size_t)m * p.dx.ldg + 4 * ix, sink_apply4(p.dx, sk, dz, yv[u], s1, s2));
+                        }
                     }
                 }
             }

@@ -14,8 +14,9 @@ def timeit(fn, reps=30):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-B, H, W, s = 16, 128, 128, 1
-for Cc, ld in ((128, 128), (144, 144), (144, 160), (144, 192), (160, 160)):
+s = 1
+for B, H, W, Cc, ld in ((16, 128, 128, 128, 128), (16, 128, 128, 144, 144), (16, 128, 128, 144, 160), (16, 128, 128, 144, 192), (16, 128, 128, 160, 160),
+                        (16, 128, 128, 32, 32), (16, 256, 256, 32, 32), (4, 256, 256, 128, 128), (64, 128, 128, 32, 32), (16, 128, 128, 64, 64), (16, 256, 256, 64, 64)):
     x = torch.randn(B, H, W, ld, device=dev); out = torch.empty(B, H, W, ld, device=dev)
     yo = torch.randn(B, H, W, ld, device=dev); g = torch.randn(B, H, W, ld, device=dev); gin = torch.empty(B, H, W, ld, device=dev)
     w = torch.randn(Cc, 9, device=dev)
@@ -30,4 +31,4 @@ for Cc, ld in ((128, 128), (144, 144), (144, 160), (144, 192), (160, 160)):
     tf = timeit(lambda: abi.check(l.pq_dw3x3_fwd(C.byref(f), st)))
     td = timeit(lambda: abi.check(l.pq_dw3x3_dgrad(C.byref(d), st)))
     n = B * H * W * Cc * 4
-    print('C=%3d ld=%3d | fwd %6.1f us %5.0f GB/s useful | dgrad %6.1f us %5.0f GB/s useful' % (Cc, ld, tf * 1e3, 2 * n / tf / 1e6, td * 1e3, 4 * n / td / 1e6))
+    print('B=%2d %3dx%3d C=%3d ld=%3d | fwd %6.1f us %5.0f GB/s useful | dgrad %6.1f us %5.0f GB/s useful' % (B, H, W, Cc, ld, tf * 1e3, 2 * n / tf / 1e6, td * 1e3, 4 * n / td / 1e6))
