@@ -1016,6 +1016,19 @@ def test_nms_selection_bit_exact(n, ncls, seed):
     np.testing.assert_array_equal(got, want)
 
 
+def test_nms_greedy_fallback_kernel_is_still_bit_exact():
+    """pq_nms normally suppresses through the suppression bit matrix; the chunk-walking greedy kernel remains the fallback for
+    (image, class) segments whose matrix would exceed the 96 MiB scratch.  PQ_NMS_GREEDY=1 forces it (read once per process, so
+    the bit-exact selection tests run again in ONE child interpreter with the variable set)."""
+    import os, subprocess, sys
+    env = dict(os.environ, PQ_NMS_GREEDY='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider', '-k',
+                        'nms_selection_bit_exact or nms_batch_is_bit_identical or nms_empty_and_ties'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
+
+
 def test_nms_candidate_compaction_paths_agree():
     """Fast path (ordered compaction of the pairs above the threshold, sorts sized by cand_cap), its overflow signal and the
     all-pairs path give the same detections, including score ties."""
