@@ -127,12 +127,16 @@ extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side
     int nparked = 0;
     bool used_side = false;
     hipEvent_t bound = nullptr;          // fork event already bound to the last main-stream kernel (no record needed)
+    bool main_dirty = true;              // a main-stream op has been issued since the last fork (else the side stream is already ordered)
     auto flush = [&]() -> int {          // one fork event, then every parked op in issue order
         if (nparked == 0) return PQ_OK;
-        hipEvent_t e = bound;
-        if (!e) { e = ev[next]; next = (next + 1) & 63; }
-        if ((!bound && hipEventRecord(e, main_s) != hipSuccess) || hipStreamWaitEvent(side_s, e, 0) != hipSuccess) {
-            pq_set_error("pq_run_ops2: fork failed"); g_failed_op = parked[0]; return PQ_ELAUNCH;
+        if (main_dirty) {
+            hipEvent_t e = bound;
+            if (!e) { e = ev[next]; next = (next + 1) & 63; }
+            if ((!bound && hipEventRecord(e, main_s) != hipSuccess) || hipStreamWaitEvent(side_s, e, 0) != hipSuccess) {
+                pq_set_error("pq_run_ops2: fork failed"); g_failed_op = parked[0]; return PQ_ELAUNCH;
+            }
+            main_dirty = false;
         }
         bound = nullptr;
         for (int k = 0; k < nparked; ++k) {
@@ -155,6 +159,7 @@ extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side
         bound = nullptr;
         if (forks_next) g_stop_event = ev[next];
         const int rc = run_one(ops[i], stream);
+        main_dirty = true;
         if (forks_next) {
             if (g_stop_event == nullptr) { bound = ev[next]; next = (next + 1) & 63; }      // taken: the kernel carries it
             g_stop_event = nullptr;

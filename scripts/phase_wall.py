@@ -31,6 +31,8 @@ def wall(fn):
 nf, nb = len(plan.fwd), len(plan.bwd)
 print('ops: fwd %d bwd %d' % (nf, nb))
 print('forward            %.3f ms' % wall(lambda: abi.check(l.pq_run_ops(plan.fwd_arr, nf, st))))
+if getattr(plan, 'fwd_two_streams', False):
+    print('forward 2 streams  %.3f ms  (side layers %s)' % (wall(lambda: abi.check(l.pq_run_ops2(plan.fwd_arr, nf, st, sd))), plan.fwd_side_layers))
 print('backward 2 streams %.3f ms' % wall(lambda: abi.check(l.pq_run_ops2(plan.bwd_arr, nb, st, sd))))
 print('backward 1 stream  %.3f ms' % wall(lambda: abi.check(l.pq_run_ops(plan.bwd_arr, nb, st))))
 # per op class, back to back: replay only the ops of one class (inputs are whatever the buffers hold)
