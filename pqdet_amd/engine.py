@@ -624,7 +624,7 @@ class Plan:
             # next side layer only, its input was produced on the main stream before the fork.  11.32 -> 11.24 ms per step
             # (PQ_FWD_SIDE=0: single-stream forward).
             self.fwd_two_streams = False
-            if os.environ.get('PQ_FWD_SIDE', '1') != '0' and not self.qat and self.bn_train and len(heads) > 1:
+            if os.environ.get('PQ_FWD_SIDE', '1') != '0' and self.bn_train and len(heads) > 1:
                 side_layers = set()
                 for i, m, a in sorted(heads, key=lambda h: h[0])[:-1]:
                     j = i - 1
