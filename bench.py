@@ -24,8 +24,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MODELS = ('mobilenetv2-fpn', 'regnetx-600m-fpn', 'regnetx-600m-pan', 'regnety-400m-fpn')
-
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -57,10 +55,8 @@ def launch_ranks(args) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = p.wait() or rc
-    return rc
+    from pqdet_amd.launch import wait_ranks        # pure-Python module: importing it does not touch the GPU
+    return wait_ranks(procs)
 
 
 def resolve_world(args):

@@ -151,6 +151,24 @@ int32_t pq_conv1x1_bwd_pays(int32_t M, int32_t I, int32_t O);
 int64_t pq_conv1x1_bwd_scratch_bytes(int32_t M, int32_t I, int32_t O);
 int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t O);
 
+/* Which kernel instantiation a pq_conv1x1_{fwd,dgrad,wgrad} call with exactly these arguments launches (pure host
+ * function of the argument struct: shapes, pitches, pointer alignment, operand kinds; nothing is launched, no device
+ * memory is touched).  The parity tests assert it for every case, so an eligibility rule cannot silently send a shape
+ * to a kernel that no test checks, and list the instantiations the BASELINE nets select at their benchmark shapes. */
+typedef struct pq_gemm_plan {
+    int32_t family;   /* 1: register-staged kernels (gemm.hip); 2: LDS-DMA ring kernels (gemm2.hip) */
+    int32_t bm, bn;   /* output tile: rows x columns (wgrad: O x I) */
+    int32_t stages;   /* family 2: ring depth; family 1: 2 = double-buffered LDS, 1 = single buffer (streaming full-N tiles) */
+    int32_t amode;    /* operand transform: 0 as stored, 1 BatchNorm affine + activation, 2 gradient pair (closed-form BN backward);
+                         wgrad: bit 0 = gradient pair, bit 1 = transformed input operand */
+    int32_t emode;    /* epilogue: 0 store (+bias), 1 + BatchNorm statistics, 2 gradient sink, 3 + per-channel min / max (QAT) */
+    int32_t splits;   /* wgrad: row splits (slabs to reduce); 0 otherwise */
+    int32_t variant;  /* family 1: B operand stored [k][n] (1) or [n][k] (0); family 2 wgrad: waves per workgroup */
+} pq_gemm_plan;
+int pq_conv1x1_fwd_plan(const pq_conv1x1_fwd_args* a, pq_gemm_plan* out);
+int pq_conv1x1_dgrad_plan(const pq_conv1x1_dgrad_args* a, pq_gemm_plan* out);
+int pq_conv1x1_wgrad_plan(const pq_conv1x1_wgrad_args* a, pq_gemm_plan* out);
+
 /* ------------------------------------------------------------------ depthwise 3x3 (groups == channels), pad 1
  * replaces nn.Conv2d(groups=C, k=3) fwd/bwd (mobilenetv2-fpn: 26 layers).  w is OIHW [C][1][3][3]. */
 typedef struct pq_dw3x3_fwd_args {

@@ -57,6 +57,14 @@ class Conv1x1Bwd(C.Structure):
                 ('M', i32), ('I', i32), ('O', i32)]
 
 
+class GemmPlan(C.Structure):
+    _fields_ = [('family', i32), ('bm', i32), ('bn', i32), ('stages', i32), ('amode', i32), ('emode', i32), ('splits', i32),
+                ('variant', i32)]
+
+    def key(self):
+        return (self.family, self.bm, self.bn, self.stages, self.amode, self.emode, self.variant)
+
+
 class GconvFwd(C.Structure):
     _fields_ = [('inp', Src), ('w', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('gw', i32), ('stride', i32),
@@ -259,6 +267,9 @@ SIGNATURES = {
     'pq_conv1x1_dgrad': (C.c_int, [C.POINTER(Conv1x1Dgrad), C.c_void_p]),
     'pq_conv1x1_wgrad': (C.c_int, [C.POINTER(Conv1x1Wgrad), C.c_void_p]),
     'pq_conv1x1_wgrad_scratch_bytes': (i64, [i32, i32, i32]),
+    'pq_conv1x1_fwd_plan': (C.c_int, [C.POINTER(Conv1x1Fwd), C.POINTER(GemmPlan)]),
+    'pq_conv1x1_dgrad_plan': (C.c_int, [C.POINTER(Conv1x1Dgrad), C.POINTER(GemmPlan)]),
+    'pq_conv1x1_wgrad_plan': (C.c_int, [C.POINTER(Conv1x1Wgrad), C.POINTER(GemmPlan)]),
     'pq_dw3x3_fwd': (C.c_int, [C.POINTER(DwFwd), C.c_void_p]),
     'pq_dw3x3_blocks': (i32, [i32, i32, i32, i32]),
     'pq_dw3x3_fwd_blocks': (i32, [i32, i32, i32, i32, i32]),

@@ -50,7 +50,9 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = '') 
     os.makedirs(OUT_DIR, exist_ok=True)
     lib = LIB if not tag else LIB.replace('.so', '_%s.so' % tag)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'pqdet_hip.h')]
+    # every header under csrc/ (common.h, ldsdma.h, qatmath.h, ...) and the public one: editing any of them rebuilds all objects
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + \
+        [os.path.join(HERE, '..', 'include', 'pqdet_hip.h')]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

@@ -752,9 +752,9 @@ static TilePick pick_tile(int M, int N) {
     return {0, best, kTiles[best].bm, kTiles[best].bn};
 }
 // gemm2.hip (LDS-DMA ring kernels)
-int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st);
-int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st);
-int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* stride_out, hipStream_t st);
+int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st, pq_gemm_plan* plan);
+int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st, pq_gemm_plan* plan);
+int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* stride_out, hipStream_t st, pq_gemm_plan* plan);
 int g2_wgrad_splits(int M, int I, int O);
 
 // Row-block height of the GEMM (M rows, N output columns, contraction K; kind 0 forward, 1 data gradient).  The BatchNorm
@@ -794,8 +794,9 @@ static TilePick pick_tile_bm(int M, int N, int bm) {
     return {0, best, kTiles[best].bm, kTiles[best].bn};
 }
 template <int AMODE, bool BKN, int EMODE>
-static void launch_nt(const GemmP& p, hipStream_t st, int bm) {
+static void launch_nt(const GemmP& p, hipStream_t st, int bm, pq_gemm_plan* plan) {
     const TilePick t = pick_tile_bm(p.M, p.N, bm);
+    if (plan) { *plan = pq_gemm_plan{1, t.bm, t.bn, t.kind == 0 ? 2 : 1, AMODE, EMODE, 0, BKN ? 1 : 0}; return; }   // query only
     dim3 blk(256);
     dim3 grid((p.N + t.bn - 1) / t.bn, (p.M + t.bm - 1) / t.bm);
     if (t.kind == 0) {
@@ -817,7 +818,7 @@ static void launch_nt(const GemmP& p, hipStream_t st, int bm) {
     }
 }
 
-extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
+static int conv1x1_fwd_impl(const pq_conv1x1_fwd_args* a, void* stream, pq_gemm_plan* plan) {
     PQ_CHECK_ARG(a && a->in.x && a->w && a->out, "null pointer");
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->in.ld & 3) == 0 && (((uintptr_t)a->in.x) & 15) == 0, "input pitch/pointer must be 16B aligned");
@@ -835,22 +836,28 @@ extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) {
     const int bm = row_bm(a->M, a->O, a->I, 0);
     const bool minmax = a->partial != nullptr && a->minmax != 0;      // QAT only: the round-1 kernels carry the 4-plane epilogue
     if (!minmax) {
-        const int rc = g2_conv1x1_fwd(a, bm, st);
+        const int rc = g2_conv1x1_fwd(a, bm, st, plan);
         if (rc < 0) return rc;
-        if (rc == 1) { PQ_CHECK_LAUNCH(); return PQ_OK; }
+        if (rc == 1) { if (plan) return PQ_OK; PQ_CHECK_LAUNCH(); return PQ_OK; }
     }
     if (xform) {
-        if (minmax) launch_nt<1, false, 3>(p, st, bm);
-        else if (a->partial) launch_nt<1, false, 1>(p, st, bm); else launch_nt<1, false, 0>(p, st, bm);
+        if (minmax) launch_nt<1, false, 3>(p, st, bm, plan);
+        else if (a->partial) launch_nt<1, false, 1>(p, st, bm, plan); else launch_nt<1, false, 0>(p, st, bm, plan);
     } else {
-        if (minmax) launch_nt<0, false, 3>(p, st, bm);
-        else if (a->partial) launch_nt<0, false, 1>(p, st, bm); else launch_nt<0, false, 0>(p, st, bm);
+        if (minmax) launch_nt<0, false, 3>(p, st, bm, plan);
+        else if (a->partial) launch_nt<0, false, 1>(p, st, bm, plan); else launch_nt<0, false, 0>(p, st, bm, plan);
     }
+    if (plan) return PQ_OK;
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
+extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) { return conv1x1_fwd_impl(a, stream, nullptr); }
+extern "C" int pq_conv1x1_fwd_plan(const pq_conv1x1_fwd_args* a, pq_gemm_plan* out) {
+    PQ_CHECK_ARG(out, "null pointer");
+    return conv1x1_fwd_impl(a, nullptr, out);
+}
 
-extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
+static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_gemm_plan* plan) {
     PQ_CHECK_ARG(a && a->dy.g && a->w && a->dx.g, "null pointer");
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "gradient pitch must be a multiple of 4");
@@ -870,18 +877,24 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int bm = row_bm(a->M, a->I, a->O, 1);
     {
-        const int rc = g2_conv1x1_dgrad(a, bm, st);
+        const int rc = g2_conv1x1_dgrad(a, bm, st, plan);
         if (rc < 0) return rc;
-        if (rc == 1) { PQ_CHECK_LAUNCH(); return PQ_OK; }
+        if (rc == 1) { if (plan) return PQ_OK; PQ_CHECK_LAUNCH(); return PQ_OK; }
     }
     if (a->wt) {        // transposed weights [I][ceil4(O)] (pad columns zero): B rows are K-contiguous like the forward operand
         p.b = a->wt; p.ldb = (a->O + 3) & ~3;
-        if (a->dy.y) launch_nt<2, false, 2>(p, st, bm); else launch_nt<0, false, 2>(p, st, bm);
+        if (a->dy.y) launch_nt<2, false, 2>(p, st, bm, plan); else launch_nt<0, false, 2>(p, st, bm, plan);
     } else {
-        if (a->dy.y) launch_nt<2, true, 2>(p, st, bm); else launch_nt<0, true, 2>(p, st, bm);
+        if (a->dy.y) launch_nt<2, true, 2>(p, st, bm, plan); else launch_nt<0, true, 2>(p, st, bm, plan);
     }
+    if (plan) return PQ_OK;
     PQ_CHECK_LAUNCH();
     return PQ_OK;
+}
+extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) { return conv1x1_dgrad_impl(a, stream, nullptr); }
+extern "C" int pq_conv1x1_dgrad_plan(const pq_conv1x1_dgrad_args* a, pq_gemm_plan* out) {
+    PQ_CHECK_ARG(out, "null pointer");
+    return conv1x1_dgrad_impl(a, nullptr, out);
 }
 
 static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, int& rows) {
@@ -909,8 +922,8 @@ extern "C" int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t 
     return (int64_t)splits * ((int64_t)O * I + O) * 4;
 }
 
-extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
-    PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->dw && a->scratch, "null pointer");
+static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_gemm_plan* plan) {
+    PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->dw && (a->scratch || plan), "null pointer");
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->in.ld & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "pitches must be multiples of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_conv1x1_wgrad: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
@@ -918,9 +931,10 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     {
         int s2 = 0; size_t stride2 = 0;
-        const int rc = g2_conv1x1_wgrad(a, &s2, &stride2, st);
+        const int rc = g2_conv1x1_wgrad(a, &s2, &stride2, st, plan);
         if (rc < 0) return rc;
         if (rc == 1) {
+            if (plan) return PQ_OK;
             PQ_CHECK_LAUNCH();
             const int n0 = a->O * a->I;
             if (s2 <= 64) hipLaunchKernelGGL(slab_reduce_cols_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
@@ -932,6 +946,10 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
         }
     }
     wgrad_plan(a->M, a->I, a->O, big, tiles, splits, rows);
+    if (plan) {
+        *plan = pq_gemm_plan{1, big ? 128 : 64, big ? 128 : 64, 1, (a->dy.y ? 1 : 0) | ((a->in.scale || a->in.act != PQ_ACT_LINEAR) ? 2 : 0), 0, splits, 0};
+        return PQ_OK;
+    }
     GemmTP p{};
     p.dy = a->dy; p.x = a->in; p.slab = a->scratch; p.M = a->M; p.O = a->O; p.I = a->I;
     p.rows_per_split = rows; p.want_bias = a->dbias != nullptr;
@@ -957,4 +975,9 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) {
                        a->dw, n0, a->dbias, n1);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
+}
+extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) { return conv1x1_wgrad_impl(a, stream, nullptr); }
+extern "C" int pq_conv1x1_wgrad_plan(const pq_conv1x1_wgrad_args* a, pq_gemm_plan* out) {
+    PQ_CHECK_ARG(out, "null pointer");
+    return conv1x1_wgrad_impl(a, nullptr, out);
 }

@@ -530,7 +530,8 @@ static bool g2_raise_lds(const void* fn, size_t bytes) {
 }
 
 template <int BM, int BN, int AMODE, int EMODE, int S>
-static int g2_launch_nt(const G2P& p, hipStream_t st) {
+static int g2_launch_nt(const G2P& p, hipStream_t st, pq_gemm_plan* plan) {
+    if (plan) { *plan = pq_gemm_plan{2, BM, BN, S, AMODE, EMODE, 0, 0}; return PQ_OK; }      // query only (pq_conv1x1_*_plan)
     constexpr int NA = AMODE == 2 ? 2 : 1;
     constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);
     constexpr int STAGE = NA * BM * 32 + BN * 32 + 4 * CW;
@@ -554,15 +555,15 @@ static int g2_pick_bn(int M, int N, int bm) {
 }
 
 template <int AMODE, int EMODE>
-static int g2_dispatch_nt(const G2P& p, int bm, hipStream_t st) {
+static int g2_dispatch_nt(const G2P& p, int bm, hipStream_t st, pq_gemm_plan* plan) {
     const int bn = g2_pick_bn(p.M, p.N, bm);
     // ring depth by LDS budget: two workgroups per CU (<= 80 KB each)
     if (AMODE == 2) {
-        if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 3>(p, st) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st);
-        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st);
+        if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
+        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
     }
-    if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st);
-    return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st);
+    if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
+    return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
 }
 
 static bool act_clamp(int act, float& lo, float& hi) {
@@ -575,7 +576,7 @@ static bool act_clamp(int act, float& lo, float& hi) {
 
 // returns 1 when the launch was taken, 0 when the shape / operands are outside this kernel family (caller falls back),
 // < 0 on error
-int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st) {
+int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st, pq_gemm_plan* plan) {
     if (!g2_enabled() || a->sub > 1 || a->in.qstate || (a->I & 15) || a->I < 128 || a->O < 64) return 0;
     if ((a->in.ld & 3) || (((uintptr_t)a->in.x) & 15) || (((uintptr_t)a->w) & 15)) return 0;
     G2P p{};
@@ -586,12 +587,12 @@ int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st) {
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->O; p.K = a->I;
     p.out = a->out; p.bias = a->bias; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     int rc;
-    if (xform) rc = a->partial ? g2_dispatch_nt<1, 1>(p, bm, st) : g2_dispatch_nt<1, 0>(p, bm, st);
-    else rc = a->partial ? g2_dispatch_nt<0, 1>(p, bm, st) : g2_dispatch_nt<0, 0>(p, bm, st);
+    if (xform) rc = a->partial ? g2_dispatch_nt<1, 1>(p, bm, st, plan) : g2_dispatch_nt<1, 0>(p, bm, st, plan);
+    else rc = a->partial ? g2_dispatch_nt<0, 1>(p, bm, st, plan) : g2_dispatch_nt<0, 0>(p, bm, st, plan);
     return rc == PQ_OK ? 1 : rc;
 }
 
-int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st) {
+int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st, pq_gemm_plan* plan) {
     if (!g2_enabled() || a->sub > 1 || !a->wt || (a->O & 15) || a->O < 64 || a->I < 64) return 0;
     const pq_gsink& sk = a->dx;
     const bool stats = sk.mean != nullptr && sk.partial != nullptr;
@@ -603,7 +604,7 @@ int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st) {
     p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
     p.b = a->wt; p.ldb = a->O; p.M = a->M; p.N = a->I; p.K = a->O;      // O % 16 == 0: the transposed rows have no pad
     p.sink = a->dx;
-    const int rc = a->dy.y ? g2_dispatch_nt<2, 2>(p, bm, st) : g2_dispatch_nt<0, 2>(p, bm, st);
+    const int rc = a->dy.y ? g2_dispatch_nt<2, 2>(p, bm, st, plan) : g2_dispatch_nt<0, 2>(p, bm, st, plan);
     return rc == PQ_OK ? 1 : rc;
 }
 
@@ -633,8 +634,9 @@ static G2WPlan g2_wgrad_plan(int M, int I, int O) {
 int g2_wgrad_splits(int M, int I, int O) { const G2WPlan pl = g2_wgrad_plan(M, I, O); return pl.ok ? pl.splits : 0; }
 
 template <bool TWO, bool XA, int NW>
-static int g2_launch_tn_nw(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
+static int g2_launch_tn_nw(const G2TP& p, const G2WPlan& pl, hipStream_t st, pq_gemm_plan* plan) {
     constexpr int S = 3;
+    if (plan) { *plan = pq_gemm_plan{2, 128, 128, S, (TWO ? 1 : 0) | (XA ? 2 : 0), 0, pl.splits, NW}; return PQ_OK; }
     constexpr size_t bytes = (size_t)S * ((TWO ? 2 : 1) * 32 * 128 + 32 * 128) * 4;        // 144 / 96 KiB (>= the 64 KiB epilogue tile)
     static bool ok = g2_raise_lds((const void*)gemm2_tn_kernel<TWO, XA, S, NW>, bytes);
     if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
@@ -642,14 +644,14 @@ static int g2_launch_tn_nw(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
     return PQ_OK;
 }
 template <bool TWO, bool XA>
-static int g2_launch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st) {
+static int g2_launch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st, pq_gemm_plan* plan) {
     static const char* e = getenv("PQ_G2_TN_WAVES");             // 4 | 8 (A/B timing)
-    if (e && e[0] == '8') return g2_launch_tn_nw<TWO, XA, 8>(p, pl, st);
-    return g2_launch_tn_nw<TWO, XA, 4>(p, pl, st);
+    if (e && e[0] == '8') return g2_launch_tn_nw<TWO, XA, 8>(p, pl, st, plan);
+    return g2_launch_tn_nw<TWO, XA, 4>(p, pl, st, plan);
 }
 
 // the GEMM half of pq_conv1x1_wgrad (the caller runs the slab reduction); 1 = taken, 0 = not eligible
-int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* stride_out, hipStream_t st) {
+int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* stride_out, hipStream_t st, pq_gemm_plan* plan) {
     if (a->sub > 1 || a->dbias || a->in.qstate) return 0;
     const G2WPlan pl = g2_wgrad_plan(a->M, a->I, a->O);
     if (!pl.ok) return 0;
@@ -663,8 +665,8 @@ int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* st
     p.slab = a->scratch; p.slab_stride = (size_t)a->O * a->I + a->O;
     p.M = a->M; p.O = a->O; p.I = a->I; p.rows_per_split = pl.rows;
     int rc;
-    if (a->dy.y) rc = xa ? g2_launch_tn<true, true>(p, pl, st) : g2_launch_tn<true, false>(p, pl, st);
-    else rc = xa ? g2_launch_tn<false, true>(p, pl, st) : g2_launch_tn<false, false>(p, pl, st);
+    if (a->dy.y) rc = xa ? g2_launch_tn<true, true>(p, pl, st, plan) : g2_launch_tn<true, false>(p, pl, st, plan);
+    else rc = xa ? g2_launch_tn<false, true>(p, pl, st, plan) : g2_launch_tn<false, false>(p, pl, st, plan);
     if (rc != PQ_OK) return rc;
     *splits_out = pl.splits;
     *stride_out = p.slab_stride;

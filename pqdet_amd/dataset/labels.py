@@ -31,7 +31,10 @@ def create_label(bboxes: Sequence[np.ndarray], output_sizes: np.ndarray, num_cla
     for gmap in grids:
         gmap[..., -1] = 1.0                                       # mix-up weight defaults to 1
     lists: List[List[np.ndarray]] = [[], [], []]
-    boxes = np.asarray(bboxes, dtype=np.float32).reshape(-1, 6)
+    boxes = np.asarray(bboxes)                 # the boxes' own dtype decides the arithmetic, as in the reference's per-box loop:
+    if boxes.dtype not in (np.float32, np.float64):   # float64 boxes take centres, // strides and the anchor IoU in float64
+        boxes = boxes.astype(np.float32)
+    boxes = boxes.reshape(-1, 6)
     n = boxes.shape[0]
     if n == 0:
         return (*grids, *lists)

@@ -166,7 +166,9 @@ class Plan:
         return t
 
     def _bn_scratch(self, C_):
-        """(scratch, tickets) shared by every BN finalize of this plan (all are issued on the main stream, in order)."""
+        """(scratch, tickets) shared by every BN finalize that runs on the MAIN stream (issued in order, so one set serves them
+        all).  Finalizes of the two-stream forward's side layers run concurrently with them and therefore never get this
+        scratch: _emit_forward clears their pointers (single-block path, their partial lists are short)."""
         l = lib()
         need, nt = l.pq_bn_finalize_scratch_bytes(C_), l.pq_bn_finalize_tickets(C_)
         cur = getattr(self, '_bnfin', None)
@@ -628,15 +630,21 @@ class Plan:
                 side_layers = set()
                 for i, m, a in sorted(heads, key=lambda h: h[0])[:-1]:
                     j = i - 1
-                    while j >= 0 and mods[j]._type == 'convolutional' and (j == i - 1 or self._consumers.get(j, 0) == 1):
+                    # a branch layer's ONLY consumer is the next branch layer (the head conv's: its yolo layer), so nothing on
+                    # the main stream ever reads a tensor written on the side stream before the join at the end of the forward
+                    while j >= 0 and mods[j]._type == 'convolutional' and self._consumers.get(j, 0) == 1:
                         side_layers.add(j)
                         j -= 1
                 self.fwd_layer += [-1] * (len(self.fwd) - len(self.fwd_layer))
                 for k, layer in enumerate(self.fwd_layer):
                     if layer in side_layers or self.fwd[k].code == abi.OP_LOSS_FWD:
                         self.fwd[k].flags = abi.OPF_SIDE
+                        if self.fwd[k].code == abi.OP_BN_FWD_FIN:       # never the main stream's reduction scratch / tickets
+                            self.fwd[k].u.bnf.scratch = None
+                            self.fwd[k].u.bnf.tickets = None
                 self.fwd_two_streams = True
                 self.fwd_side_layers = sorted(side_layers)
+                self._check_side_forward()
         else:
             rows_total = sum(a.H * a.W * (a.C // (5 + m.opt['classes'])) for _, m, a in heads)
             nv = 5 + heads[0][1].opt['classes']
@@ -649,6 +657,33 @@ class Plan:
                 d = abi.Decode(view, ptr(self.eval_out), B, a.H, a.W, A, opt['classes'], opt['stride'], rows_total, row0)
                 self._op(self.fwd, abi.OP_DECODE, d)
                 row0 += a.H * a.W * A
+
+    def _check_side_forward(self):
+        """Plan-level proof of the two-stream forward's race freedom: every buffer a side op writes is read only by LATER side
+        ops (or by the backward, after the join), and no side op shares reduction scratch with a main-stream op."""
+        side_written = {}
+        for k, op in enumerate(self.fwd):
+            side = bool(op.flags & abi.OPF_SIDE)
+            a = getattr(op.u, abi.OP_FIELD[op.code])
+            reads = []
+            if op.code in (abi.OP_CONV1X1_FWD, abi.OP_DW_FWD, abi.OP_GCONV_FWD, abi.OP_QACT_FWD):
+                reads.append(a.inp.x)
+            elif op.code == abi.OP_COPY_FWD:
+                reads += [a.a.x, a.b.x]
+            elif op.code == abi.OP_POOL_REDUCE:
+                reads.append(a.a.x)
+            elif op.code == abi.OP_LOSS_FWD:
+                reads.append(a.inp.base)
+            for r in reads:
+                if r and r in side_written and not side:
+                    raise RuntimeError('internal: forward op %d on the main stream reads a tensor written by side-stream op %d'
+                                       % (k, side_written[r]))
+            if side:
+                out = getattr(a, 'out', None)
+                if out:
+                    side_written[out] = k
+                if op.code == abi.OP_BN_FWD_FIN and (a.scratch or a.tickets):
+                    raise RuntimeError('internal: side-stream BatchNorm finalize %d shares the main stream\'s scratch' % k)
 
     def _emit_qat_weight_ops(self, flat, mods):
         """One table for every conv layer: forward = scale by gamma/sqrt(running_var+eps), observe, fake-quantise (first op

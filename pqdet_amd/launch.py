@@ -51,9 +51,33 @@ def _spawn(nproc: int, argv) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, '-m', 'pqdet_amd.launch'] + argv, env=env))
+    return wait_ranks(procs)
+
+
+def wait_ranks(procs, poll_s: float = 0.2, grace_s: float = 10.0) -> int:
+    """Wait for the rank processes.  The first rank that exits non-zero ends the job: its peers would block for ever in a
+    collective it never joins, so they are terminated (killed after ``grace_s``) and that exit code is returned."""
+    import time
+    live = list(procs)
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    while live and rc == 0:
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                rc = rc or r
+        if live and rc == 0:
+            time.sleep(poll_s)
+    if live:
+        for p in live:
+            p.terminate()
+        deadline = time.monotonic() + grace_s
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
     return rc
 
 
@@ -84,14 +108,14 @@ def main(argv=None) -> int:
     install_aliases()
     sys.argv = [ns.script] + ns.args
     sys.path.insert(0, os.path.dirname(os.path.abspath(ns.script)))
-    try:
-        runpy.run_path(ns.script, run_name='__main__')
-    finally:
-        if world > 1:
-            import torch.distributed as dist
-            if dist.is_initialized():
-                dist.barrier()
-                dist.destroy_process_group()
+    # a driver that raises (or exits non-zero) must NOT enter the closing barrier: its peers are inside other collectives and
+    # would never match it; this rank exits non-zero instead and the parent ends the job (wait_ranks)
+    runpy.run_path(ns.script, run_name='__main__')
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
     return 0
 
 

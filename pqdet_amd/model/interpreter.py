@@ -160,7 +160,10 @@ class AnyModel(nn.Module):
         return nn.Module.state_dict(self)
 
     def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
-        if not self._qat:
+        """Prepared QAT models: DETACHED CPU copies under the reference's checkpoint keys (``reference_state_dict``; building it
+        synchronises with the device).  ``keep_vars=True`` asks for the live tensors, which only exist under this module's own
+        names: it returns :meth:`plain_state_dict` (an EMA / anything that mutates the returned tensors wants that one)."""
+        if not self._qat or keep_vars:
             return nn.Module.state_dict(self, *args, destination=destination, prefix=prefix, keep_vars=keep_vars)
         from .. import tools
         if destination is None:
@@ -170,11 +173,22 @@ class AnyModel(nn.Module):
             destination[prefix + k] = v
         return destination
 
+    def reference_state_dict(self):
+        """The reference-format export of a prepared QAT model (what ``state_dict()`` returns for it), by its own name."""
+        from .. import tools
+        return tools.qat_state_dict(self)
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         if self._qat and '_qat_state' not in state_dict:
             from .. import tools
+            want = set(tools.qat_state_dict(self))
+            have = set(k[len('module.'):] if k.startswith('module.') else k for k in state_dict)
+            missing, unexpected = sorted(want - have), sorted(have - want)
+            if strict and (missing or unexpected):
+                raise RuntimeError('Error(s) in loading state_dict for %s (reference QAT layout): missing keys %s, unexpected '
+                                   'keys %s' % (type(self).__name__, missing[:5], unexpected[:5]))
             tools.load_qat_state_dict(self, state_dict)
-            return torch.nn.modules.module._IncompatibleKeys([], [])
+            return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
         out = nn.Module.load_state_dict(self, state_dict, strict=strict, **kw)
         self._plans.clear()
         return out

@@ -53,3 +53,14 @@ def r2_names():
 def g12():
     with open(os.path.join(GOLDEN_DIR, 'g12_checkpoints.json')) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def golden_r3():
+    return np.load(os.path.join(GOLDEN_DIR, 'golden_r3.npz'))
+
+
+@pytest.fixture(scope='session')
+def r3_names():
+    with open(os.path.join(GOLDEN_DIR, 'g_r3_names.json')) as f:
+        return json.load(f)

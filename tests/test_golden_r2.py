@@ -13,7 +13,7 @@ from oracle.net import OracleNet
 from pqdet_amd.model import zoo
 from seedfill import seeded_boxes, seeded_fill, seeded_images
 
-CFG = {'mbv2': 'mobilenetv2-fpn', 'rxfpn': 'regnetx-600m-fpn'}
+CFG = {'mbv2': 'mobilenetv2-fpn', 'rxfpn': 'regnetx-600m-fpn', 'rxpan': 'regnetx-600m-pan'}
 
 
 def _targets(batch, size, ncls, seed):
@@ -45,8 +45,16 @@ def _check_g5b(net, out, golden_r2, r2_names, tag, tol_loss, tol_grad):
         assert _relerr(params[name].grad, golden_r2[key]) < tol_grad, name
 
 
-@pytest.mark.parametrize('tag', ['mbv2', 'rxfpn'])
-def test_oracle_meets_reference_eval_bn_gradients(golden_r2, r2_names, tag):
+def _fixture(tag, golden_r2, r2_names, golden_r3, r3_names):
+    """G5b of the two round-2 nets lives in golden_r2.npz; regnetx-600m-pan (round 3, make_golden_r3.py: 16 full gradient
+    tensors incl. the strided projection, both stride-2 grouped convs of the bottom-up path and the conv behind every
+    two-input route) in golden_r3.npz."""
+    return (golden_r3, r3_names) if tag == 'rxpan' else (golden_r2, r2_names)
+
+
+@pytest.mark.parametrize('tag', ['mbv2', 'rxfpn', 'rxpan'])
+def test_oracle_meets_reference_eval_bn_gradients(golden_r2, r2_names, golden_r3, r3_names, tag):
+    golden_r2, r2_names = _fixture(tag, golden_r2, r2_names, golden_r3, r3_names)
     torch.set_num_threads(8)
     net = OracleNet(io.StringIO(zoo.cfg_text(CFG[tag])))
     seeded_fill(net, 5)
@@ -65,11 +73,12 @@ def test_oracle_ciou_without_nan(golden_r2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['mbv2', 'rxfpn'])
-def test_hip_meets_reference_eval_bn_gradients(golden_r2, r2_names, tag):
+@pytest.mark.parametrize('tag', ['mbv2', 'rxfpn', 'rxpan'])
+def test_hip_meets_reference_eval_bn_gradients(golden_r2, r2_names, golden_r3, r3_names, tag):
     """The reference's own gradients (BatchNorm on running statistics: no batch-statistics amplification of fp32 round-off)
     at 5e-3 norm-wise for every stored tensor and every parameter norm; losses at 1e-3 (north_star)."""
     from pqdet_amd.model.interpreter import DetectionModel
+    golden_r2, r2_names = _fixture(tag, golden_r2, r2_names, golden_r3, r3_names)
     net = DetectionModel(io.StringIO(zoo.cfg_text(CFG[tag])))
     seeded_fill(net, 5)
     net = net.to('cuda')

@@ -3,6 +3,7 @@ bookkeeping (G11), the in-repo NumPy NMS (G7).  No GPU needed."""
 import types
 
 import numpy as np
+import pytest
 
 from pqdet_amd import schedule, tools
 from pqdet_amd.eval import Evaluator, average_precision
@@ -86,3 +87,27 @@ def test_qat_checkpoint_layout_matches_reference_and_round_trips():
     assert torch.equal(other._qat_state, net._qat_state)
     for (k1, v1), (_, v2) in zip(net.state_dict().items(), other.state_dict().items()):
         assert torch.equal(v1, v2), k1
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_vectorised_create_label_keeps_the_boxes_dtype_like_the_reference_loop(dtype):
+    """dataset/train_dataset.py:109-150 computes centres, `// strides` and the anchor IoUs in whatever dtype the sample getter
+    delivers.  Boxes whose centres sit a float32 ulp away from a cell boundary must land in the same cells as the per-box
+    loop (oracle.postprocess.create_label, pinned by G8) -- for float32 AND float64 input."""
+    from oracle import postprocess as opost
+    from pqdet_amd.dataset import labels
+    rng = np.random.RandomState(11)
+    hw = np.array([[64, 64], [32, 32], [16, 16]])
+    rows = []
+    for k in range(64):
+        cx, cy = rng.randint(1, 15, 2) * 32.0                 # centres on cell boundaries of every scale ...
+        eps = (rng.rand(2) - 0.5) * 4e-5                      # ... nudged by less than a float32 ulp of the coordinate
+        w, h = rng.uniform(8, 200, 2)
+        x1, y1 = cx + eps[0] - w / 2, cy + eps[1] - h / 2
+        rows.append([x1, y1, x1 + w, y1 + h, rng.randint(0, 20), rng.uniform(0.5, 1.0)])
+    boxes = [np.array(r, dtype=dtype) for r in rows]
+    want = opost.create_label(boxes, hw, 20)
+    got = labels.create_label(boxes, hw, 20)
+    for i in range(3):
+        np.testing.assert_array_equal(got[i], want[i])
+        np.testing.assert_array_equal(np.asarray(got[3 + i], np.float32).reshape(-1, 4), np.asarray(want[3 + i], np.float32).reshape(-1, 4))

@@ -49,6 +49,16 @@ def close(got, want, rt=RT, at=AT, what=''):
         assert rel < 2e-5, '%s relative norm error %g' % (what, rel)
 
 
+def gemm_plan(kind, args, expect=None):
+    """The kernel instantiation this call launches (pq_conv1x1_*_plan); `expect` pins it, so that a dispatch rule cannot
+    silently send the case to another kernel."""
+    pl = abi.GemmPlan()
+    abi.check(getattr(abi.lib(), 'pq_conv1x1_%s_plan' % kind)(C.byref(args), C.byref(pl)))
+    if expect is not None:
+        assert pl.key() == tuple(expect), 'launch goes to %s, the case was written for %s' % (pl.key(), tuple(expect))
+    return pl.key()
+
+
 def rnd(*shape, g, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
@@ -81,7 +91,7 @@ def reduce_partial(partial, nblk, ldp, C_):
     (1000, 240, 240, 1, True, True, True),
     (515, 176, 80, 0, False, False, True),        # ... with the raw operand (no transform to hide behind)
 ])
-def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
+def test_conv1x1_fwd(M, I, O, act, affine, bias, stats, expect=None):
     g = torch.Generator().manual_seed(M + I + O)
     x = rnd(M, I, g=g)
     w = rnd(O, I, g=g, scale=1 / math.sqrt(I))
@@ -107,6 +117,7 @@ def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
         bd = b.to(DEV)
         keep.append(bd)
         a.bias = bd.data_ptr()
+    plan = gemm_plan('fwd', a, expect)
     abi.check(abi.lib().pq_conv1x1_fwd(C.byref(a), stream()))
     torch.cuda.synchronize()
     close(out[:, :O], want, what='conv1x1 out')
@@ -115,21 +126,33 @@ def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
         s1, s2 = reduce_partial(partial, nblk, ldp, O)
         close(s1.float(), want.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum')
         close(s2.float(), (want.double() ** 2).sum(0).float(), rt=1e-3, at=1e-2, what='sumsq')
+    return plan
 
 
-def test_conv1x1_fwd_strided_rows():
-    g = torch.Generator().manual_seed(5)
-    B, IH, IW, I, O = 2, 6, 10, 16, 24
+@pytest.mark.parametrize('B,IH,IW,I,O', [(2, 6, 10, 16, 24)])
+def test_conv1x1_fwd_strided_rows(B, IH, IW, I, O, act=0, stats=False, expect=None):
+    g = torch.Generator().manual_seed(5 + I + O)
     x = rnd(B, IH, IW, I, g=g)
-    w = rnd(O, I, g=g)
-    want = F.conv2d(x.permute(0, 3, 1, 2), w.view(O, I, 1, 1), stride=2).permute(0, 2, 3, 1)
+    w = rnd(O, I, g=g, scale=1 / math.sqrt(I))
+    want = F.conv2d(act_ref(x, act).permute(0, 3, 1, 2), w.view(O, I, 1, 1), stride=2).permute(0, 2, 3, 1)
     OH, OW = want.shape[1:3]
-    out = torch.empty(B * OH * OW, O, device=DEV)
+    M = B * OH * OW
+    out = torch.empty(M, O, device=DEV)
     xd, wd = x.to(DEV), w.to(DEV)
-    a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, 0), wd.data_ptr(), None, out.data_ptr(), None,
-                       B * OH * OW, I, O, O, 0, 2, OH, OW, IH, IW)
+    nblk = abi.lib().pq_conv1x1_blocks_k(M, O, I, 0)
+    ldp = (O + 15) // 16 * 16
+    partial = torch.zeros(nblk * 2 * ldp, device=DEV) if stats else None
+    a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, act), wd.data_ptr(), None, out.data_ptr(), abi.ptr(partial),
+                       M, I, O, O, ldp if stats else 0, 2, OH, OW, IH, IW)
+    plan = gemm_plan('fwd', a, expect)
     abi.check(abi.lib().pq_conv1x1_fwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
     close(out.view(B, OH, OW, O), want, what='strided 1x1')
+    if stats:
+        s1, s2 = reduce_partial(partial, nblk, ldp, O)
+        close(s1.float(), want.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='strided sum')
+        close(s2.float(), (want.double() ** 2).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='strided sumsq')
+    return plan
 
 
 # ----------------------------------------------------------------------------------------------- conv1x1 backward
@@ -160,7 +183,7 @@ def _bn_bwd_coeffs(g_, y, gamma, eps=1e-5):
     (1000, 240, 80, True, 0, True, True),
     (515, 176, 240, False, 1, False, True),       # ... one-tensor gradient operand
 ])
-def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
+def test_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=None):
     g = torch.Generator().manual_seed(M + I + O + 1)
     gy = rnd(M, O, g=g)
     yout = rnd(M, O, g=g) + 0.3
@@ -199,6 +222,7 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
                      sv[2].data_ptr() if stats else None, sv[3].data_ptr() if stats else None,
                      partial.data_ptr() if stats else None, I, I, act, int(accum), 1, ldp)
     a.M, a.I, a.O = M, I, O
+    plans = [gemm_plan('dgrad', a, expect)]
     abi.check(abi.lib().pq_conv1x1_dgrad(C.byref(a), stream()))
     torch.cuda.synchronize()
     close(gdst, gout, what='dgrad sink')
@@ -222,9 +246,16 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
         g2 = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
         a.dx.g = g2.data_ptr()
         a.wt = wt.data_ptr()
+        partial.zero_()
+        plans.append(gemm_plan('dgrad', a, expect_wt))
         abi.check(abi.lib().pq_conv1x1_dgrad(C.byref(a), stream()))
         torch.cuda.synchronize()
         close(g2, gout, what='dgrad sink (transposed weights)')
+        if stats:
+            s1, s2 = reduce_partial(partial, nblk, ldp, I)
+            close(s1.float(), gout.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum g (transposed weights)')
+            close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat (transposed weights)')
+    return plans
 
 
 @pytest.mark.parametrize('M,I,O,two,bias', [(3000, 32, 16, True, False), (1000, 24, 144, True, False),
@@ -235,14 +266,14 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
                                             (4096, 256, 512, True, False), (1024, 224, 120, True, False),
                                             (2048, 128, 96, False, False), (160, 96, 576, True, False),
                                             (16384, 352, 256, True, False)])
-def test_conv1x1_wgrad(M, I, O, two, bias):
+def test_conv1x1_wgrad(M, I, O, two, bias, xa=True, expect=None):
     g = torch.Generator().manual_seed(M + I + O + 2)
     gy = rnd(M, O, g=g)
     yout = rnd(M, O, g=g) + 0.3
     gamma = torch.rand(O, generator=g) + 0.5
     x = rnd(M, I, g=g)
     sc, sh = torch.rand(I, generator=g) + 0.5, rnd(I, g=g, scale=0.3)
-    xin = (x * sc + sh).clamp(0, 6)
+    xin = (x * sc + sh).clamp(0, 6) if xa else x
     ldg = (O + 3) // 4 * 4
     if two:
         p, q, mu, r, _ = _bn_bwd_coeffs(gy, yout, gamma)
@@ -263,14 +294,16 @@ def test_conv1x1_wgrad(M, I, O, two, bias):
     db = torch.full((O,), float('nan'), device=DEV) if bias else None
     a = abi.Conv1x1Wgrad()
     a.dy = abi.GSrc(gyd.data_ptr(), youtd.data_ptr() if two else None, *([v.data_ptr() for v in vecs] if two else [None] * 4), ldg, ldg)
-    a.inp = abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), I, 2)
+    a.inp = abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), I, 2) if xa else abi.Src(xd.data_ptr(), None, None, I, 0)
     a.dw, a.dbias, a.scratch = dw.data_ptr(), abi.ptr(db), scratch.data_ptr()
     a.M, a.I, a.O = M, I, O
+    plan = gemm_plan('wgrad', a, expect)
     abi.check(l.pq_conv1x1_wgrad(C.byref(a), stream()))
     torch.cuda.synchronize()
     close(dw, want.float(), rt=1e-3, at=1e-3, what='wgrad')
     if bias:
         close(db, dy.double().sum(0).float(), rt=1e-3, at=1e-3, what='bias grad')
+    return plan
 
 
 @pytest.mark.parametrize('M,I,O,two,act,accum,stats', [
@@ -422,7 +455,11 @@ def test_conv1x1_bwd_fused_rejects_shapes_outside_its_range():
                                              (1, 5, 9, 576, 2), (2, 40, 36, 48, 2), (1, 33, 50, 16, 1),
                                              # pruned nets: channel counts that are not multiples of 4 (pitch = ceil4)
                                              (2, 9, 13, 25, 1), (2, 10, 14, 95, 2), (1, 12, 12, 142, 1), (2, 70, 66, 25, 1),
-                                             (1, 72, 68, 95, 2)])
+                                             (1, 72, 68, 95, 2),
+                                             # plane sizes of the 512 x 512 benchmark step: the dispatch picks its streaming / column-walk
+                                             # (>= 256 x 256, dw_dgrad_s1_walk_kernel) / LDS-tiled kernels by plane size
+                                             (1, 256, 256, 32, 1), (1, 256, 256, 96, 2), (1, 128, 128, 144, 1), (1, 128, 128, 144, 2),
+                                             (2, 64, 64, 192, 1), (2, 64, 64, 192, 2), (2, 32, 32, 384, 1), (2, 16, 16, 960, 1)])
 def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     g = torch.Generator().manual_seed(B * H * W + Cc)
     l = abi.lib()
@@ -609,45 +646,60 @@ def test_gconv3x3_fwd_bwd(B, H, W, Cc, gw, stride):
     close(dw, wr.grad, rt=1e-3, at=1e-3, what='gconv wgrad')
 
 
-def test_conv1x1_strided_backward():
+@pytest.mark.parametrize('B,H,W,I,O,two', [(2, 10, 14, 32, 48, False), (2, 10, 14, 32, 48, True)])
+def test_conv1x1_strided_backward(B, H, W, I, O, two, expect=None, expect_w=None):
     """Backward of a stride-2 1x1 conv: dz scatters (accumulating) onto every second pixel, the weight gradient gathers them."""
-    g = torch.Generator().manual_seed(77)
+    g = torch.Generator().manual_seed(77 + I + O)
     l = abi.lib()
-    B, H, W, I, O, s = 2, 10, 14, 32, 48, 2
+    s = 2
     OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    M = B * OH * OW
     x = rnd(B, H, W, I, g=g)
-    w = rnd(O, I, g=g, scale=0.3)
+    w = rnd(O, I, g=g, scale=1 / math.sqrt(O))
     gy = rnd(B, OH, OW, O, g=g)
+    yout = rnd(B, OH, OW, O, g=g) + 0.3
     prev = rnd(B, H, W, I, g=g)
+    if two:
+        p, q, mu, r, _ = _bn_bwd_coeffs(gy.view(M, O), yout.view(M, O), torch.rand(O, generator=g) + 0.5)
+        dy = p * gy + q * (yout - mu) + r
+    else:
+        dy = gy
     xin = x.clamp(min=0).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
     wr = w.clone().view(O, I, 1, 1).requires_grad_(True)
     y = F.conv2d(xin, wr, stride=s)
-    y.backward(gy.permute(0, 3, 1, 2))
+    y.backward(dy.permute(0, 3, 1, 2))
     want = prev + xin.grad.permute(0, 2, 3, 1)
-    xd, wd, gyd = x.to(DEV), w.to(DEV), gy.to(DEV)
+    xd, wd, gyd, youtd = x.to(DEV), w.to(DEV), gy.to(DEV), yout.to(DEV)
+    vecs = [chan_vec(v) for v in ((p, q, mu, r) if two else ())]
     gdst = prev.to(DEV).clone()
+    wt = wd.t().contiguous()                               # O % 4 == 0 in every case: rows of ceil4(O) floats without pad
+    assert O % 4 == 0
     d = abi.Conv1x1Dgrad()
-    d.dy = abi.GSrc(gyd.data_ptr(), None, None, None, None, None, O, O)
+    d.dy = abi.GSrc(gyd.data_ptr(), youtd.data_ptr() if two else None, *([v.data_ptr() for v in vecs] if two else [None] * 4), O, O)
     d.w = wd.data_ptr()
+    d.wt = wt.data_ptr()
     d.dx = abi.GSink(gdst.data_ptr(), None, None, None, None, None, None, I, I, 0, 1, 0, 0)
-    d.M, d.I, d.O = B * OH * OW, I, O
+    d.M, d.I, d.O = M, I, O
     d.sub, d.OH, d.OW, d.IH, d.IW = s, OH, OW, H, W
+    plans = [gemm_plan('dgrad', d, expect)]
     abi.check(l.pq_conv1x1_dgrad(C.byref(d), stream()))
     torch.cuda.synchronize()
     close(gdst, want, what='strided dgrad')
     d.dx.finalize = 1
     assert l.pq_conv1x1_dgrad(C.byref(d), stream()) == -1          # must be accumulate-only
-    scratch = torch.empty(l.pq_conv1x1_wgrad_scratch_bytes(B * OH * OW, I, O) // 4, device=DEV)
+    scratch = torch.empty(l.pq_conv1x1_wgrad_scratch_bytes(M, I, O) // 4, device=DEV)
     dw = torch.full((O, I), float('nan'), device=DEV)
     wg = abi.Conv1x1Wgrad()
     wg.dy = d.dy
     wg.inp = abi.Src(xd.data_ptr(), None, None, I, 1)
     wg.dw, wg.scratch = dw.data_ptr(), scratch.data_ptr()
-    wg.M, wg.I, wg.O = B * OH * OW, I, O
+    wg.M, wg.I, wg.O = M, I, O
     wg.sub, wg.OH, wg.OW, wg.IH, wg.IW = s, OH, OW, H, W
+    plans.append(gemm_plan('wgrad', wg, expect_w))
     abi.check(l.pq_conv1x1_wgrad(C.byref(wg), stream()))
     torch.cuda.synchronize()
     close(dw, wr.grad.view(O, I), rt=1e-3, at=1e-3, what='strided wgrad')
+    return plans
 
 
 @pytest.mark.parametrize('B,H,W,O,stride', [(2, 16, 20, 32, 2), (1, 9, 9, 16, 1)])
