@@ -213,7 +213,10 @@ typedef struct pq_dw3x3_bwd_args {
     float* scratch;      /* >= pq_dw3x3_bwd_scratch_bytes */
     int32_t B, IH, IW, OH, OW, C, stride;
     int32_t part;        /* 0: both gradients in one kernel; stride 1 also 1: input gradient only (dw, scratch, in unused),
-                            2: weight gradient only (w, dx unused) -- lets the weight half run on another stream */
+                            2: weight gradient only (w, dx unused) -- lets the weight half run on another stream;
+                            3: both gradients from ONE staging of (g, y_out) and of the layer input (needs in.x == dx.y, i.e. the
+                               sink is the conv's input tensor): per-block weight-gradient rows are left in `scratch`;
+                            4: reduce those rows into dw (the only launch that may then run on another stream) */
 } pq_dw3x3_bwd_args;
 int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream);
 int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t C, int32_t stride);
@@ -422,6 +425,15 @@ typedef struct pq_yolo_loss_args {
     int64_t gsb, gsh, gsw, gsc;
     int32_t B, H, W, A, C, M, stride, box_loss, from_raw;
     float ignore_thresh, l1_gain;
+    /* whole-step glue (all optional; the reference sums the per-head 4-tuples in DetectionModel.forward, model/interpreter.py:77-85):
+     * forward: `losses` is row `head_slot` of an [n_heads][4] table; with totals != NULL this call -- which must be the LAST of
+     * the table's heads in stream order -- also writes totals[0..3] = the column sums of the table and totals[4 + h] = head h's
+     * total, i.e. the dict DetectionModel.forward returns, in one buffer;
+     * backward (used when gscale == NULL): upstream gradient SCALARS w.r.t. totals[0..3] and totals[4 + head_slot]; any may be
+     * NULL (= 0).  The weights of (box, conf, cls) are gup[0] + gup[1 | 2 | 3] + gup[4]. */
+    float* totals;
+    int32_t head_slot, n_heads;
+    const float* gup[5];
 } pq_yolo_loss_args;
 int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream);
 int pq_yolo_loss_bwd(const pq_yolo_loss_args* a, void* stream);
@@ -575,6 +587,7 @@ enum {
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
+#define PQ_OPF_JOIN 2   /* main-stream op that reads what side-stream ops wrote: `stream` waits for the side stream before it */
 typedef struct pq_op {
     int32_t code;
     int32_t flags;

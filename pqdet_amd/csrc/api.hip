@@ -148,12 +148,26 @@ extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side
         return PQ_OK;
     };
     const bool bind = bind_events();
+    bool side_dirty = false;             // side-stream work issued since the last join
+    auto join = [&]() -> int {
+        { const int rc = flush(); if (rc != PQ_OK) return rc; }
+        if (used_side && side_dirty) {
+            hipEvent_t e = ev[next]; next = (next + 1) & 63;
+            if (hipEventRecord(e, side_s) != hipSuccess || hipStreamWaitEvent(main_s, e, 0) != hipSuccess) {
+                pq_set_error("pq_run_ops2: join failed"); return PQ_ELAUNCH;
+            }
+            side_dirty = false;
+        }
+        return PQ_OK;
+    };
     for (int i = 0; i < n; ++i) {
         if (ops[i].flags & PQ_OPF_SIDE) {
             parked[nparked++] = i;
+            side_dirty = true;
             if (nparked >= group) { const int rc = flush(); if (rc != PQ_OK) return rc; }
             continue;
         }
+        if (ops[i].flags & PQ_OPF_JOIN) { const int rc = join(); if (rc != PQ_OK) return rc; }
         // the op after this one releases the parked group: offer the fork event to this op's kernel launch
         const bool forks_next = bind && i + 1 < n && (ops[i + 1].flags & PQ_OPF_SIDE) && nparked + 1 >= group;
         bound = nullptr;
@@ -166,14 +180,7 @@ extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side
         }
         if (rc != PQ_OK) { g_failed_op = i; return rc; }
     }
-    { const int rc = flush(); if (rc != PQ_OK) return rc; }
-    if (used_side) {
-        hipEvent_t e = ev[next]; next = (next + 1) & 63;
-        if (hipEventRecord(e, side_s) != hipSuccess || hipStreamWaitEvent(main_s, e, 0) != hipSuccess) {
-            pq_set_error("pq_run_ops2: join failed"); return PQ_ELAUNCH;
-        }
-    }
-    return PQ_OK;
+    return join();
 }
 
 extern "C" int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms) {
@@ -218,10 +225,17 @@ extern "C" int pq_run_ops2_timed(const pq_op* ops, int32_t n, void* stream, void
     }
     hipStream_t main_s = (hipStream_t)stream, side_s = (hipStream_t)side_stream;
     hipEvent_t fork = ev[2 * n], join = ev[2 * n + 1];
-    bool used_side = false, main_dirty = true;
+    bool used_side = false, main_dirty = true, side_dirty = false;
     for (int i = 0; i < n; ++i) {
         const bool side = (ops[i].flags & PQ_OPF_SIDE) != 0;
+        if (!side && (ops[i].flags & PQ_OPF_JOIN) && side_dirty) {
+            if (hipEventRecord(join, side_s) != hipSuccess || hipStreamWaitEvent(main_s, join, 0) != hipSuccess) {
+                pq_set_error("pq_run_ops2_timed: join failed"); g_failed_op = i; return PQ_ELAUNCH;
+            }
+            side_dirty = false;
+        }
         if (side) {
+            side_dirty = true;
             if (main_dirty) {
                 // one reusable fork event is enough here: hipStreamWaitEvent captures the record that precedes it
                 if (hipEventRecord(fork, main_s) != hipSuccess || hipStreamWaitEvent(side_s, fork, 0) != hipSuccess) {
@@ -239,7 +253,7 @@ extern "C" int pq_run_ops2_timed(const pq_op* ops, int32_t n, void* stream, void
         if (rc != PQ_OK) { g_failed_op = i; return rc; }
         (void)hipEventRecord(ev[2 * i + 1], st);
     }
-    if (used_side) {
+    if (used_side && side_dirty) {
         if (hipEventRecord(join, side_s) != hipSuccess || hipStreamWaitEvent(main_s, join, 0) != hipSuccess) {
             pq_set_error("pq_run_ops2_timed: join failed"); return PQ_ELAUNCH;
         }

@@ -369,6 +369,147 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
     }
 }
 
+// Stride 1, ONE staging for both gradients (PART 3 of pq_dw3x3_bwd): the dy' tile (10 x 18, transformed while it is staged)
+// and the RAW layer input y (10 x 18) -- which is both the weight gradient's operand (x' = act(scale * y + shift), applied at
+// the fragment read; pixels outside the image are zero padding and masked there) and the gradient sink's y (activation
+// derivative, BatchNorm-backward sums), so the input tensor is read once instead of three times (tile + halo in the
+// weight-gradient launch, centre pixels in the sink of the input-gradient launch) and (g, y_out) once instead of twice.
+// Requires in.x == dx.y (the engine's case: the sink IS the conv's input tensor).  All loads of a lane are issued before the
+// first LDS write.  The 9 weight-gradient taps of the block leave in one LDS round (the tile buffers are reused).
+__global__ __launch_bounds__(256, 2) void dwt_bwd_s1_fused_kernel(DwTP p) {
+    constexpr int TH = 8, TWD = 16, PH = TH + 2, PW = TWD + 2, NPX = PH * PW;       // 180 staged pixels per tensor
+    constexpr int NIT = (NPX + 31) / 32;                                             // 6 pixels per pixel lane
+    __shared__ float4 dyt[NPX * PQP];
+    __shared__ float4 xt[NPX * PQP];
+    __shared__ float red[32 * 8 * 8];
+    static_assert(NPX * PQP >= 5 * 32 * 8, "tap reduction reuses the tile buffers (5 + 4 taps)");
+    const int t = threadIdx.x;
+    const int q = t & 7, pl = t >> 3;
+    int tIdx, bcy;
+    xcd_block(tIdx, bcy);
+    const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
+    const int y0 = th * TH, x0 = tw * TWD;
+    const int cq0 = bcy * CBQ;
+    const int c0 = (cq0 + q) * 4;
+    const bool cok = cq0 + q < p.C4;
+    const int cc = cok ? c0 : 0;
+    const int row = pl >> 2, col0 = (pl & 3) * 4;
+    const GsrcCoef4 gk = gsrc_coef4(p.dy, cc, p.C);
+    const SrcCoef4 xk = src_coef4(p.in, cc, p.C);
+    const SinkCoef4 sk = sink_coef4(p.sink, cc, p.C);
+
+    // ---- every load of this lane first: (g, y_out, y_in) of its 6 staged pixels, the running gradient of its 4 owned pixels
+    float4 rg[NIT], ry[NIT], rx[NIT], gacc[4];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int pix = min(pl + 32 * u, NPX - 1);
+        const int py = pix / PW, px = pix % PW;
+        const int yy = min(max(y0 - 1 + py, 0), p.IH - 1), xx = min(max(x0 - 1 + px, 0), p.IW - 1);     // stride 1: OH == IH, OW == IW
+        const size_t r = ((size_t)b * p.IH + yy) * p.IW + xx;
+        rg[u] = ldg4(p.dy.g + r * p.dy.ldg + cc);
+        ry[u] = gk.two ? ldg4(p.dy.y + r * p.dy.ldy + cc) : f4zero();
+        rx[u] = ldg4(p.in.x + r * p.in.ld + cc);
+    }
+    const int oy = y0 + row;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ox = x0 + col0 + u;
+        const size_t r = ((size_t)b * p.IH + min(oy, p.IH - 1)) * p.IW + min(ox, p.IW - 1);
+        gacc[u] = p.sink.accumulate ? ldg4(p.sink.g + r * p.sink.ldg + cc) : f4zero();
+    }
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = (cok && c0 + j < p.C) ? p.w[(size_t)(c0 + j) * 9 + k] : 0.f;
+        wk[k] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int pix = pl + 32 * u;
+        if (pix < NPX) {
+            const int py = pix / PW, px = pix % PW;
+            const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+            const bool ok = cok && yy >= 0 && yy < p.IH && xx >= 0 && xx < p.IW;
+            dyt[pix * PQP + q] = ok ? gsrc_apply4(rg[u], ry[u], gk) : f4zero();
+            xt[pix * PQP + q] = rx[u];                      // raw; masked / transformed where it is read
+        }
+    }
+    __syncthreads();
+
+    float4 dx[4], dyc[4], dwacc[9];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dx[u] = f4zero();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dwacc[k] = f4zero();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dyc[u] = lds_px(dyt, (row + 1) * PW + col0 + 1 + u, q);       // dy' at the owned pixels
+    float4 yc[4];                                                                          // raw y at the owned pixels
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float4 dr[6], xr[6];
+        const bool rok = (unsigned)(y0 + row + ky - 1) < (unsigned)p.IH;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            dr[j] = lds_px(dyt, (row + ky) * PW + col0 + j, q);
+            const float4 raw = lds_px(xt, (row + ky) * PW + col0 + j, q);
+            if (ky == 1 && j >= 1 && j <= 4) yc[j - 1] = raw;
+            const bool ok = rok && (unsigned)(x0 + col0 + j - 1) < (unsigned)p.IW;
+            xr[j] = ok ? src_apply4(raw, xk) : f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kx2 = u + 2 - j;          // dx[u] += dy'[row-1+ky][col-1+j] * w[2-ky][u+2-j]
+                if (kx2 >= 0 && kx2 < 3) dx[u] = f4fma(dr[j], wk[(2 - ky) * 3 + kx2], dx[u]);
+                const int kx = j - u;               // dw[ky][kx] += dy'[row][col+u] * x'[row-1+ky][col+u-1+kx]
+                if (kx >= 0 && kx < 3) dwacc[ky * 3 + kx] = f4fma(dyc[u], xr[j], dwacc[ky * 3 + kx]);
+            }
+    }
+    float4 s1 = f4zero(), s2 = f4zero();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ox = x0 + col0 + u;
+        if (cok && oy < p.IH && ox < p.IW) {
+            const size_t r = ((size_t)b * p.IH + oy) * p.IW + ox;
+            stg4(p.sink.g + r * p.sink.ldg + c0, sink_apply4(p.sink, sk, f4add(dx[u], gacc[u]), yc[u], s1, s2));
+        }
+    }
+    // ---- the block's 9 weight-gradient taps: [tap][pixel lane][quad] float4 over both tile buffers, summed over the 32 lanes
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float4* dstp = (k < 5) ? (dyt + (k * 32 + pl) * 8 + q) : (xt + ((k - 5) * 32 + pl) * 8 + q);
+        *dstp = dwacc[k];
+    }
+    __syncthreads();
+    for (int o = t; o < 9 * 32; o += 256) {            // output o -> (tap o / 32, quad (o % 32) / 4, component o % 4)
+        const int k = o >> 5, qc = o & 31;
+        const float* base = reinterpret_cast<const float*>(k < 5 ? dyt + k * 32 * 8 : xt + (k - 5) * 32 * 8) + qc;
+        float a = 0.f;
+#pragma unroll
+        for (int l = 0; l < 32; ++l) a += base[l * 32];
+        const int c = (cq0 + (qc >> 2)) * 4 + (qc & 3);
+        if (c < p.C) p.wpartial[((size_t)tIdx * p.C + c) * 9 + k] = a;
+    }
+    if (p.sink.finalize && p.sink.mean && p.sink.partial) {     // uniform
+        float* slot = red + (pl * 8 + q) * 8;
+        slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
+        slot[4] = s2.x; slot[5] = s2.y; slot[6] = s2.z; slot[7] = s2.w;
+        __syncthreads();
+        if (t < 64) {
+            const int qq = t >> 3, comp = t & 7;
+            float a = 0.f;
+#pragma unroll
+            for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
+            const int c = (cq0 + qq) * 4 + (comp & 3);
+            if (c < p.C) p.sink.partial[(size_t)tIdx * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
+        }
+    }
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void dwt_bwd_kernel(DwTP p) {
     using T = DwBTile<S>;
@@ -664,10 +805,21 @@ extern "C" int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW,
 }
 
 extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
-    PQ_CHECK_ARG(a && a->dy.g && a->part >= 0 && a->part <= 2, "null pointer / bad part");
+    PQ_CHECK_ARG(a && a->part >= 0 && a->part <= 4, "null pointer / bad part");
+    if (a->part == 4) {       // only the reduction of the per-block weight-gradient rows a part-3 launch left in `scratch`
+        PQ_CHECK_ARG(a->dw && a->scratch && a->stride == 1 && a->B > 0 && a->C > 0, "part 4 needs dw, scratch, stride 1");
+        int th4, tw4; bwd_tiles(a->IH, a->IW, a->stride, th4, tw4);
+        const int n4 = a->C * 9;
+        hipLaunchKernelGGL(dwt_partial_reduce_kernel, dim3((n4 + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, (const float*)a->scratch,
+                           a->B * th4 * tw4, n4, a->dw);
+        PQ_CHECK_LAUNCH();
+        return PQ_OK;
+    }
+    PQ_CHECK_ARG(a->dy.g, "null pointer");
     PQ_CHECK_ARG(a->part == 2 || (a->w && a->dx.g), "input gradient needs w and the sink");
-    PQ_CHECK_ARG(a->part == 1 || (a->in.x && a->dw && a->scratch), "weight gradient needs in, dw and scratch");
+    PQ_CHECK_ARG(a->part == 1 || (a->in.x && a->scratch && (a->dw || a->part == 3)), "weight gradient needs in, dw and scratch");
     PQ_CHECK_ARG(a->part == 0 || a->stride == 1, "the split backward exists for stride 1 only");
+    PQ_CHECK_ARG(a->part != 3 || (a->in.x == a->dx.y && a->in.ld == a->dx.ldy), "part 3: the sink must be the conv's input tensor");
     PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1)");
     PQ_CHECK_ARG(a->stride == 1 || ((a->IH & 1) == 0 && (a->IW & 1) == 0), "stride-2 backward needs even input sizes");
     PQ_CHECK_ARG(a->part == 2 || !(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
@@ -682,9 +834,10 @@ extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
     if (a->stride != 1) hipLaunchKernelGGL((dwt_bwd_kernel<2>), grid, blk, 0, st, p);
     else if (a->part == 1) hipLaunchKernelGGL((dwt_bwd_s1_kernel<1>), grid, blk, 0, st, p);
     else if (a->part == 2) hipLaunchKernelGGL((dwt_bwd_s1_kernel<2>), grid, blk, 0, st, p);
+    else if (a->part == 3) PQ_LAUNCH_BINDABLE(dwt_bwd_s1_fused_kernel, grid, blk, 0, st, p);
     else hipLaunchKernelGGL((dwt_bwd_s1_kernel<0>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
-    if (a->part == 1) return PQ_OK;
+    if (a->part == 1 || a->part == 3) return PQ_OK;
     const int n = a->C * 9;
     hipLaunchKernelGGL(dwt_partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, nblk, n, a->dw);
     PQ_CHECK_LAUNCH();

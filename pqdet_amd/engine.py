@@ -485,6 +485,8 @@ class Plan:
             self._emit_backward(flat, mods, heads, resolve)
         self.fwd_arr = (abi.Op * len(self.fwd))(*self.fwd)
         self.bwd_arr = (abi.Op * len(self.bwd))(*self.bwd) if self.bwd else None
+        if self.bwd_arr is not None and self.loss_ops_b:
+            self.patch_upstream(self.default_upstream)
         self.post_arr = (abi.Op * len(self.post_bwd))(*self.post_bwd) if self.post_bwd else None
 
     # ------------------------------------------------------------------------------------------ forward emission
@@ -601,7 +603,10 @@ class Plan:
         self.nheads = nh
         if self.with_loss:
             self.loss_buf = self._new(nh, 4, fill=0.0)
-            self.gscale = self._new(nh, 3, fill=0.0)
+            self.loss_total = self._new(4 + nh, fill=0.0)      # loss, box, conf, cls summed over the heads, then each head's total
+            # what the backward loss ops read outside a real backward (profiling replays of bwd_arr): d(total loss) = 1
+            self._one = self._new(1, fill=1.0)
+            self.default_upstream = [self._one] + [None] * (3 + nh)
             self.nan_dev = torch.zeros(nh, device=self.device, dtype=torch.int32)
             self.keep.append(self.nan_dev)
             for slot, (i, m, a) in enumerate(heads):
@@ -613,11 +618,15 @@ class Plan:
                 if a.grad is None:
                     a.grad = self._new(a.rows, a.ld, fill=0.0)
                 la = abi.YoloLoss(view, None, None, ptr(partial), self.loss_buf[slot].data_ptr(),
-                                  self.nan_dev[slot:slot + 1].data_ptr(), self.gscale[slot].data_ptr(), ptr(a.grad),
+                                  self.nan_dev[slot:slot + 1].data_ptr(), None, ptr(a.grad),
                                   a.H * a.W * a.ld, a.W * a.ld, a.ld, 1,
                                   B, a.H, a.W, A, opt['classes'], 1, opt['stride'], abi.BOX_KIND[opt['bbox_loss']], 1,
                                   float(opt['ignore_thresh']), float(opt['l1_loss_gain']))
+                la.head_slot, la.n_heads = slot, nh
+                if slot == nh - 1:               # the last head's finalize also sums the table: what DetectionModel.forward returns
+                    la.totals = self.loss_total.data_ptr()
                 idx = self._op(self.fwd, abi.OP_LOSS_FWD, la)
+                la.totals = None
                 self.loss_ops_f.append((idx, slot, opt['stride']))
                 self._head_loss_args = getattr(self, '_head_loss_args', []) + [(la, slot, opt['stride'], a)]
             # Two-stream forward: the detection-head branches of all but the last level (the layers that only feed their yolo layer:
@@ -636,8 +645,13 @@ class Plan:
                         side_layers.add(j)
                         j -= 1
                 self.fwd_layer += [-1] * (len(self.fwd) - len(self.fwd_layer))
+                last_loss = self.loss_ops_f[-1][0]
                 for k, layer in enumerate(self.fwd_layer):
-                    if layer in side_layers or self.fwd[k].code == abi.OP_LOSS_FWD:
+                    if k == last_loss:
+                        # reads the rows the other heads' loss ops wrote on the side stream; its own input comes from the main
+                        # stream, so it runs there (no fork latency at the end of the forward) behind a join
+                        self.fwd[k].flags = abi.OPF_JOIN
+                    elif layer in side_layers or self.fwd[k].code == abi.OP_LOSS_FWD:
                         self.fwd[k].flags = abi.OPF_SIDE
                         if self.fwd[k].code == abi.OP_BN_FWD_FIN:       # never the main stream's reduction scratch / tickets
                             self.fwd[k].u.bnf.scratch = None
@@ -840,7 +854,20 @@ class Plan:
                                 # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
                                 need = l.pq_dw3x3_bwd_scratch_bytes(B, src.H, src.W, out.H, out.W, out.C, s)
                                 sink = self._sink(src, l.pq_dw3x3_bwd_blocks(B, src.H, src.W, s))
-                                if s == 1 and os.environ.get('PQ_DW_SPLIT', '1') != '0':
+                                mode = os.environ.get('PQ_DW_SPLIT', '3')
+                                if s == 1 and mode == '3':
+                                    # ONE staging of (g, y_out) and of the layer input for both gradients on the main stream
+                                    # (the sink is this conv's input tensor, so its y comes out of the same LDS tile); only the
+                                    # reduction of the per-block weight-gradient rows goes to the weight-gradient stream
+                                    buf = self._new(max(need, 64) // 4 + 16)
+                                    a = abi.DwBwd(dy, src.src(), wsrc, sink, None, ptr(buf), B, src.H, src.W, out.H, out.W,
+                                                  out.C, s, 3)
+                                    self._op(self.bwd, abi.OP_DW_BWD, a)
+                                    a = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), wdst, ptr(buf), B, src.H, src.W,
+                                                  out.H, out.W, out.C, s, 4)
+                                    idx = self._op(self.bwd, abi.OP_DW_BWD, a)
+                                    self.bwd[idx].flags = abi.OPF_SIDE
+                                elif s == 1 and mode == '1':
                                     # the input-gradient chain is the critical path: the weight half of the tiled kernel
                                     # goes to the weight-gradient stream (emitted first so that it starts early)
                                     a = abi.DwBwd(dy, src.src(), None, abi.GSink(), wdst, None, B, src.H, src.W, out.H,
@@ -956,6 +983,16 @@ class Plan:
                     la.label = target[li].data_ptr()
                     la.boxes = target[bi].data_ptr()
                     la.M = target[bi].shape[1]
+
+    def patch_upstream(self, grads):
+        """Upstream gradient scalars of the step's 4 + n_heads outputs (device tensors of one float each, or None) -> the
+        backward loss ops read them in place: no host-side arithmetic, no copy."""
+        ptrs = [None if g is None else g.data_ptr() for g in grads]
+        for idx, slot, _ in self.loss_ops_b:
+            la = self.bwd_arr[idx].u.loss
+            for k in range(4):
+                la.gup[k] = ptrs[k]
+            la.gup[4] = ptrs[4 + slot]
 
     def run_forward(self, x, target):
         self._patch(x, target)

@@ -36,20 +36,32 @@ _TARGET_MAP = {
 class _StepFn(torch.autograd.Function):
     """Whole-network forward/backward as one autograd node (the anchor parameter only ties it into the graph)."""
 
+    """Outputs: 4 + n_heads tensors of shape (1,): loss, box, conf, cls summed over the heads (head order, like the reference's
+    ``map(sum, zip(*outputs))``, model/interpreter.py:77), then every head's own total.  They are summed by the last head's loss
+    kernel; the upstream gradients are read in place by the backward loss kernels -- the step adds one device copy (the
+    returned values must not alias a buffer the next step overwrites) and nothing else to what the driver itself does."""
+
     @staticmethod
     def forward(ctx, anchor, model, plan, x, target):
         plan.run_forward(x, target)
         ctx.model, ctx.plan = model, plan
         ctx.x, ctx.target = x, target           # keep the batch alive until backward has consumed it
-        return plan.loss_buf.clone()
+        ctx.set_materialize_grads(False)
+        res = plan.loss_total.clone()
+        return tuple(res[k:k + 1] for k in range(res.numel()))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *grads):
         plan, model = ctx.plan, ctx.model
-        g = g.to(torch.float32)
-        plan.gscale.copy_(g[:, 0:1] + g[:, 1:4])
+        keep = []
+        for g in grads:
+            if g is not None and (g.dtype != torch.float32 or g.numel() != 1 or not g.is_cuda):
+                g = g.to(device=plan.device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+            keep.append(g)
         plan._patch(ctx.x, ctx.target)
+        plan.patch_upstream(keep)
         plan.run_backward(model._reducer)
+        plan.patch_upstream(plan.default_upstream)     # the gradient tensors die with this call: leave no pointer to them behind
         model._flat.assign_grads()
         return None, None, None, None, None
 
@@ -244,7 +256,7 @@ class AnyModel(nn.Module):
         target = tuple(t.to(x.device, torch.float32).contiguous() for t in target)
         plan = self._plan(x, True)
         anchor = self._flat.params[0]
-        losses = _StepFn.apply(anchor, self, plan, x, target)      # (heads, 4): total, box, conf, cls per head
+        losses = _StepFn.apply(anchor, self, plan, x, target)      # loss, box, conf, cls over all heads; then each head's total
         self._arm_nan(plan)
         return losses
 
@@ -255,13 +267,12 @@ class DetectionModel(AnyModel):
         out = super().forward(x, target)
         if target is None:
             return out
-        total = out.sum(0)
         return {
-            'loss': total[0:1],
-            'giou_loss': total[1:2],
-            'conf_loss': total[2:3],
-            'class_loss': total[3:4],
-            'loss_per_branch': [out[i, 0:1] for i in range(out.shape[0])],
+            'loss': out[0],
+            'giou_loss': out[1],
+            'conf_loss': out[2],
+            'class_loss': out[3],
+            'loss_per_branch': list(out[4:]),
         }
 
 

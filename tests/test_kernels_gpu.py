@@ -204,6 +204,26 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=N
     old = rnd(M, I, g=g)
     tot = dz + (old if accum else 0)
     gout = tot * act_grad_ref(yin * a_in + b_in, act)
+    # a pre-activation within fp32 rounding of a kink (0, and 6 for ReLU6) may fall on either side in an equally valid
+    # evaluation order (the kernel uses one fused multiply-add); with 10^7 elements a few do: those are not compared
+    u64 = yin.double() * a_in.double() + b_in.double()
+    kink = torch.zeros_like(u64, dtype=torch.bool)
+    for at_ in {0: (), 1: (0.0,), 2: (0.0, 6.0), 3: (0.0,)}[act]:
+        kink |= (u64 - at_).abs() < 4e-6
+    assert kink.float().mean().item() < 1e-4
+
+    def sink_close(got, what):
+        got = got.detach().cpu().clone()
+        got[kink] = gout[kink]
+        close(got, gout, what=what)
+
+    def stats_close(partial_, got, tag):
+        # the column sums are checked against the sink values the kernel itself wrote (what BatchNorm's backward consumes)
+        gref = got.detach().cpu().double()
+        s1, s2 = reduce_partial(partial_, nblk, ldp, I)
+        xh = (yin.double() - mean_in.double()) * inv_in.double()
+        close(s1.float(), gref.sum(0).float(), rt=1e-3, at=1e-2, what='sum g' + tag)
+        close(s2.float(), (gref * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat' + tag)
     gyd = torch.zeros(M, ldg, device=DEV)
     gyd[:, :O] = gy.to(DEV)
     youtd = torch.zeros(M, ldg, device=DEV)
@@ -225,12 +245,9 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=N
     plans = [gemm_plan('dgrad', a, expect)]
     abi.check(abi.lib().pq_conv1x1_dgrad(C.byref(a), stream()))
     torch.cuda.synchronize()
-    close(gdst, gout, what='dgrad sink')
+    sink_close(gdst, 'dgrad sink')
     if stats:
-        s1, s2 = reduce_partial(partial, nblk, ldp, I)
-        xh = (yin.double() - mean_in.double()) * inv_in.double()
-        close(s1.float(), gout.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum g')
-        close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat')
+        stats_close(partial, gdst, '')
     if True:
         # same result through the transposed-weight path (weights transposed on the device by pq_transpose_batch into rows
         # of ceil4(O) floats; the pad columns must be zero)
@@ -250,11 +267,9 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=N
         plans.append(gemm_plan('dgrad', a, expect_wt))
         abi.check(abi.lib().pq_conv1x1_dgrad(C.byref(a), stream()))
         torch.cuda.synchronize()
-        close(g2, gout, what='dgrad sink (transposed weights)')
+        sink_close(g2, 'dgrad sink (transposed weights)')
         if stats:
-            s1, s2 = reduce_partial(partial, nblk, ldp, I)
-            close(s1.float(), gout.double().sum(0).float(), rt=1e-3, at=1e-2, what='sum g (transposed weights)')
-            close(s2.float(), (gout.double() * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat (transposed weights)')
+            stats_close(partial, g2, ' (transposed weights)')
     return plans
 
 
@@ -300,9 +315,12 @@ def test_conv1x1_wgrad(M, I, O, two, bias, xa=True, expect=None):
     plan = gemm_plan('wgrad', a, expect)
     abi.check(l.pq_conv1x1_wgrad(C.byref(a), stream()))
     torch.cuda.synchronize()
-    close(dw, want.float(), rt=1e-3, at=1e-3, what='wgrad')
+    # entries are sums of M products: their fp32 round-off grows with the typical magnitude sqrt(M) * |dy| * |x|, so the
+    # absolute floor does too (1e-3 up to 4096 rows, as before); the norm-wise 2e-5 check inside close() is independent of it
+    floor = 1e-3 * max(1.0, math.sqrt(M / 4096.0))
+    close(dw, want.float(), rt=1e-3, at=floor, what='wgrad')
     if bias:
-        close(db, dy.double().sum(0).float(), rt=1e-3, at=1e-3, what='bias grad')
+        close(db, dy.double().sum(0).float(), rt=1e-3, at=floor, what='bias grad')
     return plan
 
 
@@ -566,6 +584,32 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
         abi.check(l.pq_dw3x3_bwd(C.byref(h2), stream()))
         torch.cuda.synchronize()
         assert torch.equal(g3, gdst2) and torch.equal(p3, part3) and torch.equal(dw3, dw2)
+        # part 3 + 4 (the engine's default): ONE staging of (g, y_out) and of the raw layer input for both gradients (the sink's y
+        # comes out of the same LDS tile), then the reduction of the per-block weight-gradient rows as its own launch.  Same
+        # arithmetic in the same order: bit-identical.
+        g4 = torch.full((B, H, W, P), float('nan'), device=DEV)
+        p4 = torch.zeros(nb3 * 2 * ldp, device=DEV)
+        dw4 = torch.full((Cc, 9), float('nan'), device=DEV)
+        sc4 = torch.full_like(sc2, float('nan'))
+        f3 = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(g4.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
+                                                              sv[1].data_ptr(), p4.data_ptr(), P, P, 2, 0, 1, ldp),
+                       None, sc4.data_ptr(), B, H, W, OH, OW, Cc, stride, 3)
+        abi.check(l.pq_dw3x3_bwd(C.byref(f3), stream()))
+        f4 = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), dw4.data_ptr(), sc4.data_ptr(), B, H, W, OH, OW, Cc, stride, 4)
+        abi.check(l.pq_dw3x3_bwd(C.byref(f4), stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(g4, gdst2) and torch.equal(p4, part3) and torch.equal(dw4, dw2)
+        # ... with an accumulating sink (the tensor has another consumer that ran before)
+        prev = rnd(B, H, W, Cc, g=g)
+        g5, g6 = padc(prev), padc(prev)
+        for gbuf, part in ((g5, 3), (g6, 0)):
+            fb2 = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(gbuf.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(),
+                                                                   sv[0].data_ptr(), sv[1].data_ptr(), p4.data_ptr(), P, P, 2, 1, 1, ldp),
+                            dw4.data_ptr(), sc4.data_ptr(), B, H, W, OH, OW, Cc, stride, part)
+            abi.check(l.pq_dw3x3_bwd(C.byref(fb2), stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(g5, g6)
+        close(g5[..., :Cc], (dxin + prev) * ((u > 0) & (u < 6)).float(), what='fused dw dgrad, accumulating sink')
 
 
 # ----------------------------------------------------------------------------------------------- stem

@@ -396,8 +396,9 @@ def test_fused_qat_plan_equals_the_materialising_plan(monkeypatch):
     straight-through mask, nothing quantised is written for conv -> conv edges) -- the plan the config-5 benchmark times --
     against the materialising plan (PQ_QAT_FUSE=0, the one the teacher-forced G9b check replays): same arithmetic on the
     same values, only the place where fq() is applied moves.  Two train steps with an optimiser step in between: observer
-    states and losses bit-identical; gradients bit-identical up to fp32 summation order inside the sinks' statistics
-    (<= 1e-6 norm-wise per parameter)."""
+    states and losses bit-identical; gradients equal up to fp32 summation order -- the BatchNorm-backward sums come out of
+    different kernels' epilogues (consumer sinks instead of pq_qact_bwd), i.e. other row blocks and another partial order:
+    measured 2e-6 norm-wise on the stem weight, asserted <= 1e-5 per parameter."""
     runs = {}
     for fuse in ('1', '0'):
         monkeypatch.setenv('PQ_QAT_FUSE', fuse)
@@ -421,9 +422,13 @@ def test_fused_qat_plan_equals_the_materialising_plan(monkeypatch):
         assert torch.equal(la, lb), (step, la, lb)
         if not torch.equal(ga, gb):
             flat = net_a._flat
+            gmax = max(gb[o:o + p.numel()].double().norm().item() for p, o in zip(flat.params, flat.offsets))
             for p, o in zip(flat.params, flat.offsets):
                 da, db = ga[o:o + p.numel()].double(), gb[o:o + p.numel()].double()
-                assert (da - db).norm().item() <= 1e-6 * db.norm().item() + 1e-12, (step, o, (da - db).norm().item(), db.norm().item())
+                # absolute floor: the bias of a BatchNorm whose only consumer is a linear conv + train-mode BatchNorm has a
+                # mathematically ZERO gradient (the next BatchNorm removes the shift); what both plans produce there is the
+                # round-off of a 10^6-term cancelling sum (~1e-3 against gradient norms of ~5e4), not a value
+                assert (da - db).norm().item() <= 1e-5 * db.norm().item() + 1e-7 * gmax, (step, o, (da - db).norm().item(), db.norm().item(), gmax)
 
 
 def test_two_stream_forward_equals_the_single_stream_forward(monkeypatch):
