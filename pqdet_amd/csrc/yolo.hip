@@ -165,33 +165,46 @@ __device__ __forceinline__ void yolo_cell(const pq_yolo_loss_args& a, int b, int
     if (GRAD)
         for (int k = 0; k < 4; ++k) OUT(k, gcorner[k] * dpc[k] * mixw * gs_box);
 
-    // ---- class term: eight classes per round, loads first (each thread walks its own 25..86-float record, so the
-    // loads of one round are the only memory-level parallelism there is; one class per round was pure load latency)
-    constexpr int CK = 8;
-    for (int k0 = 0; k0 < a.C; k0 += CK) {
-        float raw[CK], tt[CK];
-#pragma unroll
-        for (int u = 0; u < CK; ++u) {
-            const int k = min(k0 + u, a.C - 1);
-            raw[u] = IN(5 + k);
-            tt[u] = LAB(5 + k);
+    // ---- class term.  Every product carries the factor `respond` (model/loss.py:103-106), which is exactly 0 for all but the
+    // handful of cells that own a ground-truth box: there the term and its gradient are 0 whatever the class logits are --
+    // unless one of them is NaN (0 * NaN = NaN reaches the loss and trips the reference's NaN trap), so the cheap path only
+    // checks for that and skips the 3 transcendentals per class (this term was ~80 % of the kernel's instructions).
+    if (respond == 0.f) {
+        bool bad = false;
+        for (int k = 0; k < a.C; ++k) {
+            const float v = IN(5 + k);
+            bad |= (v != v);
+            if (GRAD) OUT(5 + k, (v != v) ? v : 0.f);
         }
-#pragma unroll
-        for (int u = 0; u < CK; ++u) {
-            const int k = k0 + u;
-            if (k < a.C) {
-                const float q = a.from_raw ? sigmoidf_(raw[u]) : raw[u];
-                const float t = tt[u];
-                const float alpha_t = 2.f * fabsf(t - 1.f + 0.5f);
-                const float ad = fabsf(t - q);
-                const float focal = alpha_t * (ad * ad);
-                const float bce = bce_val(q, t);
-                lcls += 2.f * focal * respond * bce;
-                if (GRAD) {
-                    const float dfocal = -2.f * alpha_t * (t - q);
-                    const float dl = 2.f * respond * (dfocal * bce + focal * bce_grad(q, t));
-                    const float dq = a.from_raw ? q * (1.f - q) : 1.f;
-                    OUT(5 + k, dl * dq * mixw * gs_cls);
+        if (bad) lcls = NAN;
+    } else {
+        // eight classes per round, loads first (the loads of one round are the memory-level parallelism of the generic kernel)
+        constexpr int CK = 8;
+        for (int k0 = 0; k0 < a.C; k0 += CK) {
+            float raw[CK], tt[CK];
+    #pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                const int k = min(k0 + u, a.C - 1);
+                raw[u] = IN(5 + k);
+                tt[u] = LAB(5 + k);
+            }
+    #pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                const int k = k0 + u;
+                if (k < a.C) {
+                    const float q = a.from_raw ? sigmoidf_(raw[u]) : raw[u];
+                    const float t = tt[u];
+                    const float alpha_t = 2.f * fabsf(t - 1.f + 0.5f);
+                    const float ad = fabsf(t - q);
+                    const float focal = alpha_t * (ad * ad);
+                    const float bce = bce_val(q, t);
+                    lcls += 2.f * focal * respond * bce;
+                    if (GRAD) {
+                        const float dfocal = -2.f * alpha_t * (t - q);
+                        const float dl = 2.f * respond * (dfocal * bce + focal * bce_grad(q, t));
+                        const float dq = a.from_raw ? q * (1.f - q) : 1.f;
+                        OUT(5 + k, dl * dq * mixw * gs_cls);
+                    }
                 }
             }
         }

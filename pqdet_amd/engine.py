@@ -854,7 +854,7 @@ class Plan:
                                 # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
                                 need = l.pq_dw3x3_bwd_scratch_bytes(B, src.H, src.W, out.H, out.W, out.C, s)
                                 sink = self._sink(src, l.pq_dw3x3_bwd_blocks(B, src.H, src.W, s))
-                                mode = os.environ.get('PQ_DW_SPLIT', '3')
+                                mode = os.environ.get('PQ_DW_SPLIT', '1')
                                 if s == 1 and mode == '3':
                                     # ONE staging of (g, y_out) and of the layer input for both gradients on the main stream
                                     # (the sink is this conv's input tensor, so its y comes out of the same LDS tile); only the
