@@ -33,6 +33,34 @@ enum { PQ_ACT_LINEAR = 0, PQ_ACT_RELU = 1, PQ_ACT_RELU6 = 2, PQ_ACT_LEAKY = 3, P
 /* box loss kinds -- reference model/loss.py:62-81 */
 enum { PQ_BOX_L1 = 0, PQ_BOX_GIOU = 1, PQ_BOX_DIOU = 2, PQ_BOX_CIOU = 3, PQ_BOX_IOU = 4 };
 
+/* Train-mode BatchNorm statistics handed from the kernel that produces a tensor to the FIRST kernel that consumes it, without
+ * a pq_bn_fwd_finalize launch in between (the dependent launch + its dispatch gap cost ~10 us per layer inside a training step;
+ * nn.BatchNorm2d semantics unchanged: model/parser.py:404-405).
+ *   producer: adds its per-row-block partial sums (sum x, sum x^2 per channel; fp32 values) into `acc` with 64-bit INTEGER
+ *             atomics on a fixed-point image of each partial (unit 2^-50, two limbs per value: the sum is exact, hence
+ *             independent of the arrival order: run-to-run deterministic).  `slots` replicas (row block b adds to slot
+ *             b % slots) keep same-address contention low.  A non-finite / out-of-range partial sets *bad instead.
+ *   consumer: every workgroup derives mean / invstd / scale / shift of the channels it touches from `acc` in its prologue
+ *             (same arithmetic as pq_bn_fwd_finalize: fp64 mean and biased variance, invstd = 1 / sqrt(var + eps) rounded to
+ *             fp32); the first workgroup of the grid also stores the four vectors (for every later consumer and for the
+ *             backward) and updates the running statistics and num_batches_tracked.
+ * acc and *bad must be zero when the producer starts (the engine clears the arena of all layers with one pq_fill per step). */
+typedef struct pq_bn_stat {
+    int64_t* acc;            /* [slots][2][ldp][2]: slot, statistic (sum, sum of squares), channel, limb (low, high); NULL: unused */
+    uint32_t* bad;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;     /* updated in place by the consumer's first workgroup; may be NULL */
+    float* running_var;
+    int64_t* num_batches_tracked;
+    float* mean;             /* out [C] */
+    float* invstd;
+    float* scale;
+    float* shift;
+    int32_t slots, ldp;
+    float count, eps, momentum;
+} pq_bn_stat;
+
 /* forward-value operand:  v[row][c] = act(scale[c] * x[row*ld + c] + shift[c]);  scale==NULL => identity affine;
  * with qstate the value is then fake-quantised (quint8 [0,255], per tensor): (clamp(rint(v/s)+zp) - zp) * s */
 typedef struct pq_src {
@@ -42,6 +70,8 @@ typedef struct pq_src {
     int32_t ld;
     int32_t act;
     const float* qstate; /* QAT: the consumer sees fake_quant(v) with this activation observer {min,max,scale,zp}; NULL otherwise */
+    pq_bn_stat stat;     /* stat.acc != NULL: scale / shift are DERIVED from these statistics by this call (see pq_bn_stat; `scale` and
+                            `shift` above are then ignored).  Only entry points for which pq_bn_stat_ok(code, args, 1) says so */
 } pq_src;
 
 /* gradient operand: v[row][c] = p[c]*g[row*ldg+c] + q[c]*(y[row*ldy+c] - mu[c]) + r[c];  y==NULL => v = g */
@@ -97,6 +127,10 @@ typedef struct pq_conv1x1_fwd_args {
     int32_t minmax;      /* != 0: `partial` rows have 4 planes: sum, sum of squares, per-channel MIN and MAX of the outputs of the
                           * row block (QAT: pq_bn_fwd_finalize turns them into the activation observer's update, no pass over
                           * the tensor) */
+    int64_t* stat_acc;   /* != NULL: the statistics are ADDED to this accumulator (pq_bn_stat.acc, pitch ldp) instead of written
+                          * as rows of `partial` (which may then be NULL) */
+    uint32_t* stat_bad;
+    int32_t stat_slots;
 } pq_conv1x1_fwd_args;
 int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream);
 /* row-blocks (partial-sum rows) a GEMM with M rows and N output columns uses: fwd N=O, dgrad sink N=I */
@@ -178,6 +212,9 @@ typedef struct pq_dw3x3_fwd_args {
     float* partial;      /* [nblk][2][ldp] or NULL; nblk = pq_dw3x3_fwd_blocks(B, OH, OW, C, stride); [nblk][4][ldp] with minmax */
     int32_t B, IH, IW, OH, OW, C, stride, ldo, ldp;
     int32_t minmax;      /* as in pq_conv1x1_fwd_args */
+    int64_t* stat_acc;   /* as in pq_conv1x1_fwd_args */
+    uint32_t* stat_bad;
+    int32_t stat_slots;
 } pq_dw3x3_fwd_args;
 int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream);
 int32_t pq_dw3x3_fwd_blocks(int32_t B, int32_t OH, int32_t OW, int32_t C, int32_t stride);   /* statistics rows written by pq_dw3x3_fwd */
@@ -346,6 +383,14 @@ typedef struct pq_bn_bwd_finalize_args {
 int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream);
 /* long partial lists are reduced by several blocks per channel group through this scratch (deterministic order) */
 int64_t pq_bn_finalize_scratch_bytes(int32_t C);
+/* Can the op `code` (PQ_OP_*) called with exactly `args` (its argument struct) take part in the statistics hand-over of
+ * pq_bn_stat?  role 0: as the PRODUCER (statistics into stat_acc instead of `partial` rows; the kernel this shape dispatches to
+ * has the atomic epilogue), role 1: as the first CONSUMER of its input operand (in.stat / a.stat derived in the prologue).
+ * Pure host function. */
+int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role);
+/* bytes of a pq_bn_stat.acc for C channels with pitch ldp and `slots` replicas, and the replica count to use for nblk row blocks */
+int64_t pq_bn_stat_bytes(int32_t ldp, int32_t slots);
+int32_t pq_bn_stat_slots(int32_t nblk);
 int32_t pq_bn_finalize_tickets(int32_t C);
 
 /* ------------------------------------------------------------------ shortcut / route / upsample
@@ -619,7 +664,8 @@ const char* pq_last_error(void);
 const char* pq_version(void);
 /* sizeof() of the argument struct of op `code` (0: pq_op, 100: pq_recover_args, 101: pq_nms_args,
  * 102: pq_decode_bwd_args, 103: pq_transpose_item, 104: pq_create_label_args,
- * 105: pq_qat_weight_item) -- lets a foreign-language binding verify its struct layout at load time */
+ * 105: pq_qat_weight_item, 106: pq_bn_eval_item, 107: pq_bn_stat, 108: pq_src) -- lets a foreign-language binding verify its
+ * struct layout at load time */
 int32_t pq_abi_sizeof(int32_t code);
 
 #ifdef __cplusplus

@@ -21,8 +21,14 @@ BOX_L1, BOX_GIOU, BOX_DIOU, BOX_CIOU, BOX_IOU = range(5)
 BOX_KIND = {'l1': BOX_L1, 'giou': BOX_GIOU, 'diou': BOX_DIOU, 'ciou': BOX_CIOU, 'iou': BOX_IOU}
 
 
+class BnStat(C.Structure):
+    _fields_ = [('acc', c_fp), ('bad', c_fp), ('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp),
+                ('num_batches_tracked', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp), ('shift', c_fp),
+                ('slots', i32), ('ldp', i32), ('count', f32), ('eps', f32), ('momentum', f32)]
+
+
 class Src(C.Structure):
-    _fields_ = [('x', c_fp), ('scale', c_fp), ('shift', c_fp), ('ld', i32), ('act', i32), ('qstate', c_fp)]
+    _fields_ = [('x', c_fp), ('scale', c_fp), ('shift', c_fp), ('ld', i32), ('act', i32), ('qstate', c_fp), ('stat', BnStat)]
 
 
 class GSrc(C.Structure):
@@ -38,7 +44,8 @@ class GSink(C.Structure):
 class Conv1x1Fwd(C.Structure):
     _fields_ = [('inp', Src), ('w', c_fp), ('bias', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('M', i32), ('I', i32), ('O', i32), ('ldo', i32), ('ldp', i32),
-                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('minmax', i32)]
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('minmax', i32),
+                ('stat_acc', c_fp), ('stat_bad', c_fp), ('stat_slots', i32)]
 
 
 class Conv1x1Dgrad(C.Structure):
@@ -84,7 +91,7 @@ class GconvWgrad(C.Structure):
 class DwFwd(C.Structure):
     _fields_ = [('inp', Src), ('w', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('stride', i32),
-                ('ldo', i32), ('ldp', i32), ('minmax', i32)]
+                ('ldo', i32), ('ldp', i32), ('minmax', i32), ('stat_acc', c_fp), ('stat_bad', c_fp), ('stat_slots', i32)]
 
 
 class DwDgrad(C.Structure):
@@ -295,6 +302,9 @@ SIGNATURES = {
     'pq_bn_bwd_finalize': (C.c_int, [C.POINTER(BnBwdFin), C.c_void_p]),
     'pq_bn_finalize_scratch_bytes': (i64, [i32]),
     'pq_bn_finalize_tickets': (i32, [i32]),
+    'pq_bn_stat_ok': (i32, [i32, C.c_void_p, i32]),
+    'pq_bn_stat_bytes': (i64, [i32, i32]),
+    'pq_bn_stat_slots': (i32, [i32]),
     'pq_copy_fwd': (C.c_int, [C.POINTER(Copy), C.c_void_p]),
     'pq_route_bwd': (C.c_int, [C.POINTER(RouteBwd), C.c_void_p]),
     'pq_ew_blocks': (i32, [i32, i32]),

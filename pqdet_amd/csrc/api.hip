@@ -263,9 +263,31 @@ extern "C" int pq_run_ops2_timed(const pq_op* ops, int32_t n, void* stream, void
     return PQ_OK;
 }
 
+// ---- BatchNorm statistics hand-over (pq_bn_stat)
+int conv1x1_fwd_stat_ok(const pq_conv1x1_fwd_args* a, int role);     // gemm.hip
+int dw_fwd_stat_ok(const pq_dw3x3_fwd_args* a, int role);           // dwtile.hip
+extern "C" int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role) {
+    if (!args || (role != 0 && role != 1)) return 0;
+    switch (code) {
+        case PQ_OP_CONV1X1_FWD: return conv1x1_fwd_stat_ok((const pq_conv1x1_fwd_args*)args, role);
+        case PQ_OP_DW_FWD: return dw_fwd_stat_ok((const pq_dw3x3_fwd_args*)args, role);
+        case PQ_OP_COPY_FWD: {           // consumer only: shortcut / route / upsample read their operands through src_coef4
+            const pq_copy_args* c = (const pq_copy_args*)args;
+            return role == 1 && !c->a.qstate && !c->b.qstate && (c->C & 3) == 0;
+        }
+        default: return 0;
+    }
+}
+extern "C" int64_t pq_bn_stat_bytes(int32_t ldp, int32_t slots) { return (int64_t)(slots > 0 ? slots : 1) * 2 * ldp * 2 * 8; }
+// replicas by the number of row blocks that add to one channel: ~64 same-address atomics in flight cost nothing, 512 cost 12 us
+// (scripts/probes/bnstat_probe.hip)
+extern "C" int32_t pq_bn_stat_slots(int32_t nblk) { return nblk <= 96 ? 1 : (nblk <= 384 ? 4 : 16); }
+
 extern "C" int32_t pq_abi_sizeof(int32_t code) {
     switch (code) {
         case 0: return (int32_t)sizeof(pq_op);
+        case 107: return (int32_t)sizeof(pq_bn_stat);
+        case 108: return (int32_t)sizeof(pq_src);
         case PQ_OP_CONV1X1_FWD: return (int32_t)sizeof(pq_conv1x1_fwd_args);
         case PQ_OP_CONV1X1_DGRAD: return (int32_t)sizeof(pq_conv1x1_dgrad_args);
         case PQ_OP_CONV1X1_WGRAD: return (int32_t)sizeof(pq_conv1x1_wgrad_args);

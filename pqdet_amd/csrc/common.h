@@ -42,6 +42,53 @@ __device__ __forceinline__ float act_bwd(float u, const ActParam& a) {
 }
 inline bool act_is_special(int act) { return act == PQ_ACT_LOGISTIC || act == PQ_ACT_TANH; }
 
+// ---- BatchNorm statistics hand-over without a finalize launch (pq_bn_stat) ---------------------------------------
+// producer side: one fp32 partial sum -> two 64-bit integer atomics on its fixed-point image (unit 2^-50: low limb = the 50
+// fraction bits, high limb = floor(v)).  Integer addition is associative, so the accumulated value does not depend on the
+// arrival order; bits of v below 2^-50 are dropped (|error| < 1e-15 per partial, the same for every order).
+constexpr float PQ_STAT_MAX = 5.0e14f;         // |v| < 2^49: 8192 partials of that size still fit the high limb
+__device__ __forceinline__ void bn_stat_add(int64_t* acc, uint32_t* bad, int slots, int ldp, int blk, int plane, int c, float v) {
+    if (!(fabsf(v) < PQ_STAT_MAX)) { atomicOr(bad, 1u); return; }          // NaN / Inf / absurd: poison the layer (NaN statistics)
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(acc + (((size_t)(blk % slots) * 2 + plane) * ldp + c) * 2);
+    const double sv = (double)v * 0x1p50;                                  // exact
+    const double hi = floor((double)v);
+    const long long h = (long long)hi, l = (long long)(sv - hi * 0x1p50);  // l in [0, 2^50)
+    if (l) atomicAdd(d, (unsigned long long)l);
+    if (h) atomicAdd(d + 1, (unsigned long long)h);
+}
+// consumer side: scale / shift (and mean / invstd) of channel c from the accumulators; same arithmetic as bn_fwd_finalize_kernel.
+// writer: also store the vectors and update the running statistics (exactly one thread of the grid per channel does that).
+struct BnCoef { float scale, shift, mean, inv; };
+__device__ __forceinline__ BnCoef bn_stat_coef(const pq_bn_stat& st, int c, bool writer) {
+    long long lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
+    for (int s = 0; s < st.slots; ++s) {
+        const longlong2 a = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)s * 2 + 0) * st.ldp + c) * 2);
+        const longlong2 b = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)s * 2 + 1) * st.ldp + c) * 2);
+        lo1 += a.x; hi1 += a.y; lo2 += b.x; hi2 += b.y;
+    }
+    double t1 = (double)hi1 + (double)lo1 * 0x1p-50, t2 = (double)hi2 + (double)lo2 * 0x1p-50;
+    if (*st.bad) t1 = t2 = __builtin_nan("");
+    const double n = (double)st.count;
+    const double mean = t1 / n;
+    double var = t2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    BnCoef k;
+    k.inv = (float)(1.0 / sqrt(var + (double)st.eps));
+    k.mean = (float)mean;
+    k.scale = st.gamma[c] * k.inv;
+    k.shift = st.beta[c] - k.mean * k.scale;
+    if (writer) {
+        st.mean[c] = k.mean; st.invstd[c] = k.inv; st.scale[c] = k.scale; st.shift[c] = k.shift;
+        if (st.running_mean) {
+            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            st.running_mean[c] = (1.f - st.momentum) * st.running_mean[c] + st.momentum * k.mean;
+            st.running_var[c] = (1.f - st.momentum) * st.running_var[c] + st.momentum * (float)unb;
+        }
+        if (c == 0 && st.num_batches_tracked) *st.num_batches_tracked += 1;
+    }
+    return k;
+}
+
 // ---- operand loaders -----------------------------------------------------------------------------------------
 // Per-thread cached coefficient pack for 4 consecutive channels of a pq_src.
 struct SrcCoef4 {
@@ -54,14 +101,25 @@ struct SrcCoef4 {
 __device__ __forceinline__ float fq_act(float v, float qs, float qinv, float qzp) {
     return (fminf(fmaxf(rintf(v * qinv) + qzp, 0.f), 255.f) - qzp) * qs;
 }
-__device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C) {
+// stat_writer: with s.stat (statistics handed over by the producer, pq_bn_stat) this thread is the one of the whole grid that
+// stores the BatchNorm vectors of these 4 channels (callers pass "first row block of the grid && first lane of the channel quad").
+__device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C, bool stat_writer = false) {
     SrcCoef4 k;
     k.act = act_param(s.act);
-    k.affine = s.scale != nullptr;
+    k.affine = s.scale != nullptr || s.stat.acc != nullptr;
     k.q = s.qstate != nullptr;
     k.qs = k.q ? s.qstate[2] : 1.f;
     k.qinv = k.q ? 1.f / k.qs : 1.f;
     k.qzp = k.q ? s.qstate[3] : 0.f;
+    if (s.stat.acc != nullptr) {            // uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            k.a[j] = 1.f; k.b[j] = 0.f;
+            if (c < C) { const BnCoef bc = bn_stat_coef(s.stat, c, stat_writer); k.a[j] = bc.scale; k.b[j] = bc.shift; }
+        }
+        return k;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int c = c0 + j;

@@ -33,6 +33,7 @@ struct DwTP {
     pq_gsink sink; float* wpartial;
     int B, IH, IW, OH, OW, C, C4, tilesH, tilesW;
     int minmax;       // forward: `partial` rows have 4 planes (+ per-channel min, max of the outputs)
+    int64_t* stat_acc; uint32_t* stat_bad; int stat_slots;     // forward: statistics into pq_bn_stat accumulators instead of rows
 };
 
 __device__ __forceinline__ float4 lds_px(const float4* tile, int pix, int q) { return tile[pix * PQP + q]; }
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
     const int c0 = (cq0 + q) * 4;
     const bool cok = cq0 + q < p.C4;
     const int cc = cok ? c0 : 0;                            // clamped channel offset for address generation
-    const SrcCoef4 xk = src_coef4(p.in, cc, p.C);
+    // (with p.in.stat: derived from the producer's accumulators; tile 0's first pixel lane stores the vectors of its quad)
+    const SrcCoef4 xk = src_coef4(p.in, cc, p.C, tIdx == 0 && pl == 0 && cok);
 
     // ---- stage the input tile (transform once, zero outside the image)
     constexpr int NPIX = T::ITH * T::ITW;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
             mn = f4min(mn, acc[u]); mx = f4max(mx, acc[u]);
         }
     }
-    if (p.partial) {      // uniform
+    if (p.partial || p.stat_acc) {      // uniform
         const int planes = p.minmax ? 4 : 2;
         float* slot = red + (pl * 8 + q) * 8;
         slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
@@ -133,7 +135,10 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
             const int c = (cq0 + qq) * 4 + (comp & 3);
-            if (c < p.C) p.partial[(size_t)tIdx * planes * p.ldp + (comp >> 2) * p.ldp + c] = a;
+            if (c < p.C) {
+                if (p.stat_acc) bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, p.ldp, tIdx, comp >> 2, c, a);
+                else p.partial[(size_t)tIdx * planes * p.ldp + (comp >> 2) * p.ldp + c] = a;
+            }
         }
         if (p.minmax) {   // planes 2 / 3: per-channel extremes of the tile (QAT observers)
             __syncthreads();
@@ -785,11 +790,16 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1)");
     PQ_CHECK_ARG((a->in.ld & 3) == 0 && (a->ldo & 3) == 0, "pitches must be multiples of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
-    if (!dw_fwd_use_tiled(a->OH, a->OW, a->stride)) return pq_dw_fwd_stream(a, stream);
+    if (!dw_fwd_use_tiled(a->OH, a->OW, a->stride)) {
+        if (a->stat_acc || a->in.stat.acc) { pq_set_error("pq_dw3x3_fwd: the statistics hand-over needs the LDS-tiled kernel (ask pq_bn_stat_ok first)"); return PQ_EUNSUPPORTED; }
+        return pq_dw_fwd_stream(a, stream);
+    }
     DwTP p{};
     p.in = a->in; p.w = a->w; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
     p.minmax = (a->partial && a->minmax) ? 1 : 0;
+    PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->minmax == 0 && a->ldp >= a->C), "stat_acc needs stat_bad, no minmax");
+    p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
     fwd_tiles(a->OH, a->OW, a->stride, p.tilesH, p.tilesW);
     dim3 grid(a->B * p.tilesH * p.tilesW, (p.C4 + CBQ - 1) / CBQ), blk(256);
     hipStream_t st = (hipStream_t)stream;
@@ -797,6 +807,12 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     else hipLaunchKernelGGL((dwt_fwd_kernel<2>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
+}
+
+// pq_bn_stat_ok for PQ_OP_DW_FWD: producer and consumer roles both need the LDS-tiled kernel (planes up to 64 x 64)
+int dw_fwd_stat_ok(const pq_dw3x3_fwd_args* a, int role) {
+    (void)role;
+    return a && !a->minmax && !a->in.qstate && dw_fwd_use_tiled(a->OH, a->OW, a->stride);
 }
 
 extern "C" int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t C, int32_t stride) {

@@ -263,8 +263,10 @@ __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
     xcd_block(bx, by);
     const int c4 = by * blockDim.x + threadIdx.x, c0 = c4 * 4;
     if (c4 >= p.C4) return;
-    const SrcCoef4 ka = src_coef4(a.a, c0, a.C);
-    const SrcCoef4 kb = src_coef4(a.b, c0, a.C);
+    // (with a.a.stat / a.b.stat: derived from the producer's accumulators; the first row block's first row lane stores the vectors)
+    const bool wr = bx == 0 && threadIdx.y == 0;
+    const SrcCoef4 ka = src_coef4(a.a, c0, a.C, wr);
+    const SrcCoef4 kb = src_coef4(a.b, c0, a.C, wr);
     const bool two = a.b.x != nullptr;
     const int rows = a.B * a.H * a.W;
     const int SH = a.H / a.up, SW = a.W / a.up;

@@ -28,6 +28,7 @@ struct GemmP {
     int M, N, K;
     // epilogue 0/1
     float* out; const float* bias; float* partial; int ldo, ldp;
+    int64_t* stat_acc; uint32_t* stat_bad; int stat_slots;     // epilogue 1: statistics into pq_bn_stat accumulators
     // epilogue 2
     pq_gsink sink;
 };
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
             }
         }
     } else {
-        want_stats = (EMODE == 1 || EMODE == 3) && p.partial != nullptr;
+        want_stats = (EMODE == 1 || EMODE == 3) && (p.partial != nullptr || p.stat_acc != nullptr);
         // Output tiles leave through LDS: a wave parks one 32x32 accumulator tile in its own 32x36 patch (lane = column, as the
         // MFMA delivers it) and reads it back as rows, so the tile is written with 4 x 16-byte-per-lane stores (8 full 128-byte
         // row segments each) instead of 16 dword stores.  Same-wave LDS traffic is ordered, no barrier inside the loop.
@@ -495,7 +496,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
             for (int q = 0; q < BM / WM; ++q) { a += red[(0 * 4 + q) * 192 + t]; b += red[(1 * 4 + q) * 192 + t]; }
             const int n = n0 + t;
-            if (n < N) {
+            if (n < N && EMODE == 1 && p.stat_acc != nullptr) {   // no finalize launch: the first consumer derives the coefficients
+                bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 0, n, a);
+                bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 1, n, b);
+            } else if (n < N) {
                 float* dst = part + (size_t)bmy * PLANES * ldp;
                 dst[n] = a;
                 dst[ldp + n] = b;
@@ -831,21 +835,28 @@ static int conv1x1_fwd_impl(const pq_conv1x1_fwd_args* a, void* stream, pq_gemm_
     p.sub = a->sub; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->O; p.K = a->I;
     p.out = a->out; p.bias = a->bias; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
+    p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
+    PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->minmax == 0 && a->ldp >= a->O), "stat_acc needs stat_bad, no minmax");
     hipStream_t st = (hipStream_t)stream;
     const bool xform = a->in.scale != nullptr || a->in.act != PQ_ACT_LINEAR || a->in.qstate != nullptr;
     const int bm = row_bm(a->M, a->O, a->I, 0);
     const bool minmax = a->partial != nullptr && a->minmax != 0;      // QAT only: the round-1 kernels carry the 4-plane epilogue
+    const bool stats = a->partial != nullptr || a->stat_acc != nullptr;
     if (!minmax) {
         const int rc = g2_conv1x1_fwd(a, bm, st, plan);
         if (rc < 0) return rc;
         if (rc == 1) { if (plan) return PQ_OK; PQ_CHECK_LAUNCH(); return PQ_OK; }
     }
+    if (a->in.stat.acc != nullptr) {      // only the LDS-DMA ring kernels derive the operand's BatchNorm from accumulators
+        pq_set_error("pq_conv1x1_fwd: in.stat is not supported for this shape (ask pq_bn_stat_ok first)");
+        return PQ_EUNSUPPORTED;
+    }
     if (xform) {
         if (minmax) launch_nt<1, false, 3>(p, st, bm, plan);
-        else if (a->partial) launch_nt<1, false, 1>(p, st, bm, plan); else launch_nt<1, false, 0>(p, st, bm, plan);
+        else if (stats) launch_nt<1, false, 1>(p, st, bm, plan); else launch_nt<1, false, 0>(p, st, bm, plan);
     } else {
         if (minmax) launch_nt<0, false, 3>(p, st, bm, plan);
-        else if (a->partial) launch_nt<0, false, 1>(p, st, bm, plan); else launch_nt<0, false, 0>(p, st, bm, plan);
+        else if (stats) launch_nt<0, false, 1>(p, st, bm, plan); else launch_nt<0, false, 0>(p, st, bm, plan);
     }
     if (plan) return PQ_OK;
     PQ_CHECK_LAUNCH();
@@ -855,6 +866,18 @@ extern "C" int pq_conv1x1_fwd(const pq_conv1x1_fwd_args* a, void* stream) { retu
 extern "C" int pq_conv1x1_fwd_plan(const pq_conv1x1_fwd_args* a, pq_gemm_plan* out) {
     PQ_CHECK_ARG(out, "null pointer");
     return conv1x1_fwd_impl(a, nullptr, out);
+}
+// pq_bn_stat_ok for PQ_OP_CONV1X1_FWD: both kernel families can ADD their statistics (role 0, no 4-plane rows); only the ring
+// kernels derive the operand's coefficients from accumulators (role 1)
+int conv1x1_fwd_stat_ok(const pq_conv1x1_fwd_args* a, int role) {
+    if (!a || a->minmax) return 0;
+    if (role == 0) return 1;
+    pq_conv1x1_fwd_args b = *a;
+    b.in.stat.acc = reinterpret_cast<int64_t*>(uintptr_t(256));        // ask the dispatch as if the hand-over were on
+    if (!b.in.scale) b.in.scale = b.in.shift = reinterpret_cast<const float*>(uintptr_t(256));
+    pq_gemm_plan pl{};
+    if (conv1x1_fwd_impl(&b, nullptr, &pl) != PQ_OK) return 0;
+    return pl.family == 2 && pl.amode == 3;
 }
 
 static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_gemm_plan* plan) {

@@ -34,6 +34,7 @@ __device__ __forceinline__ void wait_tiles(int tiles) {
 // B operand of the half k-tile at the end of a contraction that is 16 modulo 32 (see gemm2_nt_kernel)
 __device__ __attribute__((aligned(16))) float g2_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
+constexpr int G2_STAT_KMAX = 1280;       // AMODE 3: longest contraction whose coefficient table fits behind the ring
 __device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 struct G2P {
@@ -44,10 +45,14 @@ struct G2P {
     const float* b; int ldb;                                              // [N][ldb], contraction index contiguous
     int M, N, K;
     float* out; const float* bias; float* partial; int ldo, ldp;          // EMODE 0 / 1
+    int64_t* stat_acc; uint32_t* stat_bad; int stat_slots;                // EMODE 1: statistics into pq_bn_stat accumulators
     pq_gsink sink;                                                        // EMODE 2
+    pq_bn_stat stat;                                                      // AMODE 3: the operand's BatchNorm, derived in the prologue
 };
 
-// AMODE 0: A as stored; 1: clamp(c0*a + c1, lo, hi); 2: c0*g + c1*(y - c2) + c3.   EMODE 0: store(+bias); 1: + statistics;
+// AMODE 0: A as stored; 1: clamp(c0*a + c1, lo, hi); 2: c0*g + c1*(y - c2) + c3; 3: as 1, but (c0, c1) = BatchNorm scale / shift
+// DERIVED in the prologue from the producer's statistic accumulators (pq_bn_stat: no finalize launch in between) into an LDS table
+// behind the ring -- nothing rides in the ring for them.   EMODE 0: store(+bias); 1: + statistics;
 // 2: gradient sink (16-byte rows only: the host checks alignment).   K % 32 == 0, or K % 32 == 16 (RegNetX widths 48 / 80 /
 // 176 / 240 / 528): the last k-tile is then half valid -- its upper four chunks of B come from g2_zero, those of A and of the
 // coefficient vectors repeat the lower four (finite values times zero), so the loop itself is unchanged.
@@ -138,7 +143,9 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
 
     const int swz = (lrow >> 1) & 7;
     const float lo = p.lo, hi = p.hi;
-    auto compute = [&](int s) {
+    const int Kp = nk * 32;
+    float* ctab = lds + S * STAGE;                 // AMODE 3: [2][Kp] scale, shift
+    auto compute = [&](int s, int kt) {
         const float* As = lds + s * STAGE;
         const float* Bs = As + NA * A_FL;
         const float* Cs = Bs + B_FL + w * CW;
@@ -158,9 +165,9 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
             for (int j = 0; j < TJ; ++j) { bk[j][0] = bf[j].x; bk[j][1] = bf[j].y; bk[j][2] = bf[j].z; bk[j][3] = bf[j].w; }
 #pragma unroll
             for (int i = 0; i < TI; ++i) { ak[i][0] = af[i].x; ak[i][1] = af[i].y; ak[i][2] = af[i].z; ak[i][3] = af[i].w; }
-            if (AMODE == 1) {
-                const float4 c0 = *reinterpret_cast<const float4*>(&Cs[ks * 8 + 4 * lh]);
-                const float4 c1 = *reinterpret_cast<const float4*>(&Cs[32 + ks * 8 + 4 * lh]);
+            if (AMODE == 1 || AMODE == 3) {
+                const float4 c0 = *reinterpret_cast<const float4*>(AMODE == 1 ? &Cs[ks * 8 + 4 * lh] : &ctab[kt * 32 + ks * 8 + 4 * lh]);
+                const float4 c1 = *reinterpret_cast<const float4*>(AMODE == 1 ? &Cs[32 + ks * 8 + 4 * lh] : &ctab[Kp + kt * 32 + ks * 8 + 4 * lh]);
                 const float s4[4] = {c0.x, c0.y, c0.z, c0.w}, h4[4] = {c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
@@ -193,12 +200,24 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < nk) issue(d, d);
+    if (AMODE == 3) {
+        // BatchNorm coefficients of the operand from the producer's accumulators, while the first tiles are in flight; logical
+        // workgroup (0, 0) also stores the vectors / running statistics for every later consumer (pq_bn_stat)
+        const bool writer = bmy == 0 && bnx == 0;
+        for (int k = t; k < Kp; k += 256) {
+            float sc = 0.f, sh = 0.f;
+            if (k < K) { const BnCoef bc = bn_stat_coef(p.stat, k, writer); sc = bc.scale; sh = bc.shift; }
+            ctab[k] = sc;
+            ctab[Kp + k] = sh;
+        }
+        __syncthreads();
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const int issued = min(nk, kt + D);
         wait_tiles<NL>(issued - kt - 1);
         __builtin_amdgcn_s_barrier();
         if (kt + D < nk) issue((kt + D) % S, kt + D);
-        compute(kt % S);
+        compute(kt % S, kt);
     }
     __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring: it becomes epilogue scratch
 
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
             }
         }
     } else {
-        want_stats = (EMODE == 1) && p.partial != nullptr;
+        want_stats = (EMODE == 1) && (p.partial != nullptr || p.stat_acc != nullptr);
         const bool vec_out = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
         float s1[TJ], s2[TJ];
 #pragma unroll
@@ -336,9 +355,14 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
             const float b = red[(1 * 2 + 0) * BN + t] + red[(1 * 2 + 1) * BN + t];
             const int n = n0 + t;
             if (n < N) {
-                float* dst = part + (size_t)bmy * 2 * ldp;
-                dst[n] = a;
-                dst[ldp + n] = b;
+                if (EMODE == 1 && p.stat_acc != nullptr) {       // no finalize launch: the first consumer derives the coefficients
+                    bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 0, n, a);
+                    bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 1, n, b);
+                } else {
+                    float* dst = part + (size_t)bmy * 2 * ldp;
+                    dst[n] = a;
+                    dst[ldp + n] = b;
+                }
             }
         }
     }
@@ -535,7 +559,7 @@ static int g2_launch_nt(const G2P& p, hipStream_t st, pq_gemm_plan* plan) {
     constexpr int NA = AMODE == 2 ? 2 : 1;
     constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);
     constexpr int STAGE = NA * BM * 32 + BN * 32 + 4 * CW;
-    constexpr size_t ring = (size_t)S * STAGE * 4, epi = (size_t)(4 * 32 * 36 + 4 * BN) * 4;
+    constexpr size_t ring = (size_t)S * STAGE * 4 + (AMODE == 3 ? (size_t)2 * G2_STAT_KMAX * 4 : 0), epi = (size_t)(4 * 32 * 36 + 4 * BN) * 4;
     constexpr size_t bytes = ring > epi ? ring : epi;
     static bool ok = g2_raise_lds((const void*)gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>, bytes);
     if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
@@ -581,14 +605,20 @@ int g2_conv1x1_fwd(const pq_conv1x1_fwd_args* a, int bm, hipStream_t st, pq_gemm
     if ((a->in.ld & 3) || (((uintptr_t)a->in.x) & 15) || (((uintptr_t)a->w) & 15)) return 0;
     G2P p{};
     if (!act_clamp(a->in.act, p.lo, p.hi)) return 0;
-    const bool xform = a->in.scale != nullptr;
+    const bool from_stat = a->in.stat.acc != nullptr;
+    if (from_stat && a->I > G2_STAT_KMAX) return 0;
+    const bool xform = a->in.scale != nullptr || from_stat;
     if (!xform && a->in.act != PQ_ACT_LINEAR) return 0;
     p.a0 = a->in.x; p.lda0 = a->in.ld; p.c0 = a->in.scale; p.c1 = a->in.shift;
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->O; p.K = a->I;
     p.out = a->out; p.bias = a->bias; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
+    p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
+    p.stat = a->in.stat;
+    const bool stats = a->partial != nullptr || a->stat_acc != nullptr;
     int rc;
-    if (xform) rc = a->partial ? g2_dispatch_nt<1, 1>(p, bm, st, plan) : g2_dispatch_nt<1, 0>(p, bm, st, plan);
-    else rc = a->partial ? g2_dispatch_nt<0, 1>(p, bm, st, plan) : g2_dispatch_nt<0, 0>(p, bm, st, plan);
+    if (from_stat) rc = stats ? g2_dispatch_nt<3, 1>(p, bm, st, plan) : g2_dispatch_nt<3, 0>(p, bm, st, plan);
+    else if (xform) rc = stats ? g2_dispatch_nt<1, 1>(p, bm, st, plan) : g2_dispatch_nt<1, 0>(p, bm, st, plan);
+    else rc = stats ? g2_dispatch_nt<0, 1>(p, bm, st, plan) : g2_dispatch_nt<0, 0>(p, bm, st, plan);
     return rc == PQ_OK ? 1 : rc;
 }
 

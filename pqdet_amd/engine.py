@@ -502,6 +502,12 @@ class Plan:
         # statistics not trained (inference, model.eval() losses, tools.freeze_bn_stats): the per-channel vectors of all
         # BatchNorms come from the running statistics in ONE launch at the start (slot filled in after the loop)
         bne_idx = self._op(self.fwd, abi.OP_BN_EVAL, abi.BnEval(None, 0)) if not self.bn_train else None
+        # train-mode BatchNorm statistics handed from producer to first consumer without a finalize launch (_handover_bn_stats):
+        # slot 0 clears the accumulators of all such layers (a no-op until the hand-over pass fills it in)
+        self._stat_fill_idx = None
+        if self.bn_train and not self.qat and os.environ.get('PQ_BN_ATOMIC', '1') != '0':
+            self._stat_dummy = self._new(4)
+            self._stat_fill_idx = self._op(self.fwd, abi.OP_FILL, abi.Fill(self._stat_dummy.data_ptr(), 0.0, 0))
         bne_items = []
         self.fwd_layer = [-1] * len(self.fwd)      # layer index of every forward op (-1: whole-net ops); tests replay single layers
         cur_layer = -1
@@ -659,6 +665,8 @@ class Plan:
                 self.fwd_two_streams = True
                 self.fwd_side_layers = sorted(side_layers)
                 self._check_side_forward()
+            self._handover_bn_stats()
+            return
         else:
             rows_total = sum(a.H * a.W * (a.C // (5 + m.opt['classes'])) for _, m, a in heads)
             nv = 5 + heads[0][1].opt['classes']
@@ -671,6 +679,66 @@ class Plan:
                 d = abi.Decode(view, ptr(self.eval_out), B, a.H, a.W, A, opt['classes'], opt['stride'], rows_total, row0)
                 self._op(self.fwd, abi.OP_DECODE, d)
                 row0 += a.H * a.W * A
+        self._handover_bn_stats()
+
+    def _handover_bn_stats(self):
+        """Drop the BatchNorm finalize launch between a conv and the FIRST consumer of its output wherever both kernels support
+        the hand-over (pq_bn_stat, include/pqdet_hip.h): the producer adds its statistic partials into exact fixed-point
+        accumulators, the consumer derives scale / shift in its prologue and its first workgroup stores the vectors (every later
+        consumer and the backward read those) and updates the running statistics.  Only on the main stream (a later side-stream
+        consumer forks after the first consumer, so it sees the vectors), only short partial lists (same-address atomics
+        serialise: scripts/probes/bnstat_probe.hip), never for QAT plans.  The finalize op becomes a no-op (no launch); a
+        dependent launch + its dispatch gap cost ~10 us per layer in the step."""
+        self.bn_handover = 0
+        if self._stat_fill_idx is None:
+            return
+        l = lib()
+        maxblk = int(os.environ.get('PQ_BN_ATOMIC_MAXBLK', '1024'))
+        picks, total = [], 0
+        for k in range(1, len(self.fwd) - 1):
+            op = self.fwd[k]
+            if op.code != abi.OP_BN_FWD_FIN or op.flags:
+                continue
+            f = op.u.bnf
+            if not f.train or f.planes == 4 or f.sf or f.nblk > maxblk or not f.partial:
+                continue
+            prod, cons = self.fwd[k - 1], self.fwd[k + 1]
+            if prod.flags or cons.flags or prod.code not in (abi.OP_CONV1X1_FWD, abi.OP_DW_FWD):
+                continue
+            pa = getattr(prod.u, abi.OP_FIELD[prod.code])
+            if pa.partial != f.partial or not l.pq_bn_stat_ok(prod.code, C.byref(pa), 0):
+                continue
+            if cons.code == abi.OP_CONV1X1_FWD:
+                srcs = [cons.u.c1f.inp]
+            elif cons.code == abi.OP_DW_FWD:
+                srcs = [cons.u.dwf.inp]
+            elif cons.code == abi.OP_COPY_FWD:
+                srcs = [cons.u.cp.a, cons.u.cp.b]
+            else:
+                continue
+            hit = [s_ for s_ in srcs if s_.x == pa.out and s_.scale == f.scale and not s_.qstate]
+            if len(hit) != 1 or not l.pq_bn_stat_ok(cons.code, C.byref(getattr(cons.u, abi.OP_FIELD[cons.code])), 1):
+                continue
+            slots = l.pq_bn_stat_slots(f.nblk)
+            nbytes = _round_up(l.pq_bn_stat_bytes(f.ldp, slots), 64)
+            picks.append((k, pa, hit[0], f, slots, total, total + nbytes))
+            total += nbytes + 64                         # + the layer's `bad` word on its own 64-byte line
+        if not picks:
+            return
+        arena = torch.zeros(total // 8, device=self.device, dtype=torch.int64)
+        self.keep.append(arena)
+        base = arena.data_ptr()
+        for k, pa, src, f, slots, off_acc, off_bad in picks:
+            pa.partial, pa.stat_acc, pa.stat_bad, pa.stat_slots = None, base + off_acc, base + off_bad, slots
+            src.stat = abi.BnStat(base + off_acc, base + off_bad, f.gamma, f.beta, f.running_mean, f.running_var,
+                                  f.num_batches_tracked, f.mean, f.invstd, f.scale, f.shift, slots, f.ldp, f.count, f.eps,
+                                  f.momentum)
+            nop = abi.Op()
+            nop.code = abi.OP_FILL
+            nop.u.fill = abi.Fill(self._stat_dummy.data_ptr(), 0.0, 0)
+            self.fwd[k] = nop
+        self.fwd[self._stat_fill_idx].u.fill = abi.Fill(base, 0.0, total // 4)
+        self.bn_handover = len(picks)
 
     def _check_side_forward(self):
         """Plan-level proof of the two-stream forward's race freedom: every buffer a side op writes is read only by LATER side

@@ -1,0 +1,245 @@
+"""BatchNorm statistics handed from the producing kernel to its first consumer without a finalize launch (pq_bn_stat,
+include/pqdet_hip.h): the producer's fixed-point accumulators hold the EXACT sum of its fp32 partials (order independent), the
+consumer derives the same coefficients pq_bn_fwd_finalize would and its first workgroup stores the vectors / running statistics
+-- checked per kernel pair against nn.BatchNorm2d (model/parser.py:404-405) and, for the whole step, against the plan that keeps
+the finalize launches (PQ_BN_ATOMIC=0)."""
+import ctypes as C
+import io
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import test_kernels_gpu as K  # noqa: E402
+from pqdet_amd import abi  # noqa: E402
+from pqdet_amd.model import zoo  # noqa: E402
+from pqdet_amd.model.interpreter import DetectionModel  # noqa: E402
+from seedfill import seeded_fill  # noqa: E402
+
+DEV = 'cuda'
+
+
+class Stat:
+    """Accumulators + BatchNorm state of one layer, as the engine's hand-over pass sets them up."""
+
+    def __init__(self, Cc, nblk, count, g):
+        l = abi.lib()
+        self.C, self.ldp, self.count = Cc, (Cc + 15) // 16 * 16, float(count)
+        self.slots = l.pq_bn_stat_slots(nblk)
+        self.acc = torch.zeros(l.pq_bn_stat_bytes(self.ldp, self.slots) // 8, dtype=torch.int64, device=DEV)
+        self.bad = torch.zeros(16, dtype=torch.int32, device=DEV)
+        self.bn = torch.nn.BatchNorm2d(Cc)
+        with torch.no_grad():
+            self.bn.weight.copy_(torch.rand(Cc, generator=g) + 0.5)
+            self.bn.bias.copy_(K.rnd(Cc, g=g, scale=0.5))
+            self.bn.running_mean.copy_(K.rnd(Cc, g=g))
+            self.bn.running_var.copy_(torch.rand(Cc, generator=g) + 0.5)
+        self.gamma, self.beta = K.chan_vec(self.bn.weight.detach()), K.chan_vec(self.bn.bias.detach())
+        self.rm, self.rv = K.chan_vec(self.bn.running_mean), K.chan_vec(self.bn.running_var)
+        self.nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+        self.mean, self.inv, self.scale, self.shift = (torch.full((self.ldp + 16,), float('nan'), device=DEV) for _ in range(4))
+
+    def struct(self):
+        return abi.BnStat(self.acc.data_ptr(), self.bad.data_ptr(), self.gamma.data_ptr(), self.beta.data_ptr(), self.rm.data_ptr(),
+                          self.rv.data_ptr(), self.nbt.data_ptr(), self.mean.data_ptr(), self.inv.data_ptr(), self.scale.data_ptr(),
+                          self.shift.data_ptr(), self.slots, self.ldp, self.count, 1e-5, 0.1)
+
+    def sums(self):
+        a = self.acc.cpu().view(self.slots, 2, self.ldp, 2).double()
+        v = (a[..., 1] + a[..., 0] * 2.0 ** -50).sum(0)
+        return v[0, :self.C], v[1, :self.C]
+
+    def check_against(self, y):
+        """y: the raw (M, C) tensor the statistics describe (CPU).  Sums, vectors and running statistics vs BatchNorm2d."""
+        s1, s2 = self.sums()
+        yd = y.double()
+        K.close(s1.float(), yd.sum(0).float(), rt=1e-5, at=1e-3 * math.sqrt(y.shape[0] / 4096 + 1), what='sum x')
+        K.close(s2.float(), (yd ** 2).sum(0).float(), rt=1e-5, at=1e-3 * math.sqrt(y.shape[0] / 4096 + 1), what='sum x^2')
+        self.bn.train()
+        out = self.bn(y.t().reshape(1, self.C, -1, 1))            # updates the running statistics like one train step
+        mean, var = yd.mean(0), yd.var(0, unbiased=False)
+        inv = 1 / torch.sqrt(var + 1e-5)
+        K.close(self.mean[:self.C], mean.float(), rt=1e-5, at=1e-6, what='mean')
+        K.close(self.inv[:self.C], inv.float(), rt=1e-5, at=1e-6, what='invstd')
+        K.close(self.scale[:self.C], (self.bn.weight.detach().double() * inv).float(), rt=1e-5, at=1e-6, what='scale')
+        K.close(self.shift[:self.C], (self.bn.bias.detach().double() - mean * self.bn.weight.detach().double() * inv).float(), rt=1e-4, at=1e-5, what='shift')
+        K.close(self.rm[:self.C], self.bn.running_mean, rt=1e-5, at=1e-6, what='running_mean')
+        K.close(self.rv[:self.C], self.bn.running_var, rt=1e-5, at=1e-6, what='running_var')
+        assert self.nbt.item() == 1 and int(self.bad[0]) == 0
+        return out.reshape(self.C, -1).t()                         # BatchNorm2d's normalised tensor (M, C)
+
+
+@pytest.mark.parametrize('M,I,O,C2', [(4096, 160, 960, 160),      # ring kernel -> ring kernel (project conv), 64 row blocks, 1 slot
+                                      (16384, 64, 384, 64),       # register-staged producer (K = 64), 256 row blocks: 4 slots
+                                      (65536, 128, 256, 128),     # 512 row blocks of 128: 16 slots
+                                      (4000, 144, 200, 75)])      # ragged rows / columns
+def test_conv1x1_to_conv1x1_handover(M, I, O, C2):
+    """conv A (stats -> accumulators) -> BatchNorm + ReLU6 -> conv B (coefficients derived in its prologue)."""
+    l = abi.lib()
+    g = torch.Generator().manual_seed(M + I + O)
+    x = K.rnd(M, I, g=g)
+    wA = K.rnd(O, I, g=g, scale=1 / math.sqrt(I))
+    wB = K.rnd(C2, O, g=g, scale=1 / math.sqrt(O))
+    yA = x @ wA.t()
+    nblk = l.pq_conv1x1_blocks_k(M, O, I, 0)
+    st = Stat(O, nblk, M, g)
+    xd, wAd, wBd = x.to(DEV), wA.to(DEV), wB.to(DEV)
+    ya = torch.full((M, O), float('nan'), device=DEV)
+    a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, 0), wAd.data_ptr(), None, ya.data_ptr(), None, M, I, O, O, st.ldp,
+                       1, 0, 0, 0, 0)
+    a.stat_acc, a.stat_bad, a.stat_slots = st.acc.data_ptr(), st.bad.data_ptr(), st.slots
+    assert l.pq_bn_stat_ok(abi.OP_CONV1X1_FWD, C.byref(a), 0) == 1
+    abi.check(l.pq_conv1x1_fwd(C.byref(a), K.stream()))
+    ldo = (C2 + 3) // 4 * 4
+    yb = torch.full((M, ldo), float('nan'), device=DEV)
+    b = abi.Conv1x1Fwd(abi.Src(ya.data_ptr(), None, None, O, 2), wBd.data_ptr(), None, yb.data_ptr(), None, M, O, C2, ldo, 0,
+                       1, 0, 0, 0, 0)
+    b.inp.stat = st.struct()
+    assert l.pq_bn_stat_ok(abi.OP_CONV1X1_FWD, C.byref(b), 1) == 1
+    plan = K.gemm_plan('fwd', b)
+    assert plan[0] == 2 and plan[4] == 3, plan                     # LDS-DMA ring kernel, AMODE 3
+    abi.check(l.pq_conv1x1_fwd(C.byref(b), K.stream()))
+    torch.cuda.synchronize()
+    K.close(ya, yA, what='conv A')
+    norm = st.check_against(ya.cpu())
+    want = norm.detach().clamp(0, 6) @ wB.t()
+    K.close(yb[:, :C2], want, rt=1e-3, at=2e-4, what='conv B on the handed-over BatchNorm')
+    # a later consumer reads the stored vectors: same result through the ordinary path
+    yb2 = torch.full((M, ldo), float('nan'), device=DEV)
+    b2 = abi.Conv1x1Fwd(abi.Src(ya.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), O, 2), wBd.data_ptr(), None, yb2.data_ptr(),
+                        None, M, O, C2, ldo, 0, 1, 0, 0, 0, 0)
+    abi.check(l.pq_conv1x1_fwd(C.byref(b2), K.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(yb2[:, :C2], yb[:, :C2])                    # same coefficients, same kernel arithmetic
+
+
+def test_unsupported_consumers_say_so():
+    l = abi.lib()
+    x = torch.zeros(1024, 32, device=DEV)
+    w = torch.zeros(64, 32, device=DEV)
+    out = torch.zeros(1024, 64, device=DEV)
+    b = abi.Conv1x1Fwd(abi.Src(x.data_ptr(), None, None, 32, 2), w.data_ptr(), None, out.data_ptr(), None, 1024, 32, 64, 64, 0,
+                       1, 0, 0, 0, 0)
+    assert l.pq_bn_stat_ok(abi.OP_CONV1X1_FWD, C.byref(b), 1) == 0          # K = 32: register-staged kernel
+    b.inp.stat.acc = x.data_ptr()
+    assert l.pq_conv1x1_fwd(C.byref(b), K.stream()) == -3                    # PQ_EUNSUPPORTED, loudly
+    assert l.pq_bn_stat_ok(abi.OP_DW_DGRAD, C.byref(b), 1) == 0
+
+
+@pytest.mark.parametrize('B,H,W,Cc,stride', [(2, 32, 32, 96, 1), (4, 64, 64, 32, 2), (3, 16, 16, 200, 1)])
+def test_conv1x1_to_depthwise_to_conv1x1_handover(B, H, W, Cc, stride):
+    """expand conv -> BN + ReLU6 -> depthwise 3x3 (consumer AND producer of a hand-over) -> BN + ReLU6 -> project conv."""
+    l = abi.lib()
+    g = torch.Generator().manual_seed(B * H * W + Cc)
+    I, O2 = 128, 64
+    M = B * H * W
+    x = K.rnd(M, I, g=g)
+    wA = K.rnd(Cc, I, g=g, scale=1 / math.sqrt(I))
+    wD = K.rnd(Cc, 1, 3, 3, g=g, scale=0.4)
+    wB = K.rnd(O2, Cc, g=g, scale=1 / math.sqrt(Cc))
+    P = (Cc + 3) // 4 * 4
+    xd, wAd, wDd, wBd = x.to(DEV), wA.to(DEV), wD.to(DEV), wB.to(DEV)
+    st1 = Stat(Cc, l.pq_conv1x1_blocks_k(M, Cc, I, 0), M, g)
+    ya = torch.zeros(M, P, device=DEV)
+    a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, 0), wAd.data_ptr(), None, ya.data_ptr(), None, M, I, Cc, P, st1.ldp,
+                       1, 0, 0, 0, 0)
+    a.stat_acc, a.stat_bad, a.stat_slots = st1.acc.data_ptr(), st1.bad.data_ptr(), st1.slots
+    abi.check(l.pq_conv1x1_fwd(C.byref(a), K.stream()))
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    M2 = B * OH * OW
+    st2 = Stat(Cc, l.pq_dw3x3_fwd_blocks(B, OH, OW, Cc, stride), M2, g)
+    yd_ = torch.zeros(M2, P, device=DEV)
+    d = abi.DwFwd(abi.Src(ya.data_ptr(), None, None, P, 2), wDd.data_ptr(), yd_.data_ptr(), None, B, H, W, OH, OW, Cc, stride,
+                  P, st2.ldp)
+    d.inp.stat = st1.struct()
+    d.stat_acc, d.stat_bad, d.stat_slots = st2.acc.data_ptr(), st2.bad.data_ptr(), st2.slots
+    assert l.pq_bn_stat_ok(abi.OP_DW_FWD, C.byref(d), 0) == 1 and l.pq_bn_stat_ok(abi.OP_DW_FWD, C.byref(d), 1) == 1
+    abi.check(l.pq_dw3x3_fwd(C.byref(d), K.stream()))
+    yb = torch.zeros(M2, O2, device=DEV)
+    b = abi.Conv1x1Fwd(abi.Src(yd_.data_ptr(), None, None, P, 2), wBd.data_ptr(), None, yb.data_ptr(), None, M2, Cc, O2, O2, 0,
+                       1, 0, 0, 0, 0)
+    b.inp.stat = st2.struct()
+    ok_b = l.pq_bn_stat_ok(abi.OP_CONV1X1_FWD, C.byref(b), 1)
+    if not ok_b:                                       # e.g. K = 200 (not a multiple of 16): finalize-free hand-over not offered
+        pytest.skip('project conv shape is outside the ring kernels')
+    abi.check(l.pq_conv1x1_fwd(C.byref(b), K.stream()))
+    torch.cuda.synchronize()
+    n1 = st1.check_against(ya[:, :Cc].cpu())
+    act1 = n1.detach().clamp(0, 6).reshape(B, H, W, Cc).permute(0, 3, 1, 2)
+    yD = F.conv2d(act1, wD, stride=stride, padding=1, groups=Cc).permute(0, 2, 3, 1).reshape(M2, Cc)
+    K.close(yd_[:, :Cc], yD, rt=1e-3, at=2e-4, what='depthwise on the handed-over BatchNorm')
+    n2 = st2.check_against(yd_[:, :Cc].cpu())
+    K.close(yb, n2.detach().clamp(0, 6) @ wB.t(), rt=1e-3, at=2e-4, what='project conv')
+
+
+def test_shortcut_handover_and_nan_poison():
+    """project conv -> BN (linear) -> shortcut add (copy_fwd derives the coefficients); then a NaN in the producer's output
+    must reach the statistics (the step's NaN trap depends on it)."""
+    l = abi.lib()
+    g = torch.Generator().manual_seed(3)
+    B, H, W, I, Cc = 2, 32, 32, 192, 32
+    M = B * H * W
+    x, other = K.rnd(M, I, g=g), K.rnd(M, Cc, g=g)
+    wA = K.rnd(Cc, I, g=g, scale=1 / math.sqrt(I))
+    xd, od, wAd = x.to(DEV), other.to(DEV), wA.to(DEV)
+    for poison in (False, True):
+        if poison:
+            xd = xd.clone()
+            xd[5, 7] = float('nan')
+        st = Stat(Cc, l.pq_conv1x1_blocks_k(M, Cc, I, 0), M, g)
+        ya = torch.zeros(M, Cc, device=DEV)
+        a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, 0), wAd.data_ptr(), None, ya.data_ptr(), None, M, I, Cc, Cc, st.ldp,
+                           1, 0, 0, 0, 0)
+        a.stat_acc, a.stat_bad, a.stat_slots = st.acc.data_ptr(), st.bad.data_ptr(), st.slots
+        abi.check(l.pq_conv1x1_fwd(C.byref(a), K.stream()))
+        out = torch.zeros(M, Cc, device=DEV)
+        c = abi.Copy(abi.Src(ya.data_ptr(), None, None, Cc, 0), abi.Src(od.data_ptr(), None, None, Cc, 0), out.data_ptr(), B, H, W, Cc,
+                     Cc, 0, 1)
+        c.a.stat = st.struct()
+        assert l.pq_bn_stat_ok(abi.OP_COPY_FWD, C.byref(c), 1) == 1
+        abi.check(l.pq_copy_fwd(C.byref(c), K.stream()))
+        torch.cuda.synchronize()
+        if poison:
+            assert int(st.bad[0]) == 1 and torch.isnan(st.mean[:Cc]).all() and torch.isnan(out).all()
+        else:
+            norm = st.check_against(ya.cpu())
+            K.close(out, norm.detach() + other, rt=1e-3, at=2e-4, what='shortcut on the handed-over BatchNorm')
+
+
+@pytest.mark.parametrize('name', ['mobilenetv2-fpn', 'regnetx-600m-fpn'])
+def test_step_with_handover_equals_step_with_finalize_launches(name, monkeypatch):
+    """Whole train step: PQ_BN_ATOMIC=0 (a finalize launch per BatchNorm) against the default hand-over.  The statistics are the
+    same numbers up to the last bit of an fp64 sum (exact integer accumulation vs a fixed-order fp64 sum), so losses, running
+    statistics and gradients agree far inside the fp32 noise of the step; the hand-over plan replays bit-identically."""
+    from test_model_gpu import _targets
+    from seedfill import seeded_images
+    runs = {}
+    for mode in ('1', '0', '1'):
+        monkeypatch.setenv('PQ_BN_ATOMIC', mode)
+        net = DetectionModel(io.StringIO(zoo.cfg_text(name)))
+        seeded_fill(net, 4)
+        net = net.to(DEV)
+        net.train()
+        x = seeded_images(4, 256, 256, 3).to(DEV)
+        tgt = tuple(t.to(DEV) for t in _targets(4, 256, 256, 20, seed=9))
+        out = net(x, tgt)
+        out['loss'].mean().backward()
+        net.check_nan()
+        plan = list(net._plans.values())[0]
+        rec = (torch.stack([out[k] for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss')]).detach().clone(), net._flat.grad.clone(),
+               torch.cat([b_.detach().flatten().float() for b_ in net.buffers()]), plan.bn_handover, net)
+        runs.setdefault(mode, []).append(rec)
+    on, off = runs['1'][0], runs['0'][0]
+    assert on[3] >= 20 and off[3] == 0, (on[3], off[3])
+    assert torch.equal(runs['1'][0][0], runs['1'][1][0]) and torch.equal(runs['1'][0][1], runs['1'][1][1])     # deterministic
+    assert torch.equal(runs['1'][0][2], runs['1'][1][2])
+    assert ((on[0] - off[0]).abs() <= 1e-5 * off[0].abs()).all(), (on[0], off[0])
+    assert ((on[2] - off[2]).abs() <= 1e-5 * off[2].abs() + 1e-6).all()                                        # running statistics
+    flat = on[4]._flat
+    gmax = max(off[1][o:o + p.numel()].double().norm().item() for p, o in zip(flat.params, flat.offsets))
+    for p, o in zip(flat.params, flat.offsets):
+        da, db = on[1][o:o + p.numel()].double(), off[1][o:o + p.numel()].double()
+        assert (da - db).norm().item() <= 2e-3 * db.norm().item() + 1e-6 * gmax, (o, (da - db).norm().item(), db.norm().item())
