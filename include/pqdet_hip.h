@@ -41,8 +41,8 @@ enum { PQ_BOX_L1 = 0, PQ_BOX_GIOU = 1, PQ_BOX_DIOU = 2, PQ_BOX_CIOU = 3, PQ_BOX_
  *             independent of the arrival order: run-to-run deterministic).  `slots` replicas (row block b adds to slot
  *             b % slots) keep same-address contention low.  A non-finite / out-of-range partial sets *bad instead.
  *   consumer: every workgroup derives mean / invstd / scale / shift of the channels it touches from `acc` in its prologue
- *             (same arithmetic as pq_bn_fwd_finalize: fp64 mean and biased variance, invstd = 1 / sqrt(var + eps) rounded to
- *             fp32); the first workgroup of the grid also stores the four vectors (for every later consumer and for the
+ *             (mean and biased variance E[x^2] - mean^2 in fp64 like pq_bn_fwd_finalize, invstd = 1 / sqrt(var + eps) in fp32:
+ *             within an ulp of the finalize kernel's value); the first workgroup of the grid also stores the four vectors (for every later consumer and for the
  *             backward) and updates the running statistics and num_batches_tracked.
  * acc and *bad must be zero when the producer starts (the engine clears the arena of all layers with one pq_fill per step). */
 typedef struct pq_bn_stat {
@@ -59,6 +59,7 @@ typedef struct pq_bn_stat {
     float* shift;
     int32_t slots, ldp;
     float count, eps, momentum;
+    float inv_count;         /* 1 / count */
 } pq_bn_stat;
 
 /* forward-value operand:  v[row][c] = act(scale[c] * x[row*ld + c] + shift[c]);  scale==NULL => identity affine;

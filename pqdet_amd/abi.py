@@ -24,7 +24,7 @@ BOX_KIND = {'l1': BOX_L1, 'giou': BOX_GIOU, 'diou': BOX_DIOU, 'ciou': BOX_CIOU, 
 class BnStat(C.Structure):
     _fields_ = [('acc', c_fp), ('bad', c_fp), ('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp),
                 ('num_batches_tracked', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp), ('shift', c_fp),
-                ('slots', i32), ('ldp', i32), ('count', f32), ('eps', f32), ('momentum', f32)]
+                ('slots', i32), ('ldp', i32), ('count', f32), ('eps', f32), ('momentum', f32), ('inv_count', f32)]
 
 
 class Src(C.Structure):

@@ -280,8 +280,9 @@ extern "C" int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role) {
 }
 extern "C" int64_t pq_bn_stat_bytes(int32_t ldp, int32_t slots) { return (int64_t)(slots > 0 ? slots : 1) * 2 * ldp * 2 * 8; }
 // replicas by the number of row blocks that add to one channel: ~64 same-address atomics in flight cost nothing, 512 cost 12 us
-// (scripts/probes/bnstat_probe.hip)
-extern "C" int32_t pq_bn_stat_slots(int32_t nblk) { return nblk <= 96 ? 1 : (nblk <= 384 ? 4 : 16); }
+// (scripts/probes/bnstat_probe.hip); never more than 4, because EVERY workgroup of the consumer reads slots x 2 x 16 bytes per
+// channel (16 replicas made the consumers' prologues cost more than the finalize launch they replace)
+extern "C" int32_t pq_bn_stat_slots(int32_t nblk) { return nblk <= 96 ? 1 : 4; }
 
 extern "C" int32_t pq_abi_sizeof(int32_t code) {
     switch (code) {

@@ -56,30 +56,49 @@ __device__ __forceinline__ void bn_stat_add(int64_t* acc, uint32_t* bad, int slo
     if (l) atomicAdd(d, (unsigned long long)l);
     if (h) atomicAdd(d + 1, (unsigned long long)h);
 }
-// consumer side: scale / shift (and mean / invstd) of channel c from the accumulators; same arithmetic as bn_fwd_finalize_kernel.
+// consumer side: scale / shift (and mean / invstd) of channel c from the accumulators.  Called by ONE thread per channel and
+// workgroup (the callers share the result through LDS): every workgroup of the consumer grid repeats this, so it is kept to two
+// 16-byte loads per slot and a handful of fp64 operations -- mean and E[x^2] - mean^2 in fp64 (the cancellation), everything
+// after that in fp32 (invstd = 1 / sqrt(var + eps) correctly rounded in fp32; pq_bn_fwd_finalize rounds the fp64 value: the two
+// agree to an ulp, and every consumer of a layer sees the values the writer stored or derives exactly the same ones).
 // writer: also store the vectors and update the running statistics (exactly one thread of the grid per channel does that).
 struct BnCoef { float scale, shift, mean, inv; };
-__device__ __forceinline__ BnCoef bn_stat_coef(const pq_bn_stat& st, int c, bool writer) {
-    long long lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
-    for (int s = 0; s < st.slots; ++s) {
-        const longlong2 a = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)s * 2 + 0) * st.ldp + c) * 2);
-        const longlong2 b = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)s * 2 + 1) * st.ldp + c) * 2);
-        lo1 += a.x; hi1 += a.y; lo2 += b.x; hi2 += b.y;
+struct BnSums { long long lo1, hi1, lo2, hi2; };
+__device__ __forceinline__ BnSums bn_stat_load(const pq_bn_stat& st, int c) {            // all loads of a channel, no use in between
+    if (st.slots == 1) {                                                                  // uniform
+        const longlong2 a = *reinterpret_cast<const longlong2*>(st.acc + ((size_t)0 * st.ldp + c) * 2);
+        const longlong2 b = *reinterpret_cast<const longlong2*>(st.acc + ((size_t)1 * st.ldp + c) * 2);
+        return BnSums{a.x, a.y, b.x, b.y};
     }
-    double t1 = (double)hi1 + (double)lo1 * 0x1p-50, t2 = (double)hi2 + (double)lo2 * 0x1p-50;
-    if (*st.bad) t1 = t2 = __builtin_nan("");
-    const double n = (double)st.count;
-    const double mean = t1 / n;
-    double var = t2 / n - mean * mean;
+    longlong2 a[4], b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int ss = s < st.slots ? s : 0;                                              // slots <= 4 (pq_bn_stat_slots)
+        a[s] = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)ss * 2 + 0) * st.ldp + c) * 2);
+        b[s] = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)ss * 2 + 1) * st.ldp + c) * 2);
+    }
+    BnSums r{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < st.slots) { r.lo1 += a[s].x; r.hi1 += a[s].y; r.lo2 += b[s].x; r.hi2 += b[s].y; }
+    return r;
+}
+__device__ __forceinline__ BnCoef bn_stat_finish(const pq_bn_stat& st, int c, const BnSums& u, bool bad, bool writer) {
+    double t1 = (double)u.hi1 + (double)u.lo1 * 0x1p-50, t2 = (double)u.hi2 + (double)u.lo2 * 0x1p-50;
+    if (bad) t1 = t2 = __builtin_nan("");
+    const double invn = (double)st.inv_count;
+    const double mean = t1 * invn;
+    double var = fma(-mean, mean, t2 * invn);
     if (var < 0.0) var = 0.0;
     BnCoef k;
-    k.inv = (float)(1.0 / sqrt(var + (double)st.eps));
+    k.inv = 1.0f / sqrtf((float)var + st.eps);
     k.mean = (float)mean;
     k.scale = st.gamma[c] * k.inv;
     k.shift = st.beta[c] - k.mean * k.scale;
     if (writer) {
         st.mean[c] = k.mean; st.invstd[c] = k.inv; st.scale[c] = k.scale; st.shift[c] = k.shift;
         if (st.running_mean) {
+            const double n = (double)st.count;
             const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
             st.running_mean[c] = (1.f - st.momentum) * st.running_mean[c] + st.momentum * k.mean;
             st.running_var[c] = (1.f - st.momentum) * st.running_var[c] + st.momentum * (float)unb;
@@ -87,6 +106,26 @@ __device__ __forceinline__ BnCoef bn_stat_coef(const pq_bn_stat& st, int c, bool
         if (c == 0 && st.num_batches_tracked) *st.num_batches_tracked += 1;
     }
     return k;
+}
+// U channels c0, c0 + stride, ... of one thread with ALL their loads in flight before the first use (one memory round trip in the
+// consumer's prologue instead of U); out(c, coef) receives the results
+template <int U, class F>
+__device__ __forceinline__ void bn_stat_coefs(const pq_bn_stat& st, int c0, int stride, int C, bool writer, F out) {
+    BnSums u[U];
+    float g[U], b[U];
+    const unsigned bad = *st.bad;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int c = min(c0 + i * stride, C - 1);
+        u[i] = bn_stat_load(st, c);
+        g[i] = st.gamma[c]; b[i] = st.beta[c];
+    }
+    (void)g; (void)b;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int c = c0 + i * stride;
+        if (c < C) out(c, bn_stat_finish(st, c, u[i], bad != 0, writer));
+    }
 }
 
 // ---- operand loaders -----------------------------------------------------------------------------------------
@@ -101,25 +140,14 @@ struct SrcCoef4 {
 __device__ __forceinline__ float fq_act(float v, float qs, float qinv, float qzp) {
     return (fminf(fmaxf(rintf(v * qinv) + qzp, 0.f), 255.f) - qzp) * qs;
 }
-// stat_writer: with s.stat (statistics handed over by the producer, pq_bn_stat) this thread is the one of the whole grid that
-// stores the BatchNorm vectors of these 4 channels (callers pass "first row block of the grid && first lane of the channel quad").
-__device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C, bool stat_writer = false) {
+__device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C) {
     SrcCoef4 k;
     k.act = act_param(s.act);
-    k.affine = s.scale != nullptr || s.stat.acc != nullptr;
+    k.affine = s.scale != nullptr;
     k.q = s.qstate != nullptr;
     k.qs = k.q ? s.qstate[2] : 1.f;
     k.qinv = k.q ? 1.f / k.qs : 1.f;
     k.qzp = k.q ? s.qstate[3] : 0.f;
-    if (s.stat.acc != nullptr) {            // uniform
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = c0 + j;
-            k.a[j] = 1.f; k.b[j] = 0.f;
-            if (c < C) { const BnCoef bc = bn_stat_coef(s.stat, c, stat_writer); k.a[j] = bc.scale; k.b[j] = bc.shift; }
-        }
-        return k;
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int c = c0 + j;
@@ -127,6 +155,59 @@ __device__ __forceinline__ SrcCoef4 src_coef4(const pq_src& s, int c0, int C, bo
         k.a[j] = ok ? s.scale[c] : 1.f;
         k.b[j] = ok ? s.shift[c] : 0.f;
     }
+    return k;
+}
+// The same for an operand whose BatchNorm statistics were handed over by the producer (s.stat, pq_bn_stat): the workgroup's
+// LEADER lane of a channel quad derives the 4 coefficient pairs from the accumulators and shares them through `sh8` (8 floats
+// of LDS per quad); every thread of the workgroup must call this (it contains a barrier).  writer: this leader is the one of
+// the whole GRID that stores the vectors of its quad.  Without s.stat it is src_coef4.
+__device__ __forceinline__ SrcCoef4 src_coef4_shared(const pq_src& s, int c0, int C, bool leader, bool writer, float* sh8) {
+    if (s.stat.acc == nullptr) return src_coef4(s, c0, C);          // uniform
+    if (leader) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sh8[j] = 1.f; sh8[4 + j] = 0.f; }
+        bn_stat_coefs<4>(s.stat, c0, 1, C, writer, [&](int c, const BnCoef& bc) { sh8[c - c0] = bc.scale; sh8[4 + c - c0] = bc.shift; });
+    }
+    __syncthreads();
+    SrcCoef4 k;
+    k.act = act_param(s.act);
+    k.affine = true;
+    k.q = false; k.qs = 1.f; k.qinv = 1.f; k.qzp = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k.a[j] = sh8[j]; k.b[j] = sh8[4 + j]; }
+    return k;
+}
+// The same for a 256-thread workgroup that owns a chunk of up to 32 channels starting at chunk0 (8 quads: the LDS-tiled depthwise
+// kernels): thread (channel t % 32, part t / 32) issues ONE 16-byte load -- part = (slot, statistic) -- so the whole chunk costs
+// one memory round trip and no extra registers; 32 threads then finish their channel.  lds: >= 2048 + 64 floats.  quad: this
+// thread's quad inside the chunk; writer: this workgroup stores the vectors.  Every thread must call it (two barriers).
+__device__ __forceinline__ SrcCoef4 src_coef4_chunk32(const pq_src& s, int chunk0, int quad, int C, bool writer, float* lds) {
+    const pq_bn_stat& st = s.stat;                                         // callers check st.acc != NULL
+    const int t = threadIdx.x, ch = t & 31, part = t >> 5;                 // part: slot = part >> 1, statistic = part & 1
+    longlong2* stage = reinterpret_cast<longlong2*>(lds);                  // [8][32]
+    float* coef = lds + 2048;                                              // [2][32]
+    const int c = min(chunk0 + ch, C - 1);
+    if ((part >> 1) < st.slots)
+        stage[part * 32 + ch] = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)(part >> 1) * 2 + (part & 1)) * st.ldp + c) * 2);
+    const unsigned bad = *st.bad;
+    __syncthreads();
+    if (t < 32) {
+        BnSums u{0, 0, 0, 0};
+        for (int sl = 0; sl < st.slots; ++sl) {
+            const longlong2 a = stage[(2 * sl) * 32 + ch], b = stage[(2 * sl + 1) * 32 + ch];
+            u.lo1 += a.x; u.hi1 += a.y; u.lo2 += b.x; u.hi2 += b.y;
+        }
+        float sc = 1.f, sh = 0.f;
+        if (chunk0 + ch < C) { const BnCoef bc = bn_stat_finish(st, chunk0 + ch, u, bad != 0, writer); sc = bc.scale; sh = bc.shift; }
+        coef[ch] = sc; coef[32 + ch] = sh;
+    }
+    __syncthreads();
+    SrcCoef4 k;
+    k.act = act_param(s.act);
+    k.affine = true;
+    k.q = false; k.qs = 1.f; k.qinv = 1.f; k.qzp = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k.a[j] = coef[4 * quad + j]; k.b[j] = coef[32 + 4 * quad + j]; }
     return k;
 }
 __device__ __forceinline__ float4 src_apply4(float4 v, const SrcCoef4& k) {

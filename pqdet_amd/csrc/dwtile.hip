@@ -43,7 +43,7 @@ template <int S>
 __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
     using T = DwTile<S>;
     __shared__ float4 tile[T::ITH * T::ITW * PQP];
-    __shared__ float red[32 * 8 * 8];
+    __shared__ __attribute__((aligned(16))) float red[32 * 8 * 8 + 64];
     const int t = threadIdx.x;
     const int q = t & 7, pl = t >> 3;                       // quad, pixel lane
     int tIdx, bcy;
@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
     const int c0 = (cq0 + q) * 4;
     const bool cok = cq0 + q < p.C4;
     const int cc = cok ? c0 : 0;                            // clamped channel offset for address generation
-    // (with p.in.stat: derived from the producer's accumulators; tile 0's first pixel lane stores the vectors of its quad)
-    const SrcCoef4 xk = src_coef4(p.in, cc, p.C, tIdx == 0 && pl == 0 && cok);
+    // (with p.in.stat: the workgroup derives its 32 channels' coefficients from the producer's accumulators -- one 16-byte load
+    // per thread -- and tile 0 also stores the vectors for every later consumer)
+    const SrcCoef4 xk = p.in.stat.acc ? src_coef4_chunk32(p.in, cq0 * 4, q, p.C, tIdx == 0, red) : src_coef4(p.in, cc, p.C);
 
     // ---- stage the input tile (transform once, zero outside the image)
     constexpr int NPIX = T::ITH * T::ITW;

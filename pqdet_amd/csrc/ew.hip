@@ -262,11 +262,14 @@ __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
     int bx, by;
     xcd_block(bx, by);
     const int c4 = by * blockDim.x + threadIdx.x, c0 = c4 * 4;
-    if (c4 >= p.C4) return;
-    // (with a.a.stat / a.b.stat: derived from the producer's accumulators; the first row block's first row lane stores the vectors)
-    const bool wr = bx == 0 && threadIdx.y == 0;
-    const SrcCoef4 ka = src_coef4(a.a, c0, a.C, wr);
-    const SrcCoef4 kb = src_coef4(a.b, c0, a.C, wr);
+    // (with a.a.stat / a.b.stat: row lane 0 derives its quad's coefficients from the producer's accumulators and shares them
+    // through LDS; in the first row block it also stores the vectors for every later consumer)
+    __shared__ float cshare[2][64][8];
+    const bool cok = c4 < p.C4;
+    const bool lead = cok && threadIdx.y == 0;
+    const SrcCoef4 ka = src_coef4_shared(a.a, cok ? c0 : 0, a.C, lead, bx == 0, cshare[0][threadIdx.x]);
+    const SrcCoef4 kb = src_coef4_shared(a.b, cok ? c0 : 0, a.C, lead, bx == 0, cshare[1][threadIdx.x]);
+    if (!cok) return;
     const bool two = a.b.x != nullptr;
     const int rows = a.B * a.H * a.W;
     const int SH = a.H / a.up, SW = a.W / a.up;

@@ -204,12 +204,11 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
         // BatchNorm coefficients of the operand from the producer's accumulators, while the first tiles are in flight; logical
         // workgroup (0, 0) also stores the vectors / running statistics for every later consumer (pq_bn_stat)
         const bool writer = bmy == 0 && bnx == 0;
-        for (int k = t; k < Kp; k += 256) {
-            float sc = 0.f, sh = 0.f;
-            if (k < K) { const BnCoef bc = bn_stat_coef(p.stat, k, writer); sc = bc.scale; sh = bc.shift; }
-            ctab[k] = sc;
-            ctab[Kp + k] = sh;
-        }
+        for (int k = K + t; k < Kp; k += 256) { ctab[k] = 0.f; ctab[Kp + k] = 0.f; }
+        auto put = [&](int c, const BnCoef& bc) { ctab[c] = bc.scale; ctab[Kp + c] = bc.shift; };
+        // all of a thread's accumulator loads in flight at once: one memory round trip for K <= 1280 (one slot) / 512 (four)
+        if (p.stat.slots == 1) bn_stat_coefs<5>(p.stat, t, 256, K, writer, put);
+        else for (int k0 = t; k0 < K; k0 += 512) bn_stat_coefs<2>(p.stat, k0, 256, K, writer, put);
         __syncthreads();
     }
     for (int kt = 0; kt < nk; ++kt) {
@@ -559,10 +558,15 @@ static int g2_launch_nt(const G2P& p, hipStream_t st, pq_gemm_plan* plan) {
     constexpr int NA = AMODE == 2 ? 2 : 1;
     constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);
     constexpr int STAGE = NA * BM * 32 + BN * 32 + 4 * CW;
-    constexpr size_t ring = (size_t)S * STAGE * 4 + (AMODE == 3 ? (size_t)2 * G2_STAT_KMAX * 4 : 0), epi = (size_t)(4 * 32 * 36 + 4 * BN) * 4;
-    constexpr size_t bytes = ring > epi ? ring : epi;
-    static bool ok = g2_raise_lds((const void*)gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>, bytes);
+    constexpr size_t ring0 = (size_t)S * STAGE * 4, epi = (size_t)(4 * 32 * 36 + 4 * BN) * 4;
+    constexpr size_t ring_max = ring0 + (AMODE == 3 ? (size_t)2 * G2_STAT_KMAX * 4 : 0);
+    constexpr size_t bytes_max = ring_max > epi ? ring_max : epi;
+    static bool ok = g2_raise_lds((const void*)gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>, bytes_max);
     if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
+    // AMODE 3: the coefficient table behind the ring is sized by THIS contraction (a fixed 10 KB pushed the 128 x 64 x 3-stage ring
+    // over 80 KB, i.e. down to one workgroup per CU: +13 us on the K = 512 layers)
+    const size_t ring = ring0 + (AMODE == 3 ? (size_t)2 * ((p.K + 31) / 32 * 32) * 4 : 0);
+    const size_t bytes = ring > epi ? ring : epi;
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
     hipLaunchKernelGGL((gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>), grid, dim3(256), bytes, st, p);
     return PQ_OK;

@@ -693,7 +693,7 @@ class Plan:
         if self._stat_fill_idx is None:
             return
         l = lib()
-        maxblk = int(os.environ.get('PQ_BN_ATOMIC_MAXBLK', '1024'))
+        maxblk = int(os.environ.get('PQ_BN_ATOMIC_MAXBLK', '640'))
         picks, total = [], 0
         for k in range(1, len(self.fwd) - 1):
             op = self.fwd[k]
@@ -732,7 +732,7 @@ class Plan:
             pa.partial, pa.stat_acc, pa.stat_bad, pa.stat_slots = None, base + off_acc, base + off_bad, slots
             src.stat = abi.BnStat(base + off_acc, base + off_bad, f.gamma, f.beta, f.running_mean, f.running_var,
                                   f.num_batches_tracked, f.mean, f.invstd, f.scale, f.shift, slots, f.ldp, f.count, f.eps,
-                                  f.momentum)
+                                  f.momentum, 1.0 / f.count)
             nop = abi.Op()
             nop.code = abi.OP_FILL
             nop.u.fill = abi.Fill(self._stat_dummy.data_ptr(), 0.0, 0)
