@@ -324,6 +324,22 @@ __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k
     stg4(gp, sink_apply4(s, k, dz, y4, s1, s2));
 }
 
+// The same in two halves, so that a thread that emits several rows can have ALL their sink operands in flight before its first
+// store (the compiler cannot hoist the y / g loads of row k+1 above the store of row k -- they may alias -- which made every
+// emitted row its own exposed memory round trip in the streaming depthwise kernels).  `row` must be a valid (clamped) row.
+struct SinkOps { float4 y, g; };
+__device__ __forceinline__ SinkOps sink_load4(const pq_gsink& s, const SinkCoef4& k, size_t row, int c0) {
+    SinkOps o;
+    o.g = s.accumulate ? ldg4(s.g + row * (size_t)s.ldg + c0) : f4zero();
+    o.y = sink_needs_y(s, k) ? ldg4(s.y + row * (size_t)s.ldy + c0) : f4zero();
+    return o;
+}
+__device__ __forceinline__ void sink_store4(const pq_gsink& s, const SinkCoef4& k, size_t row, int c0, float4 dz, const SinkOps& o,
+                                            float4& s1, float4& s2) {
+    if (s.accumulate) dz = f4add(dz, o.g);
+    stg4(s.g + row * (size_t)s.ldg + c0, sink_apply4(s, k, dz, o.y, s1, s2));
+}
+
 // ---- XCD-aware block numbering ---------------------------------------------------------------------------------
 // MI355X has 8 XCDs with private L2s and deals workgroups to them round-robin by linear block id, so consecutive ids
 // (which normally work on neighbouring rows / tiles and therefore share halo rows or operand panels) land in eight

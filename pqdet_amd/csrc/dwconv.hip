@@ -64,6 +64,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
         float4 acc[TW];
 #pragma unroll
         for (int t = 0; t < TW; ++t) acc[t] = f4zero();
+        const size_t orow = ((size_t)b * p.OH + oy) * p.OW + ox0;
+        SinkOps so[GRAD ? TW : 1];
+        if (GRAD) {        // the sink's operands of all TW outputs travel with the first window row
+#pragma unroll
+            for (int t = 0; t < TW; ++t) so[t] = sink_load4(p.sink, sk, orow + min(t, p.OW - 1 - ox0), c0);
+        }
         // Loads are issued unconditionally at clamped coordinates (a whole window row in flight at once) and masked
         // afterwards: branching around each load would serialise them behind their own waits.
 #pragma unroll
@@ -96,12 +102,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
                 }
             }
         }
-        const size_t orow = ((size_t)b * p.OH + oy) * p.OW + ox0;
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
             if (ox0 + t >= p.OW) break;
             if (GRAD) {
-                sink_emit4(p.sink, sk, orow + t, c0, acc[t], s1, s2);
+                sink_store4(p.sink, sk, orow + t, c0, acc[t], so[t], s1, s2);
             } else {
                 stg4(p.out + (orow + t) * p.ldo + c0, acc[t]);
                 s1 = f4add(s1, acc[t]);
@@ -211,6 +216,9 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_quad_kernel(DwP p) {
             y00 = ldg4(p.dy.y + r00 * p.dy.ldy + c0); y01 = ldg4(p.dy.y + r01 * p.dy.ldy + c0);
             y10 = ldg4(p.dy.y + r10 * p.dy.ldy + c0); y11 = ldg4(p.dy.y + r11 * p.dy.ldy + c0);
         }
+        const size_t i00 = ((size_t)b * p.IH + 2 * qa) * p.IW + 2 * qb;
+        const SinkOps o00 = sink_load4(p.sink, sk, i00, c0), o01 = sink_load4(p.sink, sk, i00 + 1, c0);
+        const SinkOps o10 = sink_load4(p.sink, sk, i00 + p.IW, c0), o11 = sink_load4(p.sink, sk, i00 + p.IW + 1, c0);
         const float4 d00 = gsrc_apply4(g00, y00, gk);
         const float4 d01 = x1ok ? gsrc_apply4(g01, y01, gk) : f4zero();
         const float4 d10 = y1ok ? gsrc_apply4(g10, y10, gk) : f4zero();
@@ -219,11 +227,10 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_quad_kernel(DwP p) {
         const float4 e01 = f4fma(d01, wk[3], f4fma(d00, wk[5], f4zero()));
         const float4 e10 = f4fma(d10, wk[1], f4fma(d00, wk[7], f4zero()));
         const float4 e11 = f4fma(d11, wk[0], f4fma(d10, wk[2], f4fma(d01, wk[6], f4fma(d00, wk[8], f4zero()))));
-        const size_t i00 = ((size_t)b * p.IH + 2 * qa) * p.IW + 2 * qb;
-        sink_emit4(p.sink, sk, i00, c0, e00, s1, s2);
-        sink_emit4(p.sink, sk, i00 + 1, c0, e01, s1, s2);
-        sink_emit4(p.sink, sk, i00 + p.IW, c0, e10, s1, s2);
-        sink_emit4(p.sink, sk, i00 + p.IW + 1, c0, e11, s1, s2);
+        sink_store4(p.sink, sk, i00, c0, e00, o00, s1, s2);
+        sink_store4(p.sink, sk, i00 + 1, c0, e01, o01, s1, s2);
+        sink_store4(p.sink, sk, i00 + p.IW, c0, e10, o10, s1, s2);
+        sink_store4(p.sink, sk, i00 + p.IW + 1, c0, e11, o11, s1, s2);
     }
     float* part = (p.sink.finalize && p.sink.mean) ? p.sink.partial : nullptr;
     if (part) block_reduce_store_stats<256>(s1, s2, part, p.sink.ldp, c0, p.C, lds, bx);
@@ -280,6 +287,12 @@ __global__ __launch_bounds__(256) void dw_dgrad_s1_walk_kernel(DwP p) {
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int y = y0 + r;
+            SinkOps so[TW];                              // this row's sink operands travel with the next gradient row
+            {
+                const size_t srow = ((size_t)b * H + min(y, H - 1)) * W + x0;
+#pragma unroll
+                for (int t = 0; t < TW; ++t) so[t] = sink_load4(p.sink, sk, srow + min(t, W - 1 - x0), c0);
+            }
             load_row(y + 1, win[(r + 2) % 3]);          // r is a compile-time constant: plain register renaming
             if (y < H) {
                 float4 acc[TW];
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_s1_walk_kernel(DwP p) {
                 const size_t orow = ((size_t)b * H + y) * W + x0;
 #pragma unroll
                 for (int t = 0; t < TW; ++t)
-                    if (x0 + t < W) sink_emit4(p.sink, sk, orow + t, c0, acc[t], s1, s2);
+                    if (x0 + t < W) sink_store4(p.sink, sk, orow + t, c0, acc[t], so[t], s1, s2);
             }
         }
     }

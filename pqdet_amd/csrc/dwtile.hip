@@ -254,6 +254,13 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
             for (int j = 0; j < 4; ++j) e[j] = (cok && c0 + j < p.C) ? p.w[(size_t)(c0 + j) * 9 + k] : 0.f;
             wk[k] = make_float4(e[0], e[1], e[2], e[3]);
         }
+        const SinkCoef4 sk = sink_coef4(p.sink, cc, p.C);
+        SinkOps so[4];                                 // the sink's operands of the 4 owned pixels: in flight across the barrier
+        {
+            const size_t srow = ((size_t)b * p.IH + min(y0 + row, p.IH - 1)) * p.IW;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) so[u] = sink_load4(p.sink, sk, srow + min(x0 + col0 + u, p.IW - 1), cc);
+        }
         __syncthreads();
         float4 dx[4];
 #pragma unroll
@@ -275,12 +282,11 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
                     if (kx2 >= 0 && kx2 < 3) dx[u] = f4fma(dr[j], wk[(2 - ky) * 3 + kx2], dx[u]);
                 }
         }
-        const SinkCoef4 sk = sink_coef4(p.sink, cc, p.C);
         const int y = y0 + row;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int x = x0 + col0 + u;
-            if (cok && y < p.IH && x < p.IW) sink_emit4(p.sink, sk, ((size_t)b * p.IH + y) * p.IW + x, c0, dx[u], s1, s2);
+            if (cok && y < p.IH && x < p.IW) sink_store4(p.sink, sk, ((size_t)b * p.IH + y) * p.IW + x, c0, dx[u], so[u], s1, s2);
         }
     }
     if (PART == 1) {      // input gradient only: statistics rows of the sink, then done
