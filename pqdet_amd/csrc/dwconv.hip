@@ -70,35 +70,46 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwP p) {
 #pragma unroll
             for (int t = 0; t < TW; ++t) so[t] = sink_load4(p.sink, sk, orow + min(t, p.OW - 1 - ox0), c0);
         }
-        // Loads are issued unconditionally at clamped coordinates (a whole window row in flight at once) and masked
-        // afterwards: branching around each load would serialise them behind their own waits.
+        // Loads are issued unconditionally at clamped coordinates and masked afterwards (branching around each load would serialise
+        // them behind their own waits).  Forward: ALL THREE window rows are requested before the first one is used (18 float4 in
+        // flight per thread, one exposed round trip per item).  Gradient operand (two tensors per element): one row at a time --
+        // 36 float4 in flight cost more in occupancy than the two extra round trips (measured: 1.03 -> 1.05 ms per step).
+        constexpr int RB = GRAD ? 1 : 3;                 // window rows per load batch
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * S - 1 + ky;
-            const bool yok = iy >= 0 && iy < p.IH;
-            const int iyc = min(max(iy, 0), p.IH - 1);
-            const size_t rowbase = ((size_t)b * p.IH + iyc) * p.IW;
-            float4 ra[NCOL], rb[NCOL];
+        for (int kb = 0; kb < 3; kb += RB) {
+            float4 ra[RB][NCOL], rb[RB][NCOL];
+            bool yok[RB];
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                const int ixc = min(max(ox0 * S - 1 + j, 0), p.IW - 1);
-                if (GRAD) {
-                    ra[j] = ldg4(p.dy.g + (rowbase + ixc) * p.dy.ldg + c0);
-                    rb[j] = gk.two ? ldg4(p.dy.y + (rowbase + ixc) * p.dy.ldy + c0) : f4zero();
-                } else {
-                    ra[j] = ldg4(p.in.x + (rowbase + ixc) * p.in.ld + c0);
+            for (int kk = 0; kk < RB; ++kk) {
+                const int iy = oy * S - 1 + kb + kk;
+                yok[kk] = iy >= 0 && iy < p.IH;
+                const int iyc = min(max(iy, 0), p.IH - 1);
+                const size_t rowbase = ((size_t)b * p.IH + iyc) * p.IW;
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) {
+                    const int ixc = min(max(ox0 * S - 1 + j, 0), p.IW - 1);
+                    if (GRAD) {
+                        ra[kk][j] = ldg4(p.dy.g + (rowbase + ixc) * p.dy.ldg + c0);
+                        rb[kk][j] = gk.two ? ldg4(p.dy.y + (rowbase + ixc) * p.dy.ldy + c0) : f4zero();
+                    } else {
+                        ra[kk][j] = ldg4(p.in.x + (rowbase + ixc) * p.in.ld + c0);
+                    }
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                const int ix = ox0 * S - 1 + j;
-                const bool ok = yok && ix >= 0 && ix < p.IW;
-                float4 v = GRAD ? gsrc_apply4(ra[j], rb[j], gk) : src_apply4(ra[j], xk);
-                v = ok ? v : f4zero();
+            for (int kk = 0; kk < RB; ++kk) {
+                const int ky = kb + kk;
 #pragma unroll
-                for (int t = 0; t < TW; ++t) {
-                    const int kx = j - t * S;
-                    if (kx >= 0 && kx < 3) acc[t] = f4fma(v, wk[ky * 3 + kx], acc[t]);
+                for (int j = 0; j < NCOL; ++j) {
+                    const int ix = ox0 * S - 1 + j;
+                    const bool ok = yok[kk] && ix >= 0 && ix < p.IW;
+                    float4 v = GRAD ? gsrc_apply4(ra[kk][j], rb[kk][j], gk) : src_apply4(ra[kk][j], xk);
+                    v = ok ? v : f4zero();
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) {
+                        const int kx = j - t * S;
+                        if (kx >= 0 && kx < 3) acc[t] = f4fma(v, wk[ky * 3 + kx], acc[t]);
+                    }
                 }
             }
         }

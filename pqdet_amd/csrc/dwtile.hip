@@ -59,26 +59,27 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwTP p) {
     // per thread -- and tile 0 also stores the vectors for every later consumer)
     const SrcCoef4 xk = p.in.stat.acc ? src_coef4_chunk32(p.in, cq0 * 4, q, p.C, tIdx == 0, red) : src_coef4(p.in, cc, p.C);
 
-    // ---- stage the input tile (transform once, zero outside the image)
+    // ---- stage the input tile (transform once, zero outside the image); every load of the lane is issued before the first LDS
+    // write: one exposed memory round trip for the whole tile
     constexpr int NPIX = T::ITH * T::ITW;
-    for (int e0 = 0; e0 < NPIX; e0 += 32 * 4) {
-        float4 r[4];
-        int pix[4];
+    constexpr int NITS = (NPIX + 31) / 32;
+    {
+        float4 r[NITS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            pix[u] = e0 + pl + 32 * u;
-            const int py = min(pix[u], NPIX - 1) / T::ITW, px = min(pix[u], NPIX - 1) % T::ITW;
+        for (int u = 0; u < NITS; ++u) {
+            const int pix = min(pl + 32 * u, NPIX - 1);
+            const int py = pix / T::ITW, px = pix % T::ITW;
             const int iy = min(max(iy0 + py, 0), p.IH - 1), ix = min(max(ix0 + px, 0), p.IW - 1);
             r[u] = ldg4(p.in.x + (((size_t)b * p.IH + iy) * p.IW + ix) * p.in.ld + cc);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (pix[u] < NPIX) {
-                const int py = pix[u] / T::ITW, px = pix[u] % T::ITW;
+        for (int u = 0; u < NITS; ++u) {
+            const int pix = pl + 32 * u;
+            if (pix < NPIX) {
+                const int py = pix / T::ITW, px = pix % T::ITW;
                 const int iy = iy0 + py, ix = ix0 + px;
                 const bool ok = cok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                float4 v = src_apply4(r[u], xk);
-                tile[pix[u] * PQP + q] = ok ? v : f4zero();
+                tile[pix * PQP + q] = ok ? src_apply4(r[u], xk) : f4zero();
             }
         }
     }
@@ -223,26 +224,26 @@ __global__ __launch_bounds__(256, 3) void dwt_bwd_s1_kernel(DwTP p) {
         }
     } else {   // ---------------- phase 1
         const GsrcCoef4 gk = gsrc_coef4(p.dy, cc, p.C);
-        for (int e0 = 0; e0 < NPX; e0 += 32 * 2) {
-            float4 rg[2], ry[2];
-            int pix[2];
+        {   // every (g, y) load of the lane before the first LDS write
+            constexpr int NITS = (NPX + 31) / 32;
+            float4 rg[NITS], ry[NITS];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                pix[u] = e0 + pl + 32 * u;
-                const int py = min(pix[u], NPX - 1) / PW, px = min(pix[u], NPX - 1) % PW;
+            for (int u = 0; u < NITS; ++u) {
+                const int pix = min(pl + 32 * u, NPX - 1);
+                const int py = pix / PW, px = pix % PW;
                 const int oy = min(max(y0 - 1 + py, 0), p.OH - 1), ox = min(max(x0 - 1 + px, 0), p.OW - 1);
                 const size_t r = ((size_t)b * p.OH + oy) * p.OW + ox;
                 rg[u] = ldg4(p.dy.g + r * p.dy.ldg + cc);
                 ry[u] = gk.two ? ldg4(p.dy.y + r * p.dy.ldy + cc) : f4zero();
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (pix[u] < NPX) {
-                    const int py = pix[u] / PW, px = pix[u] % PW;
+            for (int u = 0; u < NITS; ++u) {
+                const int pix = pl + 32 * u;
+                if (pix < NPX) {
+                    const int py = pix / PW, px = pix % PW;
                     const int oy = y0 - 1 + py, ox = x0 - 1 + px;
                     const bool ok = cok && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW;
-                    const float4 v = gsrc_apply4(rg[u], ry[u], gk);
-                    tile[pix[u] * PQP + q] = ok ? v : f4zero();
+                    tile[pix * PQP + q] = ok ? gsrc_apply4(rg[u], ry[u], gk) : f4zero();
                 }
             }
         }

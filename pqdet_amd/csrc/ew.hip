@@ -273,23 +273,40 @@ __global__ __launch_bounds__(256) void copy_fwd_kernel(CopyP p) {
     const bool two = a.b.x != nullptr;
     const int rows = a.B * a.H * a.W;
     const int SH = a.H / a.up, SW = a.W / a.up;
-    for (int r = bx * blockDim.y + threadIdx.y; r < rows; r += gridDim.x * blockDim.y) {
-        size_t sr = (size_t)r;
-        if (a.up > 1) {
-            const int x = (int)(r % a.W);
-            const int t2 = r / a.W;
-            const int y = (int)(t2 % a.H);
-            const int b = t2 / a.H;
-            sr = ((size_t)b * SH + y / a.up) * SW + x / a.up;
+    // four rows per step, all their loads before the first store (the compiler may not move a load above a store that could
+    // alias it, so a one-row loop exposes a full memory round trip per row)
+    constexpr int U = 4;
+    const int stride = gridDim.x * blockDim.y;
+    for (int r0 = bx * blockDim.y + threadIdx.y; r0 < rows; r0 += U * stride) {
+        float4 va[U], vb[U], vz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = min(r0 + u * stride, rows - 1);
+            size_t sr = (size_t)r;
+            if (a.up > 1) {
+                const int x = (int)(r % a.W);
+                const int t2 = r / a.W;
+                const int y = (int)(t2 % a.H);
+                const int b = t2 / a.H;
+                sr = ((size_t)b * SH + y / a.up) * SW + x / a.up;
+            }
+            va[u] = ldg4(a.a.x + sr * a.a.ld + c0);
+            vb[u] = two ? ldg4(a.b.x + (size_t)r * a.b.ld + c0) : f4zero();
+            vz[u] = a.gate ? ldg4(a.gate + (size_t)(r / (a.H * a.W)) * a.ldgate + c0) : f4zero();
         }
-        float4 v = src_apply4(ldg4(a.a.x + sr * a.a.ld + c0), ka);
-        if (two) v = f4add(v, src_apply4(ldg4(a.b.x + (size_t)r * a.b.ld + c0), kb));
-        if (a.gate) {                                   // scale_channels: multiply by the per-image channel gate sigmoid(z)
-            const float4 z = ldg4(a.gate + (size_t)(r / (a.H * a.W)) * a.ldgate + c0);
-            v = make_float4(v.x * sigmoidf_(z.x), v.y * sigmoidf_(z.y), v.z * sigmoidf_(z.z), v.w * sigmoidf_(z.w));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * stride;
+            if (r >= rows) break;
+            float4 v = src_apply4(va[u], ka);
+            if (two) v = f4add(v, src_apply4(vb[u], kb));
+            if (a.gate) {                                   // scale_channels: multiply by the per-image channel gate sigmoid(z)
+                const float4 z = vz[u];
+                v = make_float4(v.x * sigmoidf_(z.x), v.y * sigmoidf_(z.y), v.z * sigmoidf_(z.z), v.w * sigmoidf_(z.w));
+            }
+            float* dst = a.out + (size_t)r * a.ldo + a.coff + c0;
+            if (p.unal) stg4_masked(dst, v, c0, a.C); else stg4(dst, v);
         }
-        float* dst = a.out + (size_t)r * a.ldo + a.coff + c0;
-        if (p.unal) stg4_masked(dst, v, c0, a.C); else stg4(dst, v);
     }
 }
 
@@ -306,7 +323,29 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     const int rows = a.B * a.H * a.W;
     const int OH = a.H * a.up, OW = a.W * a.up;
     float4 s1 = f4zero(), s2 = f4zero();
-    for (int r = bx * blockDim.y + threadIdx.y; r < rows && cok; r += gridDim.x * blockDim.y) {
+    const int stride = gridDim.x * blockDim.y;
+    if (!a.bcast && a.up == 1 && !a.gate && !p.unal) {
+        // the common case (shortcut / route / strided-projection finalize): four rows per step, the upstream gradient AND the
+        // sink's operands of all four in flight before the first store
+        constexpr int U = 4;
+        for (int r0 = bx * blockDim.y + threadIdx.y; r0 < rows && cok; r0 += U * stride) {
+            float4 dz[U];
+            SinkOps so[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t r = (size_t)min(r0 + u * stride, rows - 1);
+                dz[u] = ldg4(a.gout + r * a.ldgo + a.coff + c0);
+                so[u] = sink_load4(a.dx, sk, r, c0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * stride;
+                if (r >= rows) break;
+                sink_store4(a.dx, sk, (size_t)r, c0, dz[u], so[u], s1, s2);
+            }
+        }
+    } else
+    for (int r = bx * blockDim.y + threadIdx.y; r < rows && cok; r += stride) {
         float4 dz = f4zero();
         if (a.bcast) {                                  // global average pool: every pixel of image b receives gout[b] * mul
             const float* gp = a.gout + (size_t)(r / (a.H * a.W)) * a.ldgo + a.coff + c0;
