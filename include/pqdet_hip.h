@@ -480,6 +480,9 @@ typedef struct pq_yolo_loss_args {
     float* totals;
     int32_t head_slot, n_heads;
     const float* gup[5];
+    int32_t phase;       /* forward: 0 both launches; 1 the per-cell kernel only (block partials); 2 the finalize only (partials ->
+                            losses row, totals) -- lets a caller put a stream join between the two (the finalize with totals reads
+                            the other heads' rows) */
 } pq_yolo_loss_args;
 int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream);
 int pq_yolo_loss_bwd(const pq_yolo_loss_args* a, void* stream);

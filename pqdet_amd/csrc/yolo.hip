@@ -490,8 +490,11 @@ extern "C" int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream) {
     PQ_CHECK_ARG(a->totals == nullptr || (a->n_heads > 0 && a->head_slot >= 0 && a->head_slot < a->n_heads), "totals: bad head slot");
     const int nblk = pq_yolo_loss_blocks(a->H, a->W, a->A);
     hipStream_t st = (hipStream_t)stream;
-    if (!loss_launch_staged<false>(a, nblk, st)) hipLaunchKernelGGL((yolo_loss_kernel<false>), dim3(nblk, a->B), dim3(256), 0, st, *a);
-    PQ_CHECK_LAUNCH();
+    if (a->phase != 2) {
+        if (!loss_launch_staged<false>(a, nblk, st)) hipLaunchKernelGGL((yolo_loss_kernel<false>), dim3(nblk, a->B), dim3(256), 0, st, *a);
+        PQ_CHECK_LAUNCH();
+    }
+    if (a->phase == 1) return PQ_OK;
     hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)a->partial, a->B, nblk, a->losses, a->nan_flag,
                        a->totals, a->head_slot, a->n_heads);
     PQ_CHECK_LAUNCH();

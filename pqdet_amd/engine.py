@@ -629,10 +629,18 @@ class Plan:
                                   B, a.H, a.W, A, opt['classes'], 1, opt['stride'], abi.BOX_KIND[opt['bbox_loss']], 1,
                                   float(opt['ignore_thresh']), float(opt['l1_loss_gain']))
                 la.head_slot, la.n_heads = slot, nh
-                if slot == nh - 1:               # the last head's finalize also sums the table: what DetectionModel.forward returns
-                    la.totals = self.loss_total.data_ptr()
-                idx = self._op(self.fwd, abi.OP_LOSS_FWD, la)
-                la.totals = None
+                if slot == nh - 1:
+                    # the last head: its per-cell kernel only needs its own head conv; its finalize also sums the table (what
+                    # DetectionModel.forward returns) and therefore waits for the other heads' loss ops: two ops, so that a
+                    # stream join can sit between them (two-stream forward below)
+                    la.phase = 1
+                    idx = self._op(self.fwd, abi.OP_LOSS_FWD, la)
+                    la.phase, la.totals = 2, self.loss_total.data_ptr()
+                    self._last_loss_fin = self._op(self.fwd, abi.OP_LOSS_FWD, la)
+                    la.phase, la.totals = 0, None
+                    self.loss_ops_f.append((self._last_loss_fin, slot, opt['stride']))
+                else:
+                    idx = self._op(self.fwd, abi.OP_LOSS_FWD, la)
                 self.loss_ops_f.append((idx, slot, opt['stride']))
                 self._head_loss_args = getattr(self, '_head_loss_args', []) + [(la, slot, opt['stride'], a)]
             # Two-stream forward: the detection-head branches of all but the last level (the layers that only feed their yolo layer:
@@ -651,11 +659,13 @@ class Plan:
                         side_layers.add(j)
                         j -= 1
                 self.fwd_layer += [-1] * (len(self.fwd) - len(self.fwd_layer))
-                last_loss = self.loss_ops_f[-1][0]
+                last_kernel, last_fin = self._last_loss_fin - 1, self._last_loss_fin
                 for k, layer in enumerate(self.fwd_layer):
-                    if k == last_loss:
-                        # reads the rows the other heads' loss ops wrote on the side stream; its own input comes from the main
-                        # stream, so it runs there (no fork latency at the end of the forward) behind a join
+                    if k == last_kernel:
+                        pass         # the last head's per-cell kernel: main stream, right behind its head conv (no fork latency)
+                    elif k == last_fin:
+                        # ... its finalize reads the rows the other heads' loss ops wrote on the side stream: behind a join, which
+                        # by then has had the whole per-cell kernel to complete
                         self.fwd[k].flags = abi.OPF_JOIN
                     elif layer in side_layers or self.fwd[k].code == abi.OP_LOSS_FWD:
                         self.fwd[k].flags = abi.OPF_SIDE

@@ -4,20 +4,23 @@
 # usage (from the repo root on the GPU box): bash scripts/profile_round.sh
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${TAG:-r3}
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r2 -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+python3 $ROOT/scripts/trace_timeline.py $(find $OUT/stats -name "$TAG*kernel_trace.csv" | head -1) > $OUT/${TAG}_step_timeline.txt 2>&1 || true
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r2 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/fetch.log
+if [ -n "$STATS_ONLY" ]; then cp $(find $OUT/stats -name "$TAG*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv; rm -rf $OUT/stats; exit 0; fi
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/fetch.log
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r2 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/write.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/write.log
 echo "write pass done"
 cd $ROOT
-S=$(dirname $(find $OUT/stats -name 'r2*kernel_stats.csv' | head -1))
-F=$(dirname $(find $OUT/fetch -name 'r2*counter_collection.csv' | head -1))
-W=$(dirname $(find $OUT/write -name 'r2*counter_collection.csv' | head -1))
-python3 scripts/pmc_summary.py $S $F $W r2 > $OUT/r2_pmc_summary.csv
-cp $(find $OUT/stats -name 'r2*kernel_stats.csv' | head -1) $OUT/r2_kernel_stats.csv
+S=$(dirname $(find $OUT/stats -name "$TAG*kernel_stats.csv" | head -1))
+F=$(dirname $(find $OUT/fetch -name "$TAG*counter_collection.csv" | head -1))
+W=$(dirname $(find $OUT/write -name "$TAG*counter_collection.csv" | head -1))
+python3 scripts/pmc_summary.py $S $F $W $TAG > $OUT/${TAG}_pmc_summary.csv
+cp $(find $OUT/stats -name "$TAG*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 rm -rf $OUT/fetch $OUT/write $OUT/stats
 echo "summary done"
