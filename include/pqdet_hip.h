@@ -656,6 +656,10 @@ int pq_run_ops(const pq_op* ops, int32_t n, void* stream);
  * position (they see everything launched before them); `stream` waits for the side stream at the end of the call.
  * Lets the weight-gradient GEMMs overlap the latency-bound data-gradient chain of the backward pass. */
 int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side_stream);
+/* the same without the final join: `stream` does NOT wait for `side_stream` when the call returns (PQ_OPF_JOIN ops inside still
+ * do).  For callers that replay one op array in pieces and hand each piece's results to a third stream (data-parallel gradient
+ * buckets: the communication stream waits for both streams, the compute streams never stall); the caller joins once at the end. */
+int pq_run_ops2_nojoin(const pq_op* ops, int32_t n, void* stream, void* side_stream);
 /* profiling variant: brackets every op with HIP events on `stream`, synchronises at the end and writes the elapsed
  * milliseconds of op k to ms[k] (used by bench.py for the live roofline figure; never on the timed path) */
 int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms);

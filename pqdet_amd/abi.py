@@ -335,6 +335,7 @@ SIGNATURES = {
     'pq_nms_batch_scratch_bytes': (i64, [i32, i32, i32]),
     'pq_run_ops': (C.c_int, [C.POINTER(Op), i32, C.c_void_p]),
     'pq_run_ops2': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p]),
+    'pq_run_ops2_nojoin': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p]),
     'pq_run_ops_timed': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.POINTER(C.c_float)]),
     'pq_run_ops2_timed': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     'pq_last_failed_op': (C.c_int, []),

@@ -110,7 +110,7 @@ static int side_group() {
     return g;
 }
 
-extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side_stream) {
+static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_stream, bool final_join) {
     g_failed_op = -1;
     if (!ops || n < 0) { pq_set_error("pq_run_ops2: bad arguments"); return PQ_EINVAL; }
     if (!side_stream || side_stream == stream) return pq_run_ops(ops, n, stream);
@@ -180,7 +180,14 @@ extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side
         }
         if (rc != PQ_OK) { g_failed_op = i; return rc; }
     }
+    if (!final_join) return flush();         // the caller orders whatever consumes the side stream's results itself
     return join();
+}
+extern "C" int pq_run_ops2(const pq_op* ops, int32_t n, void* stream, void* side_stream) {
+    return run_ops2_impl(ops, n, stream, side_stream, true);
+}
+extern "C" int pq_run_ops2_nojoin(const pq_op* ops, int32_t n, void* stream, void* side_stream) {
+    return run_ops2_impl(ops, n, stream, side_stream, false);
 }
 
 extern "C" int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms) {

@@ -1093,8 +1093,9 @@ class Plan:
             return
         if self.post_arr is not None:
             raise NotImplementedError('quantisation-aware training is single-GPU (as in the reference, trainer.py:148)')
-        # bucketed replay: launch the ops up to each mark (pq_run_ops2 joins the side stream at the end of every call, so
-        # the gradient range is final on the main stream), then hand the finished range to the reducer
+        # bucketed replay: launch the ops up to each mark WITHOUT joining the two compute streams (the weight gradients keep
+        # overlapping the data-gradient chain across bucket boundaries); the finished range is handed to the reducer, whose
+        # communication stream waits for BOTH compute streams at that point.  One join at the very end.
         flat = self.model._flat
         start, hi = 0, flat.grad.numel()
         marks = reducer.pick_marks(self.segments, hi)
@@ -1103,12 +1104,14 @@ class Plan:
             n = op_end - start
             if n > 0:
                 sub = C.cast(C.c_void_p(base + start * C.sizeof(abi.Op)), C.POINTER(abi.Op))
-                check(l.pq_run_ops2(sub, n, st, sd), 'backward step')
-            reducer.reduce_range(flat.grad, lo, hi)
+                check(l.pq_run_ops2_nojoin(sub, n, st, sd), 'backward step')
+            reducer.reduce_range(flat.grad, lo, hi, also_wait=side)
             start, hi = op_end, lo
         if start < len(self.bwd):
             sub = C.cast(C.c_void_p(base + start * C.sizeof(abi.Op)), C.POINTER(abi.Op))
-            check(l.pq_run_ops2(sub, len(self.bwd) - start, st, sd), 'backward step')
+            check(l.pq_run_ops2_nojoin(sub, len(self.bwd) - start, st, sd), 'backward step')
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)          # the only join of the two compute streams
         if hi > 0:
             reducer.reduce_range(flat.grad, 0, hi)
         reducer.finish()

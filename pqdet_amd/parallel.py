@@ -38,7 +38,9 @@ class GradReducer:
                 hi = lo
         return marks
 
-    def reduce_range(self, flat_grad: torch.Tensor, lo: int, hi: int):
+    def reduce_range(self, flat_grad: torch.Tensor, lo: int, hi: int, also_wait=None):
+        """also_wait: a second compute stream whose work (weight-gradient kernels) also writes this range; the communication
+        stream waits for it too -- the compute streams themselves are never made to wait for each other here."""
         if hi <= lo or self.world == 1:
             return
         chunk = flat_grad[lo:hi]
@@ -48,6 +50,8 @@ class GradReducer:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
             self.stream.wait_event(ready)
+            if also_wait is not None:
+                self.stream.wait_stream(also_wait)
             with torch.cuda.stream(self.stream):
                 if dist.get_backend(self.group) == 'nccl':          # RCCL: averaging all-reduce, asynchronous on the stream
                     dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
