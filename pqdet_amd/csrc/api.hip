@@ -64,18 +64,9 @@ static int run_one(const pq_op& op, void* stream) {
 extern "C" int pq_run_ops(const pq_op* ops, int32_t n, void* stream) {
     g_failed_op = -1;
     if (!ops || n < 0) { pq_set_error("pq_run_ops: bad arguments"); return PQ_EINVAL; }
-    // PQ_DEBUG_RECORD=1|2: measurement aid -- an event record after (1) / bound to (2) every BatchNorm-backward finalize, as
-    // the two-stream executor issues them, to price the records alone (scripts/phase_wall.py, "backward 1 stream")
-    static const char* dbg = getenv("PQ_DEBUG_RECORD");
-    static hipEvent_t dbg_ev = nullptr;
-    if (dbg && !dbg_ev && hipEventCreateWithFlags(&dbg_ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) dbg = nullptr;
     for (int i = 0; i < n; ++i) {
-        const bool rec = dbg && ops[i].code == PQ_OP_BN_BWD_FIN;
-        if (rec && dbg[0] == '2') g_stop_event = dbg_ev;
         const int rc = run_one(ops[i], stream);
         if (rc != PQ_OK) { g_failed_op = i; return rc; }
-        if (rec && dbg[0] == '1') (void)hipEventRecord(dbg_ev, (hipStream_t)stream);
-        g_stop_event = nullptr;
     }
     return PQ_OK;
 }
@@ -88,27 +79,11 @@ extern "C" int pq_run_ops(const pq_op* ops, int32_t n, void* stream) {
 // safe because nothing on the main stream overwrites what a parked op reads (gradient buffers are per tensor and never
 // reused inside a step; activations are read-only in the backward), and every call flushes and joins before it returns.
 // both streams live on one device: a device-scope release is all the fork / join events need (the default is a system-scope
-// fence at every record: 11.77 -> 11.61 ms per train step without it).  PQ_EVENT_FLAGS=0|1|2: default | release-to-device | no system fence (A/B timing)
-static unsigned event_flags() {
-    static const char* e = getenv("PQ_EVENT_FLAGS");
-    const int m = e ? atoi(e) : 2;
-    return hipEventDisableTiming | (m == 1 ? hipEventReleaseToDevice : m == 2 ? hipEventDisableSystemFence : 0u);
-}
-// PQ_BIND_EVENTS=0 goes back to a hipEventRecord after the op (A/B timing)
-static bool bind_events() {
-    static const char* e = getenv("PQ_BIND_EVENTS");
-    return !(e && e[0] == '0');
-}
-static int side_group() {
-    static int g = -1;
-    if (g < 0) {
-        const char* e = getenv("PQ_SIDE_GROUP");
-        g = e ? atoi(e) : 1;
-        if (g < 1) g = 1;
-        if (g > 64) g = 64;
-    }
-    return g;
-}
+// fence at every record: 11.77 -> 11.61 ms per train step without it); the fork event is BOUND to the dispatch of the op in front
+// of it where that op supports it (PQ_LAUNCH_BINDABLE).
+static unsigned event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
+static bool bind_events() { return true; }
+static int side_group() { return 1; }
 
 static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_stream, bool final_join) {
     g_failed_op = -1;

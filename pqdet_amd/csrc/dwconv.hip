@@ -813,16 +813,14 @@ extern "C" int pq_dw3x3_dgrad(const pq_dw3x3_dgrad_args* a, void* stream) {
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     size_t sh = (size_t)g.cx * g.py * 8 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    static const char* mode = getenv("PQ_DW_DGRAD");                  // "old": the per-pixel / per-row kernels (A/B timing)
-    const bool legacy = mode && mode[0] == 'o';
     if (a->stride == 1) {
         DwP q = p;
         q.IH = a->OH; q.IW = a->OW; q.OH = a->IH; q.OW = a->IW;   // "input" = dy plane, "output" = dx plane
         // the column-walk kernel only pays on the largest planes (256x256: 0.167 -> 0.144 ms); below that the per-row kernel
         // has more parallelism and is as fast
-        if (!legacy && (long)a->IH * a->IW >= 256L * 256L) hipLaunchKernelGGL((dw_dgrad_s1_walk_kernel<4, 4>), grid, blk, sh, st, q);
+        if ((long)a->IH * a->IW >= 256L * 256L) hipLaunchKernelGGL((dw_dgrad_s1_walk_kernel<4, 4>), grid, blk, sh, st, q);
         else hipLaunchKernelGGL((dw_fwd_kernel<1, 4, true>), grid, blk, sh, st, q);
-    } else if (!legacy && (a->IH & 1) == 0 && (a->IW & 1) == 0) {
+    } else if ((a->IH & 1) == 0 && (a->IW & 1) == 0) {
         hipLaunchKernelGGL(dw_dgrad_s2_quad_kernel, grid, blk, sh, st, p);
     } else {
         hipLaunchKernelGGL((dw_dgrad_kernel<2>), grid, blk, sh, st, p);
@@ -878,9 +876,8 @@ extern "C" int pq_stem3x3_fwd(const pq_stem3x3_fwd_args* a, void* stream) {
     p.S = a->stride; p.ldo = a->ldo; p.ldp = a->ldp; p.minmax = (a->partial && a->minmax) ? 1 : 0;
     EwGeom g = ew_geom((long)a->B * a->OH * a->OW, a->O);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
-    static const char* senv = getenv("PQ_STEM");                  // "stream": the per-pixel global-load version (A/B timing)
     const int npatch_f = 3 * (3 * a->stride + 3) * (31 * a->stride + 3);
-    if ((senv && senv[0] == 's') || npatch_f > 8 * g.cx * g.py) {
+    if (npatch_f > 8 * g.cx * g.py) {           // patch too large for the LDS-tiled kernel: per-pixel global loads
         hipLaunchKernelGGL((stem_fwd_kernel<3>), grid, blk, (size_t)g.cx * g.py * 8 * sizeof(float), (hipStream_t)stream, p);
     } else {
         const int PH = 3 * a->stride + 3, PW = 31 * a->stride + 3;
@@ -911,9 +908,8 @@ extern "C" int pq_stem3x3_wgrad(const pq_stem3x3_wgrad_args* a, void* stream) {
     stem_wgrad_blocks(a->B, a->OH, a->OW, a->O, &g);
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     hipStream_t st = (hipStream_t)stream;
-    static const char* senv = getenv("PQ_STEM");                  // "stream": the per-pixel global-load version (A/B timing)
     const int npatch_w = 3 * (3 * a->stride + 3) * (31 * a->stride + 3);
-    if ((senv && senv[0] == 's') || npatch_w > 8 * g.cx * g.py) {
+    if (npatch_w > 8 * g.cx * g.py) {
         hipLaunchKernelGGL((stem_wgrad_kernel<3>), grid, blk, (size_t)g.cx * g.py * 4 * sizeof(float), st, p);
     } else {
         const int PH = 3 * a->stride + 3, PW = 31 * a->stride + 3;

@@ -495,11 +495,10 @@ __global__ void sign_l1_kernel(float* grad, const float* w, int64_t n, float rat
 using namespace pq;
 
 static int bn_row_groups(int nblk, bool have_scratch) {
-    // One block per 16 channels walks the whole partial list up to PQ_BN_R1_MAX rows (default 4096): measured on the
-    // headline step 256 -> 11.54 ms, 1024 -> 11.39, 2048/4096/8192 -> 11.35 (the ticket + two device fences of the
-    // multi-block path cost more than 16 lanes reading 4096 rows from L2).  Longer lists split the rows.
-    static const char* e = getenv("PQ_BN_R1_MAX");
-    const int r1max = e ? atoi(e) : 4096;
+    // One block per 16 channels walks the whole partial list up to 4096 rows: measured on the headline step with a limit of
+    // 256 -> 11.54 ms, 1024 -> 11.39, 2048/4096/8192 -> 11.35 (the ticket + two device fences of the multi-block path cost more
+    // than 16 lanes reading 4096 rows from L2).  Longer lists split the rows.
+    const int r1max = 4096;
     if (!have_scratch || nblk <= r1max) return 1;
     const int r = (nblk + 127) / 128;
     return r > BNF_MAXR ? BNF_MAXR : r;

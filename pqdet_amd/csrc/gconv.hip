@@ -622,12 +622,11 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
         hipLaunchKernelGGL((gconv_kernel<1, 1>), grid, dim3(256), lds, (hipStream_t)stream, p);
     } else {
         // big stride-2 layers: persistent workgroups (one resident wave of them), at least 8 tiles each
-        static const char* penv = getenv("PQ_GC_PERSIST");            // "0": one workgroup per tile (A/B timing)
         const int G = a->C / a->gw, ntiles = a->B * p.tilesH * p.tilesW;
         int occ = (int)((160 * 1024) / lds); if (occ > 3) occ = 3; if (occ < 1) occ = 1;
         int nb = 256 * occ / G; if (nb < 1) nb = 1;
         const int per = (ntiles + nb - 1) / nb;
-        if (!(penv && penv[0] == '0') && nb < ntiles && per >= 8) {
+        if (nb < ntiles && per >= 8) {
             (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((gconv_kernel<1, 2, true>), dim3((ntiles + per - 1) / per, G), dim3(256), lds, (hipStream_t)stream, p);
         } else {
@@ -644,8 +643,7 @@ extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) 
     PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape (group width multiple of 4 and <= 32, stride 1|2, pad 1)");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_gconv3x3_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }
-    static const char* s2env = getenv("PQ_GC_DGRAD_S2");       // "zero": the zero-insertion formulation (A/B timing)
-    if (a->stride == 2 && !(s2env && s2env[0] == 'z')) {
+    if (a->stride == 2) {
         GcP q{};
         q.dy = a->dy; q.grad = 1; q.w = a->w; q.sink = a->dx; q.DH = a->OH; q.DW = a->OW;
         q.B = a->B; q.OH = a->IH; q.OW = a->IW; q.C = a->C; q.gw = a->gw; q.S = 2;

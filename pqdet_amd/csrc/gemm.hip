@@ -744,8 +744,6 @@ static TilePick pick_tile(int M, int N) {
     // measured ranking of the three big tiles on every mid / low resolution layer shape (PQ_GEMM_TILE=0..3 forces one).
     int best = 0;
     float best_cost = 3.4e38f;
-    static const char* force = getenv("PQ_GEMM_TILE");          // A/B timing only: force one of the four tile shapes
-    if (force && force[0] >= '0' && force[0] <= '3') { const int c = force[0] - '0'; return {0, c, kTiles[c].bm, kTiles[c].bn}; }
     for (int c = 0; c < 4; ++c) {
         const long gm = (M + kTiles[c].bm - 1) / kTiles[c].bm, gn = (N + kTiles[c].bn - 1) / kTiles[c].bn;
         const long slots = 256L * kTiles[c].occ;
@@ -927,8 +925,7 @@ static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, 
     big = false;
     const int b = big ? 128 : 64;
     tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
-    static const char* tgt_env = getenv("PQ_WG_TARGET");
-    const int target = tgt_env ? atoi(tgt_env) : 512;
+    const int target = 512;
     int want = (target + tiles - 1) / tiles;
     int maxs = (M + 255) / 256;
     splits = want < 1 ? 1 : (want > maxs ? maxs : want);

@@ -646,17 +646,15 @@ int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st, pq_
 struct G2WPlan { bool ok; int tiles, splits, rows; };
 static G2WPlan g2_wgrad_plan(int M, int I, int O) {
     G2WPlan pl{};
-    static const char* tn_env = getenv("PQ_G2_TN");
     // 128 x 128 tiles: shapes that would leave more than a third of a tile empty stay on the 64 x 64 gemm_tn kernel
-    pl.ok = g2_enabled() && !(tn_env && tn_env[0] == '0') && (M % 32) == 0 && (I & 3) == 0 && (O & 3) == 0 &&
+    pl.ok = g2_enabled() && (M % 32) == 0 && (I & 3) == 0 && (O & 3) == 0 &&
             ((O - 1) % 128) >= 80 && ((I - 1) % 128) >= 80;
     if (!pl.ok) return pl;
     pl.tiles = ((O + 127) / 128) * ((I + 127) / 128);
     // one workgroup per CU (144 KiB of LDS): tiles x splits <= 256 in ONE round, and every workgroup must get a contraction
     // of at least 256 rows (8 k-tiles) or the fixed costs (ring fill, row-group reduction, slab) dominate: shorter ones stay
     // on gemm_tn
-    static const char* tgt_env = getenv("PQ_G2_WG_TARGET");
-    const int target = tgt_env ? atoi(tgt_env) : 256;
+    const int target = 256;
     int splits = target / pl.tiles;
     const int maxs = M / 256;
     if (splits > maxs) splits = maxs;
@@ -679,9 +677,7 @@ static int g2_launch_tn_nw(const G2TP& p, const G2WPlan& pl, hipStream_t st, pq_
 }
 template <bool TWO, bool XA>
 static int g2_launch_tn(const G2TP& p, const G2WPlan& pl, hipStream_t st, pq_gemm_plan* plan) {
-    static const char* e = getenv("PQ_G2_TN_WAVES");             // 4 | 8 (A/B timing)
-    if (e && e[0] == '8') return g2_launch_tn_nw<TWO, XA, 8>(p, pl, st, plan);
-    return g2_launch_tn_nw<TWO, XA, 4>(p, pl, st, plan);
+    return g2_launch_tn_nw<TWO, XA, 4>(p, pl, st, plan);      // (8 waves: 1 % faster alone, slower in the step -- DESIGN 5.1)
 }
 
 // the GEMM half of pq_conv1x1_wgrad (the caller runs the slab reduction); 1 = taken, 0 = not eligible

@@ -347,16 +347,13 @@ static PwPlan pw_plan(int M, int I, int O) {
     int occ = (int)((160 * 1024) / pl.lds_bytes);
     // narrow-I flavour: 3 workgroups per CU with 2 rows in flight per thread while LDS allows it; wide O (LDS for 2 at most):
     // 6 rows in flight instead
-    static const char* deep_env = getenv("PQ_PW_DEEP");
-    pl.deep = (I + 15) / 16 <= 2 && (occ < 3 || (deep_env && deep_env[0] == '1'));
+    pl.deep = (I + 15) / 16 <= 2 && occ < 3;
     const int reg_occ = ((I + 15) / 16 <= 2 && !pl.deep) ? 3 : 2;
     if (occ > reg_occ) occ = reg_occ;
     if (occ < 1) occ = 1;
-    static const char* genv = getenv("PQ_PW_GRID");
     int grid = 256 * occ;
     const int half = pl.tiles / 2 > 256 ? pl.tiles / 2 : 256;     // at least two tiles per workgroup once the chip is covered
     if (grid > half) grid = half;
-    if (genv) grid = atoi(genv);
     if (grid > pl.tiles) grid = pl.tiles;
     if (grid < 1) grid = 1;
     pl.grid = grid;

@@ -461,8 +461,6 @@ static int loss_check(const pq_yolo_loss_args* a, bool bwd) {
 
 // staged kernels: engine layout only (see yolo_loss_staged_kernel); LDS need in bytes, 0 = not eligible
 static size_t loss_staged_lds(const pq_yolo_loss_args* a, bool bwd, int* span_cap, int* lab_cap) {
-    static const char* off = getenv("PQ_LOSS_STAGED");
-    if (off && off[0] == '0') return 0;
     if (!a->from_raw || a->in.sc != 1 || a->in.sw < (int64_t)a->A * (5 + a->C) || a->in.sh != a->in.sw * a->W) return 0;
     if (bwd && (a->gsc != 1 || a->gsw != a->in.sw || a->gsh != a->in.sh)) return 0;
     // span of 256 cells: at most ceil(256 / A) + 1 pixels

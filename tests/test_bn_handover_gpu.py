@@ -76,8 +76,9 @@ class Stat:
                                       (16384, 64, 384, 64),       # register-staged producer (K = 64), 256 row blocks: 4 slots
                                       (65536, 128, 256, 128),     # 512 row blocks of 128: 16 slots
                                       (4000, 144, 208, 75)])      # ragged rows / columns
-def test_conv1x1_to_conv1x1_handover(M, I, O, C2):
-    """conv A (stats -> accumulators) -> BatchNorm + ReLU6 -> conv B (coefficients derived in its prologue)."""
+def test_conv1x1_to_conv1x1_handover(M, I, O, C2, stats_b=False, bias_b=False, expect_b=None):
+    """conv A (stats -> accumulators) -> BatchNorm + ReLU6 -> conv B (coefficients derived in its prologue).  stats_b / bias_b:
+    conv B itself emits statistic rows / adds a bias (the epilogue variants the nets use); expect_b pins its instantiation."""
     l = abi.lib()
     g = torch.Generator().manual_seed(M + I + O)
     x = K.rnd(M, I, g=g)
@@ -95,22 +96,30 @@ def test_conv1x1_to_conv1x1_handover(M, I, O, C2):
     abi.check(l.pq_conv1x1_fwd(C.byref(a), K.stream()))
     ldo = (C2 + 3) // 4 * 4
     yb = torch.full((M, ldo), float('nan'), device=DEV)
-    b = abi.Conv1x1Fwd(abi.Src(ya.data_ptr(), None, None, O, 2), wBd.data_ptr(), None, yb.data_ptr(), None, M, O, C2, ldo, 0,
-                       1, 0, 0, 0, 0)
+    biasB = K.rnd(C2, g=g).to(DEV) if bias_b else None
+    nblkB, ldpB = l.pq_conv1x1_blocks_k(M, C2, O, 0), (C2 + 15) // 16 * 16
+    partB = torch.zeros(nblkB * 2 * ldpB, device=DEV) if stats_b else None
+    b = abi.Conv1x1Fwd(abi.Src(ya.data_ptr(), None, None, O, 2), wBd.data_ptr(), abi.ptr(biasB), yb.data_ptr(), abi.ptr(partB), M, O, C2,
+                       ldo, ldpB if stats_b else 0, 1, 0, 0, 0, 0)
     b.inp.stat = st.struct()
     assert l.pq_bn_stat_ok(abi.OP_CONV1X1_FWD, C.byref(b), 1) == 1
-    plan = K.gemm_plan('fwd', b)
+    plan = K.gemm_plan('fwd', b, expect_b)
     assert plan[0] == 2 and plan[4] == 3, plan                     # LDS-DMA ring kernel, AMODE 3
     abi.check(l.pq_conv1x1_fwd(C.byref(b), K.stream()))
     torch.cuda.synchronize()
     K.close(ya, yA, what='conv A')
     norm = st.check_against(ya.cpu())
-    want = norm.detach().clamp(0, 6) @ wB.t()
+    want = norm.detach().clamp(0, 6) @ wB.t() + (biasB.cpu() if bias_b else 0)
     K.close(yb[:, :C2], want, rt=1e-3, at=2e-4, what='conv B on the handed-over BatchNorm')
+    if stats_b:
+        s1, s2 = K.reduce_partial(partB, nblkB, ldpB, C2)
+        got = yb[:, :C2].cpu().double()
+        K.close(s1.float(), got.sum(0).float(), rt=1e-3, at=1e-2, what='conv B sum')
+        K.close(s2.float(), (got ** 2).sum(0).float(), rt=1e-3, at=1e-2, what='conv B sumsq')
     # a later consumer reads the stored vectors: same result through the ordinary path
     yb2 = torch.full((M, ldo), float('nan'), device=DEV)
-    b2 = abi.Conv1x1Fwd(abi.Src(ya.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), O, 2), wBd.data_ptr(), None, yb2.data_ptr(),
-                        None, M, O, C2, ldo, 0, 1, 0, 0, 0, 0)
+    b2 = abi.Conv1x1Fwd(abi.Src(ya.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), O, 2), wBd.data_ptr(), abi.ptr(biasB),
+                        yb2.data_ptr(), None, M, O, C2, ldo, 0, 1, 0, 0, 0, 0)
     abi.check(l.pq_conv1x1_fwd(C.byref(b2), K.stream()))
     torch.cuda.synchronize()
     assert torch.equal(yb2[:, :C2], yb[:, :C2])                    # same coefficients, same kernel arithmetic

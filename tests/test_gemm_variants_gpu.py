@@ -110,6 +110,15 @@ WGRAD = [
     (65536, 160, 128, True, False, (1, 64, 64, 1, 1, 0, 0), 86),             # 160 leaves a 128-tile 1/4 full: round-1 kernel
     (16384, 96, 576, True, True, (1, 64, 64, 1, 3, 0, 0), 29),
 ]
+# ---- forward with the operand's BatchNorm DERIVED from the producer's accumulators (AMODE 3, tests/test_bn_handover_gpu.py):
+# conv A (M, I -> O) feeds conv B (M, O -> C2): stats / bias of conv B, expected instantiation of conv B
+HANDOVER = [
+    (16384, 32, 192, 64, True, False, (2, 64, 64, 3, 3, 1, 0)),
+    (4096, 256, 160, 960, True, False, (2, 128, 64, 3, 3, 1, 0)),
+    (65536, 128, 256, 75, False, True, (2, 128, 128, 2, 3, 0, 0)),
+    (16384, 128, 256, 512, True, False, (2, 128, 128, 2, 3, 1, 0)),
+    (7200, 128, 352, 75, False, True, (2, 64, 64, 3, 3, 0, 0)),
+]
 WGRAD_BIAS = [(65536, 256, 75, False, (1, 64, 64, 1, 2, 0, 0))]                  # detection head: bias gradient in the same pass
 
 
@@ -158,6 +167,12 @@ def test_conv1x1_strided_backward_at_benchmark_shapes(case):
     K.test_conv1x1_strided_backward(*case[:5], True, expect=case[5], expect_w=case[6])
 
 
+@pytest.mark.parametrize('case', HANDOVER, ids=lambda c: '%dx%dx%dx%d' % c[:4])
+def test_conv1x1_fwd_with_handed_over_batchnorm_at_benchmark_shapes(case):
+    import test_bn_handover_gpu as H
+    H.test_conv1x1_to_conv1x1_handover(*case[:4], stats_b=case[4], bias_b=case[5], expect_b=case[6])
+
+
 def _selected(model_name, size, batch):
     """{(kind, plan key)} over every 1x1 GEMM launch of one train step of the net at (batch, size)."""
     from pqdet_amd.engine import Plan
@@ -196,6 +211,8 @@ def _covered():
         cov.add(('wgrad', tuple(c[5])))
     for c in WGRAD_BIAS:
         cov.add(('wgrad', tuple(c[4])))
+    for c in HANDOVER:
+        cov.add(('fwd', tuple(c[6])))
     for c in FWD_STRIDED:
         cov.add(('fwd', tuple(c[5])))
     for c in BWD_STRIDED:
