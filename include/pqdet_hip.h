@@ -416,6 +416,8 @@ typedef struct pq_route_bwd_args {
     int32_t ldgate;
     int32_t bcast;       /* global average pool backward: gout is [B][ldgo], dz[b,p,c] = gout[b][c] * mul */
     float mul;
+    pq_gsink dx2;        /* dx2.g != NULL: a SECOND destination of the same dz (both inputs of a shortcut add receive the output's
+                            gradient, model/parser.py:149-156): gout is read once for the two sinks.  up == 1, no gate / bcast */
 } pq_route_bwd_args;
 int pq_route_bwd(const pq_route_bwd_args* a, void* stream);
 int32_t pq_ew_blocks(int32_t rows, int32_t C);   /* row-blocks used by elementwise sinks (partial rows) */

@@ -157,7 +157,7 @@ class PoolReduce(C.Structure):
 class RouteBwd(C.Structure):
     _fields_ = [('gout', c_fp), ('dx', GSink),
                 ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('ldgo', i32), ('coff', i32), ('up', i32),
-                ('gate', c_fp), ('ldgate', i32), ('bcast', i32), ('mul', f32)]
+                ('gate', c_fp), ('ldgate', i32), ('bcast', i32), ('mul', f32), ('dx2', GSink)]
 
 
 class HeadView(C.Structure):

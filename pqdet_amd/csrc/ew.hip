@@ -324,6 +324,37 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
     const int OH = a.H * a.up, OW = a.W * a.up;
     float4 s1 = f4zero(), s2 = f4zero();
     const int stride = gridDim.x * blockDim.y;
+    if (a.dx2.g != nullptr) {
+        // shortcut add: both inputs receive the output's gradient -- one read of gout, two sinks (each with its own accumulate /
+        // activation derivative / statistics), four rows per step with every operand in flight before the first store
+        const SinkCoef4 sk2 = sink_coef4(a.dx2, c0, a.C);
+        float4 t1 = f4zero(), t2 = f4zero();
+        constexpr int U = 4;
+        for (int r0 = bx * blockDim.y + threadIdx.y; r0 < rows && cok; r0 += U * stride) {
+            float4 dz[U];
+            SinkOps so[U], so2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t r = (size_t)min(r0 + u * stride, rows - 1);
+                dz[u] = ldg4(a.gout + r * a.ldgo + a.coff + c0);
+                so[u] = sink_load4(a.dx, sk, r, c0);
+                so2[u] = sink_load4(a.dx2, sk2, r, c0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * stride;
+                if (r >= rows) break;
+                sink_store4(a.dx, sk, (size_t)r, c0, dz[u], so[u], s1, s2);
+                sink_store4(a.dx2, sk2, (size_t)r, c0, dz[u], so2[u], t1, t2);
+            }
+        }
+        float* part1 = (a.dx.finalize && a.dx.mean) ? a.dx.partial : nullptr;
+        float* part2 = (a.dx2.finalize && a.dx2.mean) ? a.dx2.partial : nullptr;
+        if (part1) block_reduce_store_stats<256>(s1, s2, part1, a.dx.ldp, c0, a.C, lds, bx);
+        if (part1 && part2) __syncthreads();
+        if (part2) block_reduce_store_stats<256>(t1, t2, part2, a.dx2.ldp, c0, a.C, lds, bx);
+        return;
+    }
     if (!a.bcast && a.up == 1 && !a.gate && !p.unal) {
         // the common case (shortcut / route / strided-projection finalize): four rows per step, the upstream gradient AND the
         // sink's operands of all four in flight before the first store
@@ -557,6 +588,13 @@ extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a->ldgo % 4 == 0 && a->dx.ldg % 4 == 0, "pitches must be multiples of 4");
     PQ_CHECK_ARG(!(a->gate || a->bcast) || (a->C % 4 == 0 && a->coff % 4 == 0), "gated / broadcast routing needs multiples of 4");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    if (a->dx2.g) {
+        PQ_CHECK_ARG(a->up == 1 && !a->gate && !a->bcast && (a->C & 3) == 0 && (a->coff & 3) == 0 && a->dx2.ldg % 4 == 0,
+                     "two sinks: plain routing of a multiple of 4 channels only");
+        PQ_CHECK_ARG(!(a->dx2.finalize && (a->dx2.act != PQ_ACT_LINEAR || a->dx2.mean)) || a->dx2.y, "second sink needs y to finalize");
+        PQ_CHECK_ARG(a->dx2.g != a->dx.g, "the two sinks must be different tensors");
+        if (act_is_special(a->dx2.act)) { pq_set_error("pq_route_bwd: logistic/tanh sinks are not supported yet"); return PQ_EUNSUPPORTED; }
+    }
     if (act_is_special(a->dx.act)) { pq_set_error("pq_route_bwd: logistic/tanh sinks are not supported yet"); return PQ_EUNSUPPORTED; }
     RouteP p{*a, (a->C + 3) / 4, ((a->C & 3) || (a->coff & 3)) ? 1 : 0};
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);

@@ -969,10 +969,18 @@ class Plan:
                     self._qact_bwd(out, self._inner[i], ('a', i))
                     out = self._inner[i]
                 if out.grad is not None:
-                    for srcT in (T[resolve(i - 1, i)], T[resolve(m._from, i)]):
-                        r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B, srcT.H,
-                                         srcT.W, srcT.C, out.ld, 0, 1)
+                    sa, sb = T[resolve(i - 1, i)], T[resolve(m._from, i)]
+                    if sa is not sb and sa.C % 4 == 0 and not self.qat:
+                        # both addends receive the sum's gradient: ONE pass over it feeds the two sinks (pq_route_bwd dx2)
+                        k1 = self._sink(sa, l.pq_ew_blocks(sa.rows, sa.C))
+                        k2 = self._sink(sb, l.pq_ew_blocks(sb.rows, sb.C))
+                        r = abi.RouteBwd(ptr(out.grad), k1, sa.B, sa.H, sa.W, sa.C, out.ld, 0, 1, None, 0, 0, 0.0, k2)
                         self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+                    else:
+                        for srcT in (sa, sb):
+                            r = abi.RouteBwd(ptr(out.grad), self._sink(srcT, l.pq_ew_blocks(srcT.rows, srcT.C)), srcT.B, srcT.H,
+                                             srcT.W, srcT.C, out.ld, 0, 1)
+                            self._op(self.bwd, abi.OP_ROUTE_BWD, r)
             elif t == 'route':
                 if not m.single and len(m._layers) > 1:
                     out = T[i]

@@ -931,6 +931,43 @@ def test_copy_and_route():
     close(t2.float(), (gw.double() * xh).sum((0, 1, 2)).float(), at=1e-3)
 
 
+@pytest.mark.parametrize('B,H,W,Cc', [(2, 9, 13, 24), (2, 32, 32, 96), (1, 5, 7, 64)])
+def test_route_bwd_two_sinks_equals_two_calls(B, H, W, Cc):
+    """Shortcut backward: both addends receive the sum's gradient.  One pq_route_bwd call with dx2 (gout read once) against
+    two calls: bit-identical gradients and statistic rows -- one sink finalises with ReLU6' and BatchNorm-backward sums, the
+    other accumulates into an existing gradient (the residual path)."""
+    l = abi.lib()
+    g = torch.Generator().manual_seed(B * H * W + Cc)
+    rows = B * H * W
+    gout = rnd(rows, Cc, g=g).to(DEV)
+    y1, y2 = rnd(rows, Cc, g=g).to(DEV) * 2 + 1, rnd(rows, Cc, g=g).to(DEV)
+    old2 = rnd(rows, Cc, g=g).to(DEV)
+    sc, sh = chan_vec(torch.rand(Cc, generator=g) + 0.5), chan_vec(rnd(Cc, g=g, scale=0.5))
+    mean, inv = chan_vec(rnd(Cc, g=g)), chan_vec(torch.rand(Cc, generator=g) + 0.5)
+    nblk, ldp = l.pq_ew_blocks(rows, Cc), (Cc + 15) // 16 * 16
+
+    def sinks():
+        g1 = torch.full((rows, Cc), float('nan'), device=DEV)
+        g2 = old2.clone()
+        p1, p2 = torch.zeros(nblk * 2 * ldp, device=DEV), torch.zeros(nblk * 2 * ldp, device=DEV)
+        k1 = abi.GSink(g1.data_ptr(), y1.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr(), p1.data_ptr(),
+                       Cc, Cc, 2, 0, 1, ldp)
+        k2 = abi.GSink(g2.data_ptr(), y2.data_ptr(), None, None, mean.data_ptr(), inv.data_ptr(), p2.data_ptr(), Cc, Cc, 0, 1, 1, ldp)
+        return g1, g2, p1, p2, k1, k2
+    g1, g2, p1, p2, k1, k2 = sinks()
+    for k in (k1, k2):
+        r = abi.RouteBwd(gout.data_ptr(), k, B, H, W, Cc, Cc, 0, 1)
+        abi.check(l.pq_route_bwd(C.byref(r), stream()))
+    h1, h2, q1, q2, k1, k2 = sinks()
+    r = abi.RouteBwd(gout.data_ptr(), k1, B, H, W, Cc, Cc, 0, 1, None, 0, 0, 0.0, k2)
+    abi.check(l.pq_route_bwd(C.byref(r), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(h1, g1) and torch.equal(h2, g2) and torch.equal(q1, p1) and torch.equal(q2, p2)
+    u = y1.cpu() * sc[:Cc].cpu() + sh[:Cc].cpu()
+    close(h1, gout.cpu() * ((u > 0) & (u < 6)).float(), what='two-sink route: finalising sink')
+    close(h2, old2.cpu() + gout.cpu(), what='two-sink route: accumulating sink')
+
+
 def test_copy_and_route_with_channel_counts_that_are_not_multiples_of_four():
     """Pruned nets concatenate e.g. 25 + 95 channels: the second slice starts at an unaligned offset and the first one ends
     inside a quad.  Pitches stay multiples of 4; pad lanes are never written."""
