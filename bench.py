@@ -186,7 +186,7 @@ PMC_PATTERN = {
     'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<|gemm2_tn_kernel<', r'pq::slab_reduce'),
     'conv1x1_bwd narrow layers (fused dgrad+wgrad, one pass over dy)': (r'pw_bwd_kernel<', r'pw_slab_reduce_kernel'),
 }
-PMC_FILE = 'r2_pmc_summary.csv'
+PMC_FILE = 'r3_pmc_summary.csv'
 
 
 def measured_traffic(kernel_class, model_name):
