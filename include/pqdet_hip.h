@@ -254,11 +254,18 @@ typedef struct pq_dw3x3_bwd_args {
                             2: weight gradient only (w, dx unused) -- lets the weight half run on another stream;
                             3: both gradients from ONE staging of (g, y_out) and of the layer input (needs in.x == dx.y, i.e. the
                                sink is the conv's input tensor): per-block weight-gradient rows are left in `scratch`;
-                            4: reduce those rows into dw (the only launch that may then run on another stream) */
+                            4: reduce those rows into dw (the only launch that may then run on another stream);
+                            5: both gradients by the WALKING kernel (any plane size, stride 1|2; needs in.x == dx.y): a workgroup
+                               walks down a 16-column strip with (dy', input) row rings in LDS, every tensor is read once; the
+                               sink's statistics rows and the weight-gradient rows in `scratch` are one per workgroup
+                               (pq_dw3x3_bwd_walk_blocks);
+                            6: reduce the rows a part-5 launch left in `scratch` into dw */
 } pq_dw3x3_bwd_args;
 int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream);
 int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t C, int32_t stride);
 int32_t pq_dw3x3_bwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t stride);
+/* parts 5 / 6: workgroups of the walking kernel = rows of the sink's statistics = rows [C][9] of `scratch` */
+int32_t pq_dw3x3_bwd_walk_blocks(int32_t B, int32_t IH, int32_t IW, int32_t C, int32_t stride);
 /* 1 when the fused tiled backward beats pq_dw3x3_dgrad + pq_dw3x3_wgrad for this plane size (measured heuristic) */
 int32_t pq_dw3x3_bwd_fused_pays(int32_t IH, int32_t IW, int32_t stride);
 

@@ -19,6 +19,7 @@ SOURCES = {            # file -> extra flags
     'gemm2.hip': ['-Wno-inline-asm'],
     'dwconv.hip': [],
     'dwtile.hip': [],
+    'dwwalk.hip': [],
     'gconv.hip': [],
     'pwbwd.hip': [],
     'qat.hip': ['-ffp-contract=off'],

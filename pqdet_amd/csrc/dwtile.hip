@@ -759,6 +759,8 @@ static void bwd_tiles(int IH, int IW, int stride, int& th, int& tw) {
 }
 
 int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream);     // dwconv.hip
+int dw_walk_blocks(int B, int IH, int IW, int C, int stride);       // dwwalk.hip
+int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream);
 
 // Which forward / backward variant pays: the LDS-tiled kernels win while the planes are small (<= 64x64 at batch 16:
 // few, fat workgroups per image), the streaming register-window kernels win on the big early planes (measured with
@@ -828,8 +830,30 @@ extern "C" int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW,
     return (int64_t)pq_dw3x3_bwd_blocks(B, IH, IW, stride) * C * 9 * 4;
 }
 
+extern "C" int32_t pq_dw3x3_bwd_walk_blocks(int32_t B, int32_t IH, int32_t IW, int32_t C, int32_t stride) {
+    if (B <= 0 || IH <= 0 || IW <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
+    return dw_walk_blocks(B, IH, IW, C, stride);
+}
+
 extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
-    PQ_CHECK_ARG(a && a->part >= 0 && a->part <= 4, "null pointer / bad part");
+    PQ_CHECK_ARG(a && a->part >= 0 && a->part <= 6, "null pointer / bad part");
+    if (a->part >= 5) {       // the walking kernel (dwwalk.hip): 5 = both gradients, rows left in scratch; 6 = their reduction
+        PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1)");
+        PQ_CHECK_ARG(a->scratch && (a->part == 5 || a->dw), "part 5 / 6 need scratch (6: and dw)");
+        if (a->part == 5) {
+            PQ_CHECK_ARG(a->dy.g && a->w && a->dx.g && a->in.x, "null pointer");
+            PQ_CHECK_ARG(a->in.x == a->dx.y && a->in.ld == a->dx.ldy, "part 5: the sink must be the conv's input tensor");
+            PQ_CHECK_ARG(a->in.scale == a->dx.scale && a->in.shift == a->dx.shift && a->in.act == a->dx.act,
+                         "part 5: the sink's scale / shift / activation must be the input operand's (same tensor)");
+            PQ_CHECK_ARG(a->stride == 1 || ((a->IH & 1) == 0 && (a->IW & 1) == 0), "stride-2 backward needs even input sizes");
+            PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->in.ld & 3) == 0 && (a->dx.ldg & 3) == 0 && (!a->dy.y || (a->dy.ldy & 3) == 0), "pitches must be multiples of 4");
+            if (act_is_special(a->dx.act) || act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_bwd: logistic/tanh are not supported"); return PQ_EUNSUPPORTED; }
+        }
+        const int rc = dw_walk_launch(a, stream);
+        if (rc != PQ_OK) return rc;
+        PQ_CHECK_LAUNCH();
+        return PQ_OK;
+    }
     if (a->part == 4) {       // only the reduction of the per-block weight-gradient rows a part-3 launch left in `scratch`
         PQ_CHECK_ARG(a->dw && a->scratch && a->stride == 1 && a->B > 0 && a->C > 0, "part 4 needs dw, scratch, stride 1");
         int th4, tw4; bwd_tiles(a->IH, a->IW, a->stride, th4, tw4);

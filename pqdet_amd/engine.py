@@ -928,7 +928,27 @@ class Plan:
                                                    B, src.H, src.W, out.H, out.W, out.C, gw, s)
                                 self._op(self.bwd, abi.OP_GCONV_DGRAD, d)
                         else:
-                            if l.pq_dw3x3_bwd_fused_pays(src.H, src.W, s) and (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0)):
+                            walk = os.environ.get('PQ_DW_WALK', '1') != '0' and src.needs_grad and \
+                                (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0))
+                            if walk:
+                                nblk = l.pq_dw3x3_bwd_walk_blocks(B, src.H, src.W, out.C, s)
+                                sink, sin = self._sink(src, nblk), src.src()
+                                if not (sink.y == sin.x and sink.ldy == sin.ld and sink.scale == sin.scale and
+                                        sink.shift == sin.shift and sink.act == sin.act):
+                                    raise RuntimeError('internal: layer %d: the depthwise conv\'s gradient sink is not its input tensor' % i)
+                            if walk:
+                                # the WALKING backward (dwwalk.hip): both gradients from one pass over (g, y_out, y_in) on the main
+                                # stream -- 4 tensor passes instead of the 7 of a data- and a weight-gradient kernel -- with one
+                                # statistics / weight-gradient row per workgroup; only the reduction of those few rows goes to the
+                                # weight-gradient stream.  (PQ_DW_WALK=0: the round-2 split, A/B and tests.)
+                                buf = self._new(nblk * out.C * 9 + 16)
+                                a = abi.DwBwd(dy, sin, wsrc, sink, None, ptr(buf), B, src.H, src.W, out.H, out.W, out.C, s, 5)
+                                self._op(self.bwd, abi.OP_DW_BWD, a)
+                                a = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), wdst, ptr(buf), B, src.H, src.W, out.H,
+                                              out.W, out.C, s, 6)
+                                idx = self._op(self.bwd, abi.OP_DW_BWD, a)
+                                self.bwd[idx].flags = abi.OPF_SIDE
+                            elif l.pq_dw3x3_bwd_fused_pays(src.H, src.W, s) and (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0)):
                                 # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
                                 need = l.pq_dw3x3_bwd_scratch_bytes(B, src.H, src.W, out.H, out.W, out.C, s)
                                 sink = self._sink(src, l.pq_dw3x3_bwd_blocks(B, src.H, src.W, s))

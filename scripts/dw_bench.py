@@ -15,7 +15,7 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-tot = [0, 0, 0]
+tot = [0, 0, 0, 0, 0]
 for (B, H, W, Cc, s) in SHAPES:
     OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
     x = torch.randn(B, H, W, Cc, device=dev); yo = torch.randn(B, OH, OW, Cc, device=dev); g = torch.randn(B, OH, OW, Cc, device=dev)
@@ -33,10 +33,19 @@ for (B, H, W, Cc, s) in SHAPES:
     t1 = timeit(lambda: abi.check(l.pq_dw3x3_dgrad(C.byref(d), st)))
     t2 = timeit(lambda: abi.check(l.pq_dw3x3_wgrad(C.byref(wg), st)))
     t3 = timeit(lambda: abi.check(l.pq_dw3x3_bwd(C.byref(fb), st)))
+    nbw = l.pq_dw3x3_bwd_walk_blocks(B, H, W, Cc, s)
+    partw = torch.empty(nbw * 2 * Cc, device=dev); scw = torch.empty(nbw * Cc * 9 + 16, device=dev)
+    sinkw = abi.GSink(gin.data_ptr(), x.data_ptr(), a.data_ptr(), b2.data_ptr(), mn.data_ptr(), iv.data_ptr(), partw.data_ptr(), Cc, Cc, 2, 0, 1, Cc)
+    f5 = abi.DwBwd(gs, src, w.data_ptr(), sinkw, None, scw.data_ptr(), B, H, W, OH, OW, Cc, s, 5)
+    f6 = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), dw.data_ptr(), scw.data_ptr(), B, H, W, OH, OW, Cc, s, 6)
+    t5 = timeit(lambda: abi.check(l.pq_dw3x3_bwd(C.byref(f5), st)))
+    t6 = timeit(lambda: abi.check(l.pq_dw3x3_bwd(C.byref(f6), st)))
     byt = 4.0 * (B * H * W * Cc * 2 + B * OH * OW * Cc * 2)     # minimal: g, y_out, y_in read + g_in written
-    tot[0] += t1; tot[1] += t2; tot[2] += t3
-    print('B=%d %dx%d C=%d s=%d | dgrad %.3f wgrad %.3f sum %.3f | fused %.3f ms (%.0f GB/s of minimal traffic)' % (B, H, W, Cc, s, t1, t2, t1 + t2, t3, byt / t3 / 1e6), flush=True)
-print('sum dgrad %.3f wgrad %.3f fused %.3f' % tuple(tot))
+    tot[0] += t1; tot[1] += t2; tot[2] += t3; tot[3] += t5; tot[4] += t6
+    print('B=%d %dx%d C=%d s=%d | dgrad %.3f wgrad %.3f sum %.3f | fused tiled %.3f ms | walking %.3f ms (%.0f GB/s of minimal traffic, %d workgroup rows) + reduce %.3f' % (
+        B, H, W, Cc, s, t1, t2, t1 + t2, t3, t5, byt / t5 / 1e6, nbw, t6), flush=True)
+print('sum dgrad %.3f wgrad %.3f fused tiled %.3f walking %.3f + reduce %.3f' % tuple(tot))
+if os.environ.get('BWD_ONLY'): sys.exit(0)
 
 # ---- forward: PQ_DW_MODE decides tiled vs streaming (run the script twice)
 print('forward, mode', os.environ.get('PQ_DW_MODE', 'auto'))

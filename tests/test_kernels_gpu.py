@@ -571,6 +571,32 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     t1, t2 = reduce_partial(part3, nb3, ldp, Cc)
     close(t1.float(), gwant.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum')
     close(t2.float(), (gwant.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum xhat')
+    # the WALKING kernel (parts 5 + 6, the engine's default): row rings in LDS, every tensor read once, one statistics / weight-
+    # gradient row per workgroup; any plane size, both strides; plain and accumulating sink
+    nbw = l.pq_dw3x3_bwd_walk_blocks(B, H, W, Cc, stride)
+    assert nbw > 0
+    prev = rnd(B, H, W, Cc, g=g)
+    for accumulate in (0, 1):
+        gw_ = padc(prev) if accumulate else torch.full((B, H, W, P), float('nan'), device=DEV)
+        if not accumulate:
+            gw_[..., Cc:] = 0                     # pad lanes are zero at allocation in the engine
+        pw = torch.full((nbw * 2 * ldp,), float('nan'), device=DEV)
+        scw = torch.full((nbw * Cc * 9 + 16,), float('nan'), device=DEV)
+        dww = torch.full((Cc, 9), float('nan'), device=DEV)
+        f5 = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(gw_.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
+                                                              sv[1].data_ptr(), pw.data_ptr(), P, P, 2, accumulate, 1, ldp),
+                       None, scw.data_ptr(), B, H, W, OH, OW, Cc, stride, 5)
+        abi.check(l.pq_dw3x3_bwd(C.byref(f5), stream()))
+        f6 = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), dww.data_ptr(), scw.data_ptr(), B, H, W, OH, OW, Cc, stride, 6)
+        abi.check(l.pq_dw3x3_bwd(C.byref(f6), stream()))
+        torch.cuda.synchronize()
+        want = (dxin + prev) * ((u > 0) & (u < 6)).float() if accumulate else gwant
+        close(gw_[..., :Cc], want, what='walking dw dgrad (accumulate=%d)' % accumulate)
+        assert bool((gw_[..., Cc:] == 0).all())
+        close(dww.view(Cc, 1, 3, 3), wr.grad, rt=1e-3, at=1e-3, what='walking dw wgrad')
+        t1, t2 = reduce_partial(pw, nbw, ldp, Cc)
+        close(t1.float(), want.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='walking dw sum')
+        close(t2.float(), (want.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='walking dw sum xhat')
     if stride == 1:
         # the two halves on their own (the engine runs the weight half on the weight-gradient stream): bit-identical
         g3 = torch.full((B, H, W, P), float('nan'), device=DEV)
