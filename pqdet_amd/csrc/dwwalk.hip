@@ -19,7 +19,7 @@
 namespace pq {
 
 constexpr int WKQ = 8;            // channel quads per workgroup (32 channels)
-constexpr int WPQ = 9;            // LDS pixel pitch in quads (8 + 1 pad: conflict-free 16-lane ds_read_b128 groups)
+constexpr int WPQ = 8;            // LDS pixel pitch in quads: a 16-lane ds_read_b128 group = two adjacent pixels = 256 contiguous bytes = every bank once
 
 struct WalkGeom2 {                                    // stride 2: a step = 8 input rows x 16 columns (4 x 8 outputs)
     static constexpr int TH = 8;
