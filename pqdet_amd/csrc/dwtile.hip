@@ -761,6 +761,8 @@ static void bwd_tiles(int IH, int IW, int stride, int& th, int& tw) {
 int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream);     // dwconv.hip
 int dw_walk_blocks(int B, int IH, int IW, int C, int stride);       // dwwalk.hip
 int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream);
+int dw_fwd_walk_blocks(int B, int H, int W, int C);
+int dw_fwd_walk_launch(const pq_dw3x3_fwd_args* a, void* stream);
 
 // Which forward / backward variant pays: the LDS-tiled kernels win while the planes are small (<= 64x64 at batch 16:
 // few, fat workgroups per image), the streaming register-window kernels win on the big early planes (measured with
@@ -772,6 +774,11 @@ static int dw_mode_override() {
         mode = !e ? -1 : (e[0] == 't' ? 1 : 0);
     }
     return mode;
+}
+// stride-1 forward: the walking kernel (dwwalk.hip) at every plane size; PQ_DW_FWD_WALK=0 restores the tiled / streaming pair (A/B)
+static bool dw_fwd_use_walk(int stride) {
+    static const char* e = getenv("PQ_DW_FWD_WALK");
+    return stride == 1 && !(e && e[0] == '0') && dw_mode_override() < 0;
 }
 static bool dw_fwd_use_tiled(int OH, int OW, int stride) {
     const int o = dw_mode_override();
@@ -786,6 +793,7 @@ extern "C" int32_t pq_dw3x3_bwd_fused_pays(int32_t IH, int32_t IW, int32_t strid
 }
 
 extern "C" int32_t pq_dw3x3_fwd_blocks(int32_t B, int32_t OH, int32_t OW, int32_t C, int32_t stride) {
+    if (dw_fwd_use_walk(stride)) return dw_fwd_walk_blocks(B, OH, OW, C);
     if (!dw_fwd_use_tiled(OH, OW, stride)) return ew_geom((long)B * OH * OW, C).gx;
     int th, tw; fwd_tiles(OH, OW, stride, th, tw);
     return B * th * tw;
@@ -800,6 +808,13 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1)");
     PQ_CHECK_ARG((a->in.ld & 3) == 0 && (a->ldo & 3) == 0, "pitches must be multiples of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
+    if (dw_fwd_use_walk(a->stride)) {
+        PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->minmax == 0 && a->ldp >= a->C), "stat_acc needs stat_bad, no minmax");
+        const int rc = dw_fwd_walk_launch(a, stream);
+        if (rc != PQ_OK) return rc;
+        PQ_CHECK_LAUNCH();
+        return PQ_OK;
+    }
     if (!dw_fwd_use_tiled(a->OH, a->OW, a->stride)) {
         if (a->stat_acc || a->in.stat.acc) { pq_set_error("pq_dw3x3_fwd: the statistics hand-over needs the LDS-tiled kernel (ask pq_bn_stat_ok first)"); return PQ_EUNSUPPORTED; }
         return pq_dw_fwd_stream(a, stream);
@@ -822,7 +837,7 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
 // pq_bn_stat_ok for PQ_OP_DW_FWD: producer and consumer roles both need the LDS-tiled kernel (planes up to 64 x 64)
 int dw_fwd_stat_ok(const pq_dw3x3_fwd_args* a, int role) {
     (void)role;
-    return a && !a->minmax && !a->in.qstate && dw_fwd_use_tiled(a->OH, a->OW, a->stride);
+    return a && !a->minmax && !a->in.qstate && (dw_fwd_use_walk(a->stride) || dw_fwd_use_tiled(a->OH, a->OW, a->stride));
 }
 
 extern "C" int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t C, int32_t stride) {

@@ -531,6 +531,169 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s1_kernel(DwWP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, stride 1
+// The same walk for the forward pass: ONE ring (the transformed input x' = act(scale * y + shift), zero padding applied at
+// staging), a step = 4 output rows x 16 columns, two outputs per lane (column pl % 16, rows 2 * (pl / 16) + {0, 1}; taps of an
+// output in (ky, kx) order as in every other depthwise kernel: bit-identical outputs).  Every input element is fetched once
+// (+ the 2 / 16 column halo), the next step's rows are in flight during the arithmetic, and the workgroup leaves ONE
+// statistics row (or one set of accumulator atomics: pq_bn_stat hand-over, both roles, any plane size).
+struct DwFWP {
+    pq_src in; const float* w; float* out; float* partial;
+    int ldo, ldp, B, H, W, C, C4, strips, segs, seg_rows, minmax;
+    int64_t* stat_acc; uint32_t* stat_bad; int stat_slots;
+};
+
+__global__ __launch_bounds__(256, 3) void dw_fwd_walk_s1_kernel(DwFWP p) {
+    constexpr int R = 6, CW = 18, TH = 4;
+    constexpr int RING_F4 = R * CW * WPQ;
+    constexpr int LDS_F4 = RING_F4 > 32 * 8 * 2 + 16 ? RING_F4 : 32 * 8 * 2 + 16;      // ring | statistics reduction | coefficient staging
+    __shared__ float4 xtr[LDS_F4 < 544 ? 544 : LDS_F4];                                  // >= 2048 + 64 floats for src_coef4_chunk32
+    __shared__ float4 wtab[WKQ][9];
+    const int t = threadIdx.x;
+    const int q = t & 7, pl = t >> 3;
+    int tIdx, bcy;
+    xcd_block(tIdx, bcy);
+    const int strip = tIdx % p.strips, seg = (tIdx / p.strips) % p.segs, b = tIdx / (p.strips * p.segs);
+    const int ys = seg * p.seg_rows, x0 = strip * 16;
+    const int rows_here = min(p.seg_rows, p.H - ys);
+    const int nsteps = (rows_here + TH - 1) / TH;
+    const int yend = ys + rows_here;
+    const int cq0 = bcy * WKQ;
+    const int c0 = (cq0 + q) * 4;
+    const bool cok = cq0 + q < p.C4;
+    const int cc = cok ? c0 : 0;
+    // (with p.in.stat: the workgroup derives its 32 channels' coefficients from the producer's accumulators; workgroup 0 of the
+    // channel chunk also stores the vectors for every later consumer)
+    const SrcCoef4 xk = p.in.stat.acc ? src_coef4_chunk32(p.in, cq0 * 4, q, p.C, tIdx == 0, reinterpret_cast<float*>(xtr))
+                                      : src_coef4(p.in, cc, p.C);
+    if (pl == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (cok && c0 + j < p.C) ? p.w[(size_t)(c0 + j) * 9 + k] : 0.f;
+            wtab[q][k] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    }
+    auto ring = [&](int slot) { return slot >= R ? slot - R : slot; };
+    const bool lane_on = pl < CW;
+    const int lc = min(pl, CW - 1);
+    const int gx = x0 - 1 + lc;
+    const bool cin = cok && (unsigned)gx < (unsigned)p.W;
+    const int ox_ = min(max(gx, 0), p.W - 1) * p.in.ld + cc;
+    const int lcol = lc * WPQ + q;
+    const size_t img = (size_t)b * p.H * p.W;
+    auto load_rows = [&](auto& rx, int l0) {
+        constexpr int N = sizeof(rx) / sizeof(rx[0]);
+        if (lane_on) {
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const size_t rowb = img + (size_t)min(max(ys - 1 + l0 + u, 0), p.H - 1) * p.W;      // uniform
+                rx[u] = ldg4(p.in.x + rowb * p.in.ld + ox_);
+            }
+        }
+    };
+    auto store_rows = [&](const auto& rx, int l0, int slot0) {
+        constexpr int N = sizeof(rx) / sizeof(rx[0]);
+        if (lane_on) {
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const bool ok = cin && (unsigned)(ys - 1 + l0 + u) < (unsigned)p.H;
+                int slot = slot0 + u;
+                while (slot >= R) slot -= R;                                // uniform
+                xtr[slot * (CW * WPQ) + lcol] = ok ? src_apply4(rx[u], xk) : f4zero();
+            }
+        }
+    };
+    __syncthreads();                                   // the coefficient staging of src_coef4_chunk32 is done with the buffer
+    {
+        float4 rx[R];
+        load_rows(rx, 0);
+        store_rows(rx, 0, 0);
+    }
+    float4 s1 = f4zero(), s2 = f4zero();
+    const float inf = __builtin_huge_valf();
+    float4 mn = make_float4(inf, inf, inf, inf), mx = make_float4(-inf, -inf, -inf, -inf);
+    __syncthreads();
+
+    const int col = pl & 15, rp = pl >> 4;
+    const int wcol = col * WPQ + q;
+    int s0 = 0;
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+        const bool more = k + 1 < nsteps;              // uniform
+        float4 rx[TH];
+        if (more) load_rows(rx, R + k * TH);
+        const int y0 = ys + k * TH;
+        float4 acc[2] = {f4zero(), f4zero()};
+#pragma unroll
+        for (int wr = 0; wr < 4; ++wr) {               // window row wr (plane row y0 + 2rp - 1 + wr) meets kernel row wr - u of output u
+            const int sl = ring(s0 + 2 * rp + wr) * (CW * WPQ) + wcol;
+            float4 xr[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xr[j] = xtr[sl + j * WPQ];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ky = wr - u;
+                if (ky >= 0 && ky <= 2) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[u] = f4fma(xr[j], wtab[q][ky * 3 + j], acc[u]);
+                }
+            }
+        }
+        const int ox = x0 + col;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int oy = y0 + 2 * rp + u;
+            if (cok && oy < yend && ox < p.W) {
+                stg4(p.out + (img + (size_t)oy * p.W + ox) * p.ldo + c0, acc[u]);
+                s1 = f4add(s1, acc[u]);
+                s2 = f4fma(acc[u], acc[u], s2);
+                mn = f4min(mn, acc[u]); mx = f4max(mx, acc[u]);
+            }
+        }
+        __syncthreads();                               // every lane is done reading the rows the next step replaces
+        if (more) {
+            store_rows(rx, R + k * TH, s0);
+            s0 = ring(s0 + TH);
+            __syncthreads();
+        }
+    }
+    if (p.partial || p.stat_acc) {      // uniform
+        const int planes = p.minmax ? 4 : 2;
+        float* red = reinterpret_cast<float*>(xtr);
+        float* slot = red + (pl * 8 + q) * 8;
+        slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
+        slot[4] = s2.x; slot[5] = s2.y; slot[6] = s2.z; slot[7] = s2.w;
+        __syncthreads();
+        if (t < 64) {     // thread -> (quad t>>3, component t&7)
+            const int qq = t >> 3, comp = t & 7;
+            float a = 0.f;
+#pragma unroll
+            for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
+            const int c = (cq0 + qq) * 4 + (comp & 3);
+            if (c < p.C) {
+                if (p.stat_acc) bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, p.ldp, tIdx, comp >> 2, c, a);
+                else p.partial[(size_t)tIdx * planes * p.ldp + (comp >> 2) * p.ldp + c] = a;
+            }
+        }
+        if (p.minmax) {   // planes 2 / 3: per-channel extremes of the workgroup's outputs (QAT observers)
+            __syncthreads();
+            slot[0] = mn.x; slot[1] = mn.y; slot[2] = mn.z; slot[3] = mn.w;
+            slot[4] = mx.x; slot[5] = mx.y; slot[6] = mx.z; slot[7] = mx.w;
+            __syncthreads();
+            if (t < 64) {
+                const int qq = t >> 3, comp = t & 7;
+                float a = comp < 4 ? inf : -inf;
+#pragma unroll
+                for (int l = 0; l < 32; ++l) { const float v = red[(l * 8 + qq) * 8 + comp]; a = comp < 4 ? fminf(a, v) : fmaxf(a, v); }
+                const int c = (cq0 + qq) * 4 + (comp & 3);
+                if (c < p.C) p.partial[(size_t)tIdx * 4 * p.ldp + (2 + (comp >> 2)) * p.ldp + c] = a;
+            }
+        }
+    }
+}
+
 // out[j] = sum over the workgroups' rows (few: one per strip segment); 32 columns x 32 row lanes per block, fixed order
 __global__ __launch_bounds__(1024) void dww_partial_reduce_kernel(const float* part, int nblk, int n, float* out) {
     __shared__ float red[32][33];
@@ -590,5 +753,19 @@ int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream) {
     dim3 grid(w.nblk, w.chunks), blk(256);
     if (a->stride == 1) PQ_LAUNCH_BINDABLE(dw_bwd_walk_s1_kernel, grid, blk, 0, st, p);
     else PQ_LAUNCH_BINDABLE(dw_bwd_walk_s2_kernel, grid, blk, 0, st, p);
+    return PQ_OK;
+}
+
+// forward, stride 1 (pq_dw3x3_fwd in dwtile.hip checks the arguments and decides)
+int dw_fwd_walk_blocks(int B, int H, int W, int C) { return walk_plan(B, H, W, C, 1).nblk; }
+int dw_fwd_walk_launch(const pq_dw3x3_fwd_args* a, void* stream) {
+    const WalkPlan w = walk_plan(a->B, a->IH, a->IW, a->C, 1);
+    DwFWP p{};
+    p.in = a->in; p.w = a->w; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
+    p.B = a->B; p.H = a->IH; p.W = a->IW; p.C = a->C; p.C4 = (a->C + 3) / 4;
+    p.strips = w.strips; p.segs = w.segs; p.seg_rows = w.seg_rows;
+    p.minmax = (a->partial && a->minmax) ? 1 : 0;
+    p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
+    hipLaunchKernelGGL(dw_fwd_walk_s1_kernel, dim3(w.nblk, w.chunks), dim3(256), 0, (hipStream_t)stream, p);
     return PQ_OK;
 }
