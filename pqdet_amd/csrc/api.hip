@@ -103,6 +103,7 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
     bool used_side = false;
     hipEvent_t bound = nullptr;          // fork event already bound to the last main-stream kernel (no record needed)
     bool main_dirty = true;              // a main-stream op has been issued since the last fork (else the side stream is already ordered)
+    hipEvent_t early_join = nullptr;     // join event already recorded behind the last side op (see flush)
     auto flush = [&]() -> int {          // one fork event, then every parked op in issue order
         if (nparked == 0) return PQ_OK;
         if (main_dirty) {
@@ -114,12 +115,27 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
             main_dirty = false;
         }
         bound = nullptr;
+        const int last = parked[nparked - 1];
         for (int k = 0; k < nparked; ++k) {
             const int rc = run_one(ops[parked[k]], side_stream);
             if (rc != PQ_OK) { g_failed_op = parked[k]; return rc; }
         }
         nparked = 0;
         used_side = true;
+        // if the next thing that concerns the side stream is a JOIN (or the end of the call), record the join event NOW, right
+        // behind the last side op: by the time the main stream gets there it is usually signalled already and the wait costs
+        // nothing (recorded at the join itself, the record -> signal -> wait round trip through both queues left the main queue
+        // idle for ~45 us in front of the last head's loss finalize)
+        early_join = nullptr;
+        for (int j = last + 1; j <= n; ++j) {
+            if (j == n) { if (final_join) early_join = ev[next]; break; }
+            if (ops[j].flags & PQ_OPF_SIDE) break;
+            if (ops[j].flags & PQ_OPF_JOIN) { early_join = ev[next]; break; }
+        }
+        if (early_join) {
+            next = (next + 1) & 63;
+            if (hipEventRecord(early_join, side_s) != hipSuccess) { pq_set_error("pq_run_ops2: join record failed"); return PQ_ELAUNCH; }
+        }
         return PQ_OK;
     };
     const bool bind = bind_events();
@@ -127,10 +143,13 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
     auto join = [&]() -> int {
         { const int rc = flush(); if (rc != PQ_OK) return rc; }
         if (used_side && side_dirty) {
-            hipEvent_t e = ev[next]; next = (next + 1) & 63;
-            if (hipEventRecord(e, side_s) != hipSuccess || hipStreamWaitEvent(main_s, e, 0) != hipSuccess) {
-                pq_set_error("pq_run_ops2: join failed"); return PQ_ELAUNCH;
+            hipEvent_t e = early_join;
+            if (!e) {
+                e = ev[next]; next = (next + 1) & 63;
+                if (hipEventRecord(e, side_s) != hipSuccess) { pq_set_error("pq_run_ops2: join failed"); return PQ_ELAUNCH; }
             }
+            if (hipStreamWaitEvent(main_s, e, 0) != hipSuccess) { pq_set_error("pq_run_ops2: join failed"); return PQ_ELAUNCH; }
+            early_join = nullptr;
             side_dirty = false;
         }
         return PQ_OK;
