@@ -248,6 +248,7 @@ class _OpU(C.Union):
 
 OPF_SIDE = 1
 OPF_JOIN = 2
+OPF_LAZY = 4
 
 
 class Op(C.Structure):

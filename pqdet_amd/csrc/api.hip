@@ -158,12 +158,13 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
         if (ops[i].flags & PQ_OPF_SIDE) {
             parked[nparked++] = i;
             side_dirty = true;
-            if (nparked >= group) { const int rc = flush(); if (rc != PQ_OK) return rc; }
+            const bool lazy = (ops[i].flags & PQ_OPF_LAZY) != 0 && nparked < 60;      // rides with the next side op's fork
+            if (!lazy && nparked >= group) { const int rc = flush(); if (rc != PQ_OK) return rc; }
             continue;
         }
         if (ops[i].flags & PQ_OPF_JOIN) { const int rc = join(); if (rc != PQ_OK) return rc; }
         // the op after this one releases the parked group: offer the fork event to this op's kernel launch
-        const bool forks_next = bind && i + 1 < n && (ops[i + 1].flags & PQ_OPF_SIDE) && nparked + 1 >= group;
+        const bool forks_next = bind && i + 1 < n && (ops[i + 1].flags & PQ_OPF_SIDE) && !(ops[i + 1].flags & PQ_OPF_LAZY) && nparked + 1 >= group;
         bound = nullptr;
         if (forks_next) g_stop_event = ev[next];
         const int rc = run_one(ops[i], stream);

@@ -724,8 +724,7 @@ __global__ __launch_bounds__(1024) void dww_partial_reduce_kernel(const float* p
 
 using namespace pq;
 
-// Walk geometry: 16-column strips; the rows of an image are cut into segments (whole steps) until the launch has about two
-// rounds of workgroups for the chip (two fit a CU), never below four steps per segment where the plane allows it.
+// Walk geometry: 16-column strips; the rows of an image are cut into at most two segments of whole steps.
 struct WalkPlan { int strips, segs, seg_rows, nblk, chunks; };
 static WalkPlan walk_plan(int B, int IH, int IW, int C, int stride) {
     WalkPlan w{};
@@ -734,9 +733,13 @@ static WalkPlan walk_plan(int B, int IH, int IW, int C, int stride) {
     w.chunks = ((C + 3) / 4 + WKQ - 1) / WKQ;
     const int steps_total = (IH + th - 1) / th;
     const long base = (long)B * w.strips * w.chunks;
-    long segs = (1024 + base - 1) / base;
+    // measured (scripts/dw_bench.py, every layer shape of the nets, 1 .. 16 segments): long walks win -- two segments once the
+    // launch would otherwise leave workgroup slots empty (512 fit the chip) or the plane has >= 16 steps, one otherwise; 3+ lose
+    long segs = (512 + base - 1) / base;
+    if (segs < 2 && steps_total >= 16) segs = 2;
     const long maxsegs = steps_total / 4 > 0 ? steps_total / 4 : 1;
     if (segs > maxsegs) segs = maxsegs;
+    if (segs > 2) segs = 2;
     if (segs < 1) segs = 1;
     const int seg_steps = (int)((steps_total + segs - 1) / segs);
     w.segs = (steps_total + seg_steps - 1) / seg_steps;

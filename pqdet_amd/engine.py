@@ -947,7 +947,8 @@ class Plan:
                                 a = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), wdst, ptr(buf), B, src.H, src.W, out.H,
                                               out.W, out.C, s, 6)
                                 idx = self._op(self.bwd, abi.OP_DW_BWD, a)
-                                self.bwd[idx].flags = abi.OPF_SIDE
+                                # the reduction of a few rows is not urgent: it rides with the next weight gradient's fork
+                                self.bwd[idx].flags = abi.OPF_SIDE | (abi.OPF_LAZY if os.environ.get('PQ_LAZY_REDUCE', '1') != '0' else 0)
                             elif l.pq_dw3x3_bwd_fused_pays(src.H, src.W, s) and (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0)):
                                 # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
                                 need = l.pq_dw3x3_bwd_scratch_bytes(B, src.H, src.W, out.H, out.W, out.C, s)
