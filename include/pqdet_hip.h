@@ -269,6 +269,25 @@ int32_t pq_dw3x3_bwd_walk_blocks(int32_t B, int32_t IH, int32_t IW, int32_t C, i
 /* 1 when the fused tiled backward beats pq_dw3x3_dgrad + pq_dw3x3_wgrad for this plane size (measured heuristic) */
 int32_t pq_dw3x3_bwd_fused_pays(int32_t IH, int32_t IW, int32_t stride);
 
+/* ------------------------------------------------------------------ forward-only layers of the classifier cfgs
+ * replaces FC (model/parser.py:122-137), nn.MaxPool2d / nn.AdaptiveAvgPool2d (:441-449), dense k x k nn.Conv2d beyond the grouped
+ * 3 x 3 kernels (:389-410, as im2col + pq_conv1x1_fwd) and logistic / tanh as an ordinary conv activation (:106-112).  The
+ * reference has no training path for these nets, so there is no backward. */
+#define PQ_LAYER_MAXPOOL 0   /* nn.MaxPool2d(k, stride, pad), -inf padding */
+#define PQ_LAYER_AVGPOOL 1   /* nn.AdaptiveAvgPool2d((OH, OW)) */
+#define PQ_LAYER_IM2COL 2    /* out[B*OH*OW][ldo], column = ci*k*k + ky*k + kx (OIHW weight-row order), zero padding, pad columns 0 */
+#define PQ_LAYER_FC 3        /* out[o] = act(bias[o] + sum_n w[o][n] * in'(n)), n over the NCHW-flattened (1, C, IH, IW) input */
+#define PQ_LAYER_ACT 4       /* out = act(scale * x + shift) materialised at pitch ldo (logistic / tanh allowed) */
+#define PQ_LAYER_PADROWS 5   /* out[r][0..ldo) = w[r][0..k), then zeros; r < O */
+typedef struct pq_layer_fwd_args {
+    pq_src in;           /* NHWC virtual source (B, IH, IW, C); IM2COL with nchw != 0: the raw (B, C, IH, IW) network input */
+    const float* w;      /* FC: [O][C*IH*IW]; PADROWS: [O][k] */
+    const float* bias;   /* FC: [O] or NULL */
+    float* out;
+    int32_t kind, B, IH, IW, OH, OW, C, k, stride, pad, ldo, O, act, nchw;
+} pq_layer_fwd_args;
+int pq_layer_fwd(const pq_layer_fwd_args* a, void* stream);
+
 /* ------------------------------------------------------------------ grouped 3x3 convolution, pad 1, stride 1|2
  * replaces nn.Conv2d(k=3, groups=C/gw) fwd/bwd in the conv blocks of model/parser.py:389-410 (regnetx-600m-fpn/pan: group
  * width 24 in the backbone, 16 in the neck; also a dense 3x3 with C == gw <= 32).  gw % 4 == 0, gw <= 32, C % gw == 0.
@@ -641,7 +660,8 @@ enum {
     PQ_OP_DECODE, PQ_OP_LOSS_FWD, PQ_OP_LOSS_BWD, PQ_OP_ADAM, PQ_OP_FILL, PQ_OP_DW_BWD,
     PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD, PQ_OP_TRANSPOSE,
     PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE, PQ_OP_CONV1X1_BWD,
-    PQ_OP_BN_EVAL
+    PQ_OP_BN_EVAL,
+    PQ_OP_LAYER_FWD
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -660,6 +680,7 @@ typedef struct pq_op {
         pq_copy_args cp; pq_route_bwd_args rb;
         pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill; pq_transpose_args tr;
         pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr; pq_conv1x1_bwd_args c1b; pq_bn_eval_args bne;
+        pq_layer_fwd_args lay;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);

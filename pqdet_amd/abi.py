@@ -237,13 +237,23 @@ class QactBwd(C.Structure):
     _fields_ = [('gq', c_fp), ('dx', GSink), ('state', c_fp), ('rows', i32), ('C', i32), ('ldgq', i32), ('quantise', i32)]
 
 
+class LayerFwd(C.Structure):
+    _fields_ = [('inp', Src), ('w', c_fp), ('bias', c_fp), ('out', c_fp), ('kind', i32), ('B', i32), ('IH', i32), ('IW', i32),
+                ('OH', i32), ('OW', i32), ('C', i32), ('k', i32), ('stride', i32), ('pad', i32), ('ldo', i32), ('O', i32),
+                ('act', i32), ('nchw', i32)]
+
+
+LAYER_MAXPOOL, LAYER_AVGPOOL, LAYER_IM2COL, LAYER_FC, LAYER_ACT, LAYER_PADROWS = range(6)
+
+
 class _OpU(C.Union):
     _fields_ = [('c1f', Conv1x1Fwd), ('c1d', Conv1x1Dgrad), ('c1w', Conv1x1Wgrad),
                 ('dwf', DwFwd), ('dwd', DwDgrad), ('dww', DwWgrad), ('dwb', DwBwd), ('stf', StemFwd), ('stw', StemWgrad),
                 ('bnf', BnFwdFin), ('bnb', BnBwdFin), ('cp', Copy), ('rb', RouteBwd),
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
                 ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose),
-                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce), ('c1b', Conv1x1Bwd), ('bne', BnEval)]
+                ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce), ('c1b', Conv1x1Bwd), ('bne', BnEval),
+                ('lay', LayerFwd)]
 
 
 OPF_SIDE = 1
@@ -258,7 +268,7 @@ class Op(C.Structure):
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
  OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE, OP_QAT_WPREP, OP_QAT_WGRAD, OP_QACT_FWD,
- OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL) = range(1, 30)
+ OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL, OP_LAYER_FWD) = range(1, 31)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
@@ -266,7 +276,7 @@ OP_FIELD = {
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
     OP_TRANSPOSE: 'tr', OP_QAT_WPREP: 'qw', OP_QAT_WGRAD: 'qw', OP_QACT_FWD: 'qa', OP_QACT_BWD: 'qb',
-    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b', OP_BN_EVAL: 'bne',
+    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b', OP_BN_EVAL: 'bne', OP_LAYER_FWD: 'lay',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -301,6 +311,7 @@ SIGNATURES = {
     'pq_stem3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32, i32]),
     'pq_bn_fwd_finalize': (C.c_int, [C.POINTER(BnFwdFin), C.c_void_p]),
     'pq_bn_eval_batch': (C.c_int, [C.POINTER(BnEval), C.c_void_p]),
+    'pq_layer_fwd': (C.c_int, [C.POINTER(LayerFwd), C.c_void_p]),
     'pq_bn_bwd_finalize': (C.c_int, [C.POINTER(BnBwdFin), C.c_void_p]),
     'pq_bn_finalize_scratch_bytes': (i64, [i32]),
     'pq_bn_finalize_tickets': (i32, [i32]),

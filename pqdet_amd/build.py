@@ -20,6 +20,7 @@ SOURCES = {            # file -> extra flags
     'dwconv.hip': [],
     'dwtile.hip': [],
     'dwwalk.hip': [],
+    'layers.hip': [],
     'gconv.hip': [],
     'pwbwd.hip': [],
     'qat.hip': ['-ffp-contract=off'],

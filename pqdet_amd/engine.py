@@ -31,6 +31,11 @@ def _round_up(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
+def _one(v) -> int:
+    """kernel_size / stride / padding of a torch pooling module: int or (h, w) with h == w."""
+    return int(v[0] if isinstance(v, (tuple, list)) else v)
+
+
 class FlatParams:
     """All parameters of a model as views into one flat fp32 buffer (+ a parallel flat gradient buffer)."""
 
@@ -156,6 +161,7 @@ class Plan:
         self.post_bwd: List[abi.Op] = []
         self._inner: Dict[int, TensorRef] = {}                # QAT: layer index -> un-quantised producer tensor
         self._wq: Dict[int, tuple] = {}                       # QAT: layer index -> (wq, sf, dwq) buffers
+        self._wpad: Dict[int, torch.Tensor] = {}              # dense k x k convs: weight rows padded to the patch pitch
         self._build()
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -297,11 +303,20 @@ class Plan:
                 h, w = h * f, w * f
             elif t == 'yolo':
                 use(resolve(i - 1, i))
-            elif t == 'avgpool':                               # squeeze of an SE block: global average per image
-                if tuple(m.output_size) != (1, 1):
-                    raise NotImplementedError('only global average pooling (height = width = 1) is supported')
+            elif t == 'avgpool':                               # nn.AdaptiveAvgPool2d (global: squeeze of an SE block / classifier head)
                 use(resolve(i - 1, i))
-                h, w = 1, 1
+                osz = m.output_size if isinstance(m.output_size, (tuple, list)) else (m.output_size, m.output_size)
+                h, w = int(osz[0]), int(osz[1])
+            elif t == 'maxpool':                               # reference model/parser.py:441-444
+                use(resolve(i - 1, i))
+                k_, s_, p_ = _one(m.kernel_size), _one(m.stride), _one(m.padding)
+                h, w = (h + 2 * p_ - k_) // s_ + 1, (w + 2 * p_ - k_) // s_ + 1
+            elif t == 'fc':                                    # reference :122-137: nn.Linear on x.view(input)
+                use(resolve(i - 1, i))
+                if B * h * w * c != m.input:
+                    raise ValueError('fc layer %d expects %d inputs (x.view(input)), the tensor in front of it has %d x %d x %d x %d'
+                                     % (i, m.input, B, c, h, w))
+                h, w, c = 1, 1, m.fc.out_features
             elif t == 'scale_channels':                        # excitation: feature map x sigmoid(gate)
                 use(resolve(i - 1, i))
                 use(resolve(m._from, i))
@@ -343,8 +358,10 @@ class Plan:
                 if act == abi.ACT_LOGISTIC and i + 1 < len(mods) and mods[i + 1]._type == 'scale_channels' \
                         and consumers.get(i, 0) == 1 and not hasattr(m, 'bn'):
                     act, is_gate = 0, True          # the sigmoid of an SE gate is applied inside the scale_channels kernels
-                if act in (abi.ACT_LOGISTIC, abi.ACT_TANH):
-                    raise NotImplementedError('logistic / tanh are only supported as the gate of a scale_channels layer')
+                special_act = act in (abi.ACT_LOGISTIC, abi.ACT_TANH)
+                if special_act and (train_graph or self.qat):
+                    raise NotImplementedError('logistic / tanh as a conv activation have no backward / QAT support (forward only; '
+                                              'the gate of a scale_channels layer is the exception)')
                 raw = self._new(rows, ld) if ld == Cout else self._new(rows, ld, fill=0.0)
                 out = TensorRef(raw, B, OH, OW, Cout, ld, bn, act)
                 out.is_gate = is_gate
@@ -357,9 +374,33 @@ class Plan:
                     sfv = self._new(_round_up(Cout, ALIGN), fill=1.0)
                     dwq = self._new(conv.weight.numel()) if train_graph else None
                     self._wq[i] = (wq, sfv, dwq)
-                if i == 0:
-                    if not (k == 3 and groups == 1 and Cin == 3):
-                        raise NotImplementedError('first layer must be a dense 3x3 conv on 3 channels')
+                pad = conv.padding[0]
+                stem_ok = i == 0 and k == 3 and groups == 1 and Cin == 3 and pad == 1
+                c1_ok = i > 0 and k == 1 and groups == 1 and pad == 0
+                dw_ok = i > 0 and k == 3 and groups == Cin == Cout and pad == 1
+                gc_ok = (i > 0 and k == 3 and pad == 1 and Cin == Cout and Cin % groups == 0 and (Cin // groups) % 4 == 0 and
+                         Cin // groups <= 32 and s in (1, 2) and conv.bias is None)
+                if not (stem_ok or c1_ok or dw_ok or gc_ok):
+                    # any other dense convolution (7 x 7 stem, 3 x 3 with Cin != Cout or wide groups: the classifier cfgs): patch matrix +
+                    # the 1x1 GEMM kernels.  Forward only (the reference has no training path for these nets).
+                    if groups != 1:
+                        raise NotImplementedError('conv k=%d groups=%d (%d->%d): grouped convs beyond group width 32 / unequal '
+                                                  'channel counts have no HIP kernel' % (k, groups, Cin, Cout))
+                    if train_graph or self.qat:
+                        raise NotImplementedError('dense %d x %d conv %d->%d (layer %d) is forward only (im2col + GEMM): no backward / '
+                                                  'QAT support' % (k, k, Cin, Cout, i))
+                    K = Cin * k * k
+                    ldk = _round_up(K, 4)
+                    patches = TensorRef(self._new(rows, ldk), B, OH, OW, ldk, ldk, None, 0)
+                    srcT = None if i == 0 else T[resolve(i - 1, i)]
+                    self._deferred.append(('lay', i, abi.LAYER_IM2COL, srcT, patches, dict(k=k, stride=s, pad=pad, C=Cin)))
+                    if ldk != K:                    # weight rows to the patch pitch (refreshed every forward: the weights may change)
+                        wpad = self._new(Cout * ldk)
+                        self._wpad[i] = wpad
+                        self._deferred.append(('lay', i, abi.LAYER_PADROWS, None, wpad, dict(w=conv.weight, O=Cout, k=K, ldo=ldk)))
+                    nblk = l.pq_conv1x1_blocks_k(rows, Cout, ldk, 0)
+                    self._deferred.append(('c1_fwd', i, out, nblk, patches, 1))
+                elif i == 0:
                     nblk = l.pq_ew_blocks(rows, Cout)
                     if self.qat:
                         self.qimg = self._new(B * 3 * self.IH * self.IW)
@@ -378,9 +419,7 @@ class Plan:
                         nblk = l.pq_gconv3x3_blocks(B, OH, OW)
                         self._deferred.append(('gc_fwd', i, out, nblk, src, s))
                     else:
-                        raise NotImplementedError(
-                            'conv k=%d groups=%d (%d->%d) has no HIP kernel yet (3x3 convs need equal in/out channels and a '
-                            'group width that is a multiple of 4 and at most 32)' % (k, groups, Cin, Cout))
+                        raise RuntimeError('internal: conv dispatch')
                 if bn is not None:
                     bn.fwd_nblk = nblk
                     if want_stats:
@@ -393,6 +432,29 @@ class Plan:
                     qout = TensorRef(qbuf, B, OH, OW, Cout, ld, None, 0)
                     self._deferred.append(('qact', i, out, qout))
                     out = qout
+                if special_act and not is_gate:
+                    # consumers only apply the piecewise-linear family while loading: act(bn(conv)) is materialised once
+                    mat = TensorRef(self._new(rows, ld), B, OH, OW, Cout, ld, None, 0)
+                    self._deferred.append(('lay', i, abi.LAYER_ACT, out, mat, {}))
+                    out = mat
+                T.append(out)
+            elif t == 'maxpool' or (t == 'avgpool' and (tuple(shapes[i][:2]) != (1, 1) or T[resolve(i - 1, i)].C % 4)) or t == 'fc':
+                if train_graph or self.qat:
+                    raise NotImplementedError("layer type '%s' is forward only (no backward / QAT support)" % t)
+                a = T[resolve(i - 1, i)]
+                OH, OW, Co = shapes[i]
+                if t == 'fc':
+                    ld = _round_up(Co, 4)
+                    out = TensorRef(self._new(1, ld, fill=0.0), 1, 1, 1, Co, ld, None, 0)
+                    self._deferred.append(('lay', i, abi.LAYER_FC, a, out, dict(w=m.fc.weight, bias=m.fc.bias, O=Co,
+                                                                                act=act_code_of(m.act))))
+                else:
+                    out = TensorRef(self._new(B * OH * OW, a.ld, fill=0.0), B, OH, OW, a.C, a.ld, None, 0)
+                    if t == 'maxpool':
+                        self._deferred.append(('lay', i, abi.LAYER_MAXPOOL, a, out, dict(k=_one(m.kernel_size), stride=_one(m.stride),
+                                                                                          pad=_one(m.padding))))
+                    else:
+                        self._deferred.append(('lay', i, abi.LAYER_AVGPOOL, a, out, {}))
                 T.append(out)
             elif t == 'shortcut':
                 a, b_ = T[resolve(i - 1, i)], T[resolve(m._from, i)]
@@ -455,6 +517,8 @@ class Plan:
                     raise NotImplementedError('yolo layer must follow a linear conv without batch norm')
                 heads.append((i, m, a))
                 T.append(a)
+        if train_graph and not heads:
+            raise NotImplementedError('a net without yolo layers has no loss: forward only (the reference never trains AnyModel)')
         for i_, n_ in consumers.items():
             T[i_].n_consumers = n_
         self._consumers = dict(consumers)
@@ -495,6 +559,8 @@ class Plan:
         mods = list(model.module_list)
         B = self.B
         def wptr(i):
+            if i in self._wpad:
+                return ptr(self._wpad[i])
             return ptr(self._wq[i][0]) if self.qat else ptr(mods[i].conv.weight)
 
         if self.qat:
@@ -576,6 +642,27 @@ class Plan:
                 if getattr(out, 'fold_obs', False):
                     a.planes, a.act, a.qstate, a.mm, a.avg_const = 4, out.act, self._qstate(('a', i)), out.fold_mm.data_ptr(), 0.01
                 self._op(self.fwd, abi.OP_BN_FWD_FIN, a)
+            elif kind == 'lay':
+                _, i, lk, a_, out, kw = item
+                la = abi.LayerFwd()
+                la.kind = lk
+                la.out = ptr(out) if isinstance(out, torch.Tensor) else ptr(out.raw)
+                if lk == abi.LAYER_PADROWS:
+                    la.w, la.O, la.k, la.ldo = ptr(kw['w']), kw['O'], kw['k'], kw['ldo']
+                else:
+                    if a_ is None:                             # the network input itself (NCHW): pointer patched per call
+                        la.nchw, la.B, la.IH, la.IW, la.C = 1, B, self.IH, self.IW, 3
+                    else:
+                        la.inp, la.B, la.IH, la.IW, la.C = a_.src(), a_.B, a_.H, a_.W, a_.C
+                    la.OH, la.OW, la.ldo = out.H, out.W, out.ld
+                    la.k, la.stride, la.pad = kw.get('k', 0), kw.get('stride', 1), kw.get('pad', 0)
+                    if lk == abi.LAYER_IM2COL:
+                        la.C = kw['C']
+                    if lk == abi.LAYER_FC:
+                        la.w, la.bias, la.O, la.act = ptr(kw['w']), ptr(kw['bias']), kw['O'], kw['act']
+                idx = self._op(self.fwd, abi.OP_LAYER_FWD, la)
+                if lk == abi.LAYER_IM2COL and a_ is None:
+                    self.patch_x.append(('fwd', idx, 'lay'))
             elif kind == 'pool':
                 _, i, out, a_ = item
                 pr = abi.PoolReduce(a_.src(), None, 0, None, 0, ptr(out.raw), out.ld, a_.B, a_.H * a_.W, a_.C, 1.0 / (a_.H * a_.W))
@@ -677,6 +764,19 @@ class Plan:
                 self._check_side_forward()
             self._handover_bn_stats()
             return
+        elif not heads:
+            # a net without yolo layers (classifier cfgs): the output is the last layer's tensor (reference model/interpreter.py:60-65),
+            # materialised if it is still virtual
+            last = self.tensors[-1]
+            if last.bn is not None or last.act != 0:
+                mat = TensorRef(self._new(last.rows, last.ld), last.B, last.H, last.W, last.C, last.ld, None, 0)
+                la = abi.LayerFwd()
+                la.kind, la.out, la.inp = abi.LAYER_ACT, ptr(mat.raw), last.src()
+                la.B, la.IH, la.IW, la.C, la.ldo = last.B, last.H, last.W, last.C, mat.ld
+                self._op(self.fwd, abi.OP_LAYER_FWD, la)
+                last = mat
+            self.eval_out = None
+            self.final = last
         else:
             rows_total = sum(a.H * a.W * (a.C // (5 + m.opt['classes'])) for _, m, a in heads)
             nv = 5 + heads[0][1].opt['classes']
@@ -1069,6 +1169,8 @@ class Plan:
             arr = self.fwd_arr if which == 'fwd' else self.bwd_arr
             if field == 'qa':
                 arr[idx].u.qa.inp.x = xp          # QAT: the batch enters through the input observer
+            elif field == 'lay':
+                arr[idx].u.lay.inp.x = xp         # dense first conv: the patch matrix is gathered from the NCHW batch
             else:
                 getattr(arr[idx].u, field).image = xp
         if target is not None:

@@ -251,6 +251,11 @@ class AnyModel(nn.Module):
         if target is None:
             plan = self._plan(x, False)
             plan.run_forward(x, None)
+            if plan.eval_out is None:                  # no yolo layers (classifier cfgs): the last layer's output, reference :60-65
+                f = plan.final
+                if self.module_list[-1]._type == 'fc':
+                    return f.raw.view(-1)[:f.C].clone()                                   # nn.Linear on x.view(input): (output,)
+                return f.raw.view(f.B, f.H, f.W, f.ld)[..., :f.C].permute(0, 3, 1, 2).contiguous()
             return plan.eval_out.clone()
         self.check_nan(wait=False)
         target = tuple(t.to(x.device, torch.float32).contiguous() for t in target)
