@@ -92,6 +92,11 @@ class OracleNet(nn.Module):
                 m = _Holder(kind, s)
                 if stride is not None:
                     stride //= s['stride']
+            elif kind == 'fc':                                # :122-137 FC: nn.Linear on x.view(input), then the activation
+                m = _Holder(kind, s)
+                m.fc = nn.Linear(s['input'], s['output'])
+                m.act = _ACTS[s['activation']]() if s['activation'] != 'linear' else None
+                chans = s['output']
             elif kind == 'maxpool':
                 m = _Holder(kind, s)
                 if stride is not None:
@@ -146,6 +151,10 @@ class OracleNet(nn.Module):
                 x = F.max_pool2d(x, k, m.spec['stride'], pad)
             elif kind == 'avgpool':
                 x = F.adaptive_avg_pool2d(x, (m.spec['height'], m.spec['width']))
+            elif kind == 'fc':
+                x = m.fc(x.view(m.spec['input']))
+                if m.act is not None:
+                    x = m.act(x)
             elif kind == 'yolo':
                 opt = m.opt
                 x = self.decode(x, opt['classes'], opt['stride'])
@@ -156,6 +165,8 @@ class OracleNet(nn.Module):
             else:
                 raise ValueError(kind)
             cache.append(x)
+        if not heads:                                         # model/interpreter.py:60-65: no output layer -> the last layer's output
+            return cache[-1]
         if target is None:
             return torch.cat([h.reshape(h.shape[0], -1, h.shape[-1]) for h in heads], 1)
         total = [sum(parts) for parts in zip(*heads)]

@@ -377,15 +377,16 @@ class Plan:
                 pad = conv.padding[0]
                 stem_ok = i == 0 and k == 3 and groups == 1 and Cin == 3 and pad == 1
                 c1_ok = i > 0 and k == 1 and groups == 1 and pad == 0
-                dw_ok = i > 0 and k == 3 and groups == Cin == Cout and pad == 1
+                dw_ok = i > 0 and k == 3 and groups == Cin == Cout and pad == 1 and conv.bias is None     # (no bias input: never dropped silently)
                 gc_ok = (i > 0 and k == 3 and pad == 1 and Cin == Cout and Cin % groups == 0 and (Cin // groups) % 4 == 0 and
                          Cin // groups <= 32 and s in (1, 2) and conv.bias is None)
                 if not (stem_ok or c1_ok or dw_ok or gc_ok):
                     # any other dense convolution (7 x 7 stem, 3 x 3 with Cin != Cout or wide groups: the classifier cfgs): patch matrix +
                     # the 1x1 GEMM kernels.  Forward only (the reference has no training path for these nets).
                     if groups != 1:
-                        raise NotImplementedError('conv k=%d groups=%d (%d->%d): grouped convs beyond group width 32 / unequal '
-                                                  'channel counts have no HIP kernel' % (k, groups, Cin, Cout))
+                        raise NotImplementedError('conv k=%d groups=%d (%d->%d, bias=%s): grouped / depthwise convs need batch_normalize=1 '
+                                                  '(no bias), equal channel counts and a group width of 1 or a multiple of 4 up to 32'
+                                                  % (k, groups, Cin, Cout, conv.bias is not None))
                     if train_graph or self.qat:
                         raise NotImplementedError('dense %d x %d conv %d->%d (layer %d) is forward only (im2col + GEMM): no backward / '
                                                   'QAT support' % (k, k, Cin, Cout, i))

@@ -1332,3 +1332,81 @@ def test_adam_state_survives_state_dict_round_trip_and_reflatten():
     for p, q in zip(a.parameters(), b.parameters()):
         assert torch.equal(p, q)
     assert int(oa2.state_dict()['state'][0]['step']) == 4
+
+
+# ----------------------------------------------------------------------------------------------- forward-only layers (classifier cfgs)
+@pytest.mark.parametrize('B,H,W,Cc,act', [(2, 9, 13, 24, 1), (1, 16, 16, 64, 2), (2, 7, 7, 10, 0)])
+def test_layer_fwd_pools_im2col_fc_act(B, H, W, Cc, act):
+    g = torch.Generator().manual_seed(B * H * W + Cc)
+    l = abi.lib()
+    P = (Cc + 3) // 4 * 4
+    x = rnd(B, H, W, Cc, g=g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, rnd(Cc, g=g, scale=0.3)
+    xd = torch.zeros(B, H, W, P, device=DEV)
+    xd[..., :Cc] = x.to(DEV)
+    scd, shd = chan_vec(sc), chan_vec(sh)
+    xin = act_ref(x * sc + sh, act).permute(0, 3, 1, 2).contiguous()          # what a consumer sees (NCHW for torch)
+    src = abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), P, act)
+
+    def run(kind, out, OH=0, OW=0, k=0, stride=1, pad=0, **kw):
+        a = abi.LayerFwd()
+        a.inp, a.out, a.kind, a.B, a.IH, a.IW, a.OH, a.OW, a.C = src, out.data_ptr(), kind, B, H, W, OH, OW, Cc
+        a.k, a.stride, a.pad, a.ldo = k, stride, pad, kw.pop('ldo', P)
+        for key, v in kw.items():
+            setattr(a, key, v)
+        abi.check(l.pq_layer_fwd(C.byref(a), stream()))
+        torch.cuda.synchronize()
+
+    # nn.MaxPool2d(3, 2, 1) and (2, 2, 0)
+    for k, s_, p_ in ((3, 2, 1), (2, 2, 0), (3, 1, 1)):
+        want = F.max_pool2d(xin, k, s_, p_)
+        OH, OW = want.shape[2:]
+        out = torch.full((B, OH, OW, P), float('nan'), device=DEV)
+        run(abi.LAYER_MAXPOOL, out, OH, OW, k, s_, p_)
+        close(out[..., :Cc], want.permute(0, 2, 3, 1), what='maxpool %d/%d/%d' % (k, s_, p_))
+    # nn.AdaptiveAvgPool2d: global, and cells that do not divide the plane
+    for OH, OW in ((1, 1), (2, 3), (H, W)):
+        want = F.adaptive_avg_pool2d(xin, (OH, OW))
+        out = torch.full((B, OH, OW, P), float('nan'), device=DEV)
+        run(abi.LAYER_AVGPOOL, out, OH, OW)
+        close(out[..., :Cc], want.permute(0, 2, 3, 1), what='avgpool %dx%d' % (OH, OW))
+    # patch matrix of a dense k x k convolution == F.unfold (column = ci*k*k + ky*k + kx), then the conv as a matrix product
+    for k, s_, p_ in ((3, 1, 1), (3, 2, 1), (7, 2, 3)):
+        OH, OW = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+        K = Cc * k * k
+        ldk = (K + 3) // 4 * 4
+        out = torch.full((B * OH * OW, ldk), float('nan'), device=DEV)
+        run(abi.LAYER_IM2COL, out, OH, OW, k, s_, p_, ldo=ldk)
+        want = F.unfold(xin, k, padding=p_, stride=s_).permute(0, 2, 1).reshape(B * OH * OW, K)
+        close(out[:, :K], want, what='im2col %d/%d/%d' % (k, s_, p_))
+        assert bool((out[:, K:] == 0).all())
+    # materialised activation, logistic / tanh included
+    for a2 in (4, 5, act):
+        s2 = abi.Src(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), P, a2)
+        a = abi.LayerFwd()
+        out = torch.full((B, H, W, P), float('nan'), device=DEV)
+        a.inp, a.out, a.kind, a.B, a.IH, a.IW, a.C, a.ldo = s2, out.data_ptr(), abi.LAYER_ACT, B, H, W, Cc, P
+        abi.check(l.pq_layer_fwd(C.byref(a), stream()))
+        torch.cuda.synchronize()
+        close(out[..., :Cc], act_ref(x * sc + sh, a2), what='act %d' % a2)
+        assert bool((out[..., Cc:] == 0).all())
+    # nn.Linear on x.view(input) of ONE image (NCHW order), with bias and an output activation
+    O = 37
+    wfc, bfc = rnd(O, Cc * H * W, g=g, scale=0.1), rnd(O, g=g)
+    want = act_ref(F.linear(xin[:1].reshape(-1), wfc, bfc), 1)
+    out = torch.full((O,), float('nan'), device=DEV)
+    a = abi.LayerFwd()
+    wd, bd = wfc.to(DEV), bfc.to(DEV)
+    a.inp, a.w, a.bias, a.out, a.kind = src, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), abi.LAYER_FC
+    a.B, a.IH, a.IW, a.C, a.O, a.act = 1, H, W, Cc, O, 1
+    abi.check(l.pq_layer_fwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(out, want, rt=1e-3, at=1e-3, what='fc')
+    # weight rows to a padded pitch
+    wsrc = rnd(5, 147, g=g).to(DEV)
+    out = torch.full((5, 148), float('nan'), device=DEV)
+    a = abi.LayerFwd()
+    a.w, a.out, a.kind, a.O, a.k, a.ldo = wsrc.data_ptr(), out.data_ptr(), abi.LAYER_PADROWS, 5, 147, 148
+    abi.check(l.pq_layer_fwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :147], wsrc) and bool((out[:, 147:] == 0).all())

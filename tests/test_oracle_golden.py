@@ -1,5 +1,6 @@
 """Pin the CPU oracle (oracle/) against golden vectors recorded from the imported reference."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -137,3 +138,30 @@ def test_g5_full_model(golden, g5_names, tag, size):
     np.testing.assert_allclose(sd[rm[0]].numpy(), golden['g5_%s_rmean_first' % tag], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(sd[rm[-1].replace('running_mean', 'running_var')].numpy(),
                                golden['g5_%s_rvar_last' % tag], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['regnetx-600m', 'regnety-400m', 'resnet50-1g', 'resnet50'])
+def test_g13_classifier_cfgs(name):
+    """G13 (make_golden_r3b.py): the reference's AnyModel on the four classifier cfgs (7 x 7 stem, maxpool, dense 3 x 3 convs,
+    global avgpool, fc), seeded fill, one seeded 64 x 64 image -> (1000,)."""
+    import io
+    import json
+    torch.set_num_threads(8)
+    here = os.path.dirname(os.path.abspath(__file__))
+    g1 = json.load(open(os.path.join(here, 'golden', 'g1_parser.json')))['cfgs']['classifier/%s.cfg' % name]
+    g13 = np.load(os.path.join(here, 'golden', 'golden_r3b.npz'))
+    lines = []
+    for sec in g1['specs']:
+        lines.append('[%s]' % sec['name'])
+        lines += ['%s=%s' % (k, ', '.join(str(x) for x in v) if isinstance(v, list) else v) for k, v in sec.items() if k != 'name']
+        lines.append('')
+    net = OracleNet(io.StringIO('\n'.join(lines) + '\n'))
+    assert sum(p.numel() for p in net.parameters()) == g1['params']
+    seeded_fill(net, 5)
+    net.eval()
+    cache = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: cache.append(out)) for m in net.module_list]
+    with torch.no_grad():
+        y = net(seeded_images(1, 64, 64, 7))
+    np.testing.assert_allclose(y.numpy(), g13['g13_%s_out' % name], rtol=1e-4, atol=1e-4)
+    assert len(hooks) == g1['n_layers']
