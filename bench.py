@@ -225,14 +225,18 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(batch, size, steps=2, model='mobilenetv2-fpn'):
+def cpu_baseline(batch, size, steps=2, model='mobilenetv2-fpn', qat=False):
     """The CPU oracle (oracle/, PyTorch-CPU restatement pinned against the reference's golden vectors) timed on the
     host cores on the same workload shape.  Reported baseline only -- never part of the measured path."""
     from oracle.net import OracleNet
     threads = usable_cores()
     torch.set_num_threads(threads)
     log('cpu baseline on %d threads (os.cpu_count=%s)' % (threads, os.cpu_count()))
-    net = OracleNet(io.StringIO(zoo.cfg_text(model)))
+    if qat:                                        # config 5: the oracle's quantisation-aware net (observers + fake-quant on)
+        from oracle.qat import OracleQATNet
+        net = OracleQATNet(io.StringIO(zoo.cfg_text(model)))
+    else:
+        net = OracleNet(io.StringIO(zoo.cfg_text(model)))
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=4e-4)
     x = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(0))
@@ -248,8 +252,8 @@ def cpu_baseline(batch, size, steps=2, model='mobilenetv2-fpn'):
             times.append(time.perf_counter() - t0)
     dt = sum(times) / len(times)
     return {'value': batch / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d timed train steps (after 1 warm-up) of %s %dx%d batch %d on the CPU oracle, '
-                      '%.2f s/step' % (steps, model, size, size, batch, dt)}
+            'sample': '%d timed train steps (after 1 warm-up) of %s%s %dx%d batch %d on the CPU oracle, '
+                      '%.2f s/step' % (steps, model, ' (QAT)' if qat else '', size, size, batch, dt)}
 
 
 def main(args, world, rank, local):
@@ -348,8 +352,8 @@ def main(args, world, rank, local):
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and not args.qat:
-            line['cpu_baseline'] = cpu_baseline(B, S, steps=max(1, args.cpu_steps), model=args.model)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(B, S, steps=max(1, args.cpu_steps), model=args.model, qat=args.qat)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
