@@ -95,7 +95,7 @@ KERNEL_CLASS = {
     abi.OP_CONV1X1_WGRAD: ('conv1x1_wgrad (gemm_tn, fp32 MFMA)', 'mfma'),
     abi.OP_CONV1X1_BWD: ('conv1x1_bwd narrow layers (fused dgrad+wgrad, one pass over dy)', 'hbm'),
     abi.OP_DW_FWD: ('dw3x3_fwd', 'hbm'), abi.OP_DW_DGRAD: ('dw3x3_dgrad', 'hbm'), abi.OP_DW_WGRAD: ('dw3x3_wgrad', 'hbm'),
-    abi.OP_DW_BWD: ('dw3x3_bwd (fused dgrad+wgrad, LDS tiles)', 'hbm'),
+    abi.OP_DW_BWD: ('dw3x3_bwd (both gradients, one pass: walking kernel)', 'hbm'),
     abi.OP_GCONV_FWD: ('gconv3x3_fwd (implicit GEMM, fp32 MFMA)', 'mfma'),
     abi.OP_GCONV_DGRAD: ('gconv3x3_dgrad (implicit GEMM, fp32 MFMA)', 'mfma'),
     abi.OP_GCONV_WGRAD: ('gconv3x3_wgrad (implicit GEMM, fp32 MFMA)', 'mfma'),
