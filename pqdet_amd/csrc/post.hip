@@ -278,6 +278,70 @@ __global__ void nms_offsets_kernel(const unsigned* hist, int C, unsigned* offs) 
     }
 }
 
+// ---- both sorts of a call with a capacity of up to NMS_SMALL_MAX entries in ONE workgroup (no vendor library on this path): bitonic sort of
+// 64-bit keys in LDS.  The radix sorts' results depend on their stability (ties in score keep ascending pair index, classes keep
+// score order); here both orders are made TOTAL by putting the tie-breaker into the key -- (descending score, ascending pair
+// index) and (class, score rank) --, so any correct sort gives the same, bit-identical permutation.  The per-class segment
+// offsets are lower bounds in the class-sorted keys.  Replaces ~12 dependent launches (rocPRIM radix sort x 2, class keys,
+// histogram scan) of a call that is launch-bound at these sizes.
+constexpr int NMS_SMALL_MAX = 8192;      // = the default candidate capacity of ops.nms; measured against the library sorts (one
+                                        // image, 16128 x 20 pairs): 100 / 1000 / 2000 candidates 0.063 / 0.092 / 0.123 ms against 0.103 / 0.120 /
+                                        // 0.140, equal at ~4000, slower beyond (7000: 0.284 against 0.213): larger capacities keep the library
+
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* a, int P, int t, int nt) {
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = t; i < (P >> 1); i += nt) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;     // the pair (lo, lo + j) of compare distance j
+                const bool up = (lo & k) == 0;
+                const unsigned long long x = a[lo], y = a[hi];
+                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+        }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void nms_sort_small_kernel(const float* keys0, const unsigned* vals0, int S, int P, int compact, int C, int NC,
+                                                               int nimg, const NmsMeta* meta, float* keys1, unsigned* vals1, unsigned* rk1,
+                                                               unsigned* offs) {
+    extern __shared__ unsigned long long sk[];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const unsigned K = meta->count;
+    // after the ordered compaction the candidates are the first K entries (the rest is fill): only the next power of two takes
+    // part in the sorts -- a trained detector leaves 10^2..10^3 candidates in a capacity of 8192
+    int Q = P;
+    if (compact) { Q = 64; while (Q < (int)K) Q <<= 1; if (Q > P) Q = P; }
+    const int SQ = S < Q ? S : Q;
+    // (descending score, ascending pair index): the ordered image of the score is inverted, entries beyond S sort last
+    for (int i = t; i < Q; i += nt)
+        sk[i] = i < S ? ((unsigned long long)(~f2ord(keys0[i])) << 32) | (unsigned long long)vals0[i] : ~0ull;
+    bitonic_sort_lds(sk, Q, t, nt);
+    for (int i = t; i < Q; i += nt) {
+        const unsigned long long v = sk[i];
+        unsigned long long k2 = ~0ull;
+        if (i < S) {
+            const unsigned e = (unsigned)v;
+            keys1[i] = ord2f(~(unsigned)(v >> 32));
+            vals1[i] = e;
+            const unsigned c = (unsigned)i < K ? e % (unsigned)C + (unsigned)C * ((e / (unsigned)C) / (unsigned)nimg) : 0xFFFFu;
+            k2 = ((unsigned long long)c << 32) | (unsigned long long)(unsigned)i;       // (class per image, score rank)
+        }
+        sk[i] = k2;               // (element i is read and rewritten by the same thread)
+    }
+    for (int i = Q + t; i < S; i += nt) { keys1[i] = keys0[i]; vals1[i] = vals0[i]; rk1[i] = (unsigned)i; }   // fill, already in place
+    bitonic_sort_lds(sk, Q, t, nt);
+    for (int i = t; i < SQ; i += nt) rk1[i] = (unsigned)sk[i];
+    // offs[c] = first position whose class is >= c (c = 0 .. NC): lower bound over the sorted (class, rank) keys; beyond the
+    // sorted part every entry is a non-candidate (class 0xFFFF)
+    for (int c = t; c <= NC; c += nt) {
+        const unsigned long long want = (unsigned long long)(unsigned)c << 32;
+        int lo = 0, hi = SQ;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sk[mid] < want) lo = mid + 1; else hi = mid; }
+        offs[c] = (unsigned)lo;
+    }
+}
+
 __device__ __forceinline__ bool nms_overlap(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2,
                                             float by2, float barea, float thr) {
     const float w = fmaxf(0.f, fminf(ax2, bx2) - fmaxf(ax1, bx1));
@@ -633,6 +697,18 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
                            (unsigned)S);
         PQ_CHECK_LAUNCH();
     }
+    static const char* lib_env = getenv("PQ_NMS_LIBSORT");            // "1": the library radix sorts at every size (A/B timing, tests)
+    const bool small = S <= NMS_SMALL_MAX && !(lib_env && lib_env[0] == '1');
+    if (small) {
+        int P = 1024;                                                    // power of two >= S, >= the block size (uniform loops)
+        while (P < S) P <<= 1;
+        static bool raised = hipFuncSetAttribute((const void*)nms_sort_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 NMS_SMALL_MAX * 8) == hipSuccess;
+        if (!raised) { pq_set_error("pq_nms: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
+        hipLaunchKernelGGL(nms_sort_small_kernel, dim3(1), dim3(1024), (size_t)P * 8, st, (const float*)keys0, (const unsigned*)vals0, (int)S, P,
+                           S == E ? 0 : 1, a->C, NC, a->N, (const NmsMeta*)meta, keys1, vals1, rk1, offs);
+        PQ_CHECK_LAUNCH();
+    } else {
     size_t need = 0;
     hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, need, keys0, keys1, vals0, vals1, (size_t)S, 0, 32, st);
     if (e != hipSuccess || need > tmp_avail) { pq_set_error("pq_nms: sort scratch (%zu needed, %zu available)", need, tmp_avail); return PQ_EINVAL; }
@@ -647,6 +723,7 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
     if (e != hipSuccess || need2 > tmp_avail) { pq_set_error("pq_nms: class-sort scratch (%zu needed, %zu available)", need2, tmp_avail); return PQ_EINVAL; }
     e = rocprim::radix_sort_pairs(tmp, need2, ck0, ck1, rk0, rk1, (size_t)S, 0, 16, st);
     if (e != hipSuccess) { pq_set_error("pq_nms: class sort failed: %s", hipGetErrorString(e)); return PQ_ELAUNCH; }
+    }
     NmsMaskPlan mp{(unsigned*)(base + L.tp), (unsigned long long*)(base + L.wp), (unsigned long long*)(base + L.mask),
                    (unsigned long long)(L.mask_bytes / 8)};
     static const char* greedy_env = getenv("PQ_NMS_GREEDY");          // "1": always the chunk-walking kernel (A/B timing, tests)

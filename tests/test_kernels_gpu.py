@@ -1188,6 +1188,20 @@ def test_nms_greedy_fallback_kernel_is_still_bit_exact():
     assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
 
 
+def test_nms_library_sort_path_is_still_bit_exact():
+    """Up to a capacity of 8192 entries both sorts of pq_nms run in one workgroup (bitonic sort of 64-bit keys in LDS: tie-breakers inside the
+    keys); above that the rocPRIM radix sorts remain.  PQ_NMS_LIBSORT=1 forces the library at every size: the bit-exact
+    selection tests run again in ONE child interpreter with the variable set, and the large-candidate cases of
+    test_nms_selection_bit_exact / test_nms_invariants_at_the_largest_candidate_count cover it by size."""
+    import os, subprocess, sys
+    env = dict(os.environ, PQ_NMS_LIBSORT='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider', '-k',
+                        'nms_selection_bit_exact or nms_batch_is_bit_identical or nms_empty_and_ties or nms_candidate_compaction'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
+
+
 def test_nms_candidate_compaction_paths_agree():
     """Fast path (ordered compaction of the pairs above the threshold, sorts sized by cand_cap), its overflow signal and the
     all-pairs path give the same detections, including score ties."""
