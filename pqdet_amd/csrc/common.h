@@ -435,7 +435,10 @@ inline EwGeom ew_geom(long items, int C) {
     if (g.py < 1) g.py = 1;
     g.gy = (c4 + g.cx - 1) / g.cx;
     long want = (items + g.py - 1) / g.py;
-    long cap = 2048 / g.gy;
+    // at most ~512 workgroups (two per CU): fewer, fatter workgroups keep four rows per thread in flight and leave a quarter of the
+    // statistics rows for the BatchNorm finalize that follows (2048 / 1024 / 512 / 256: mobilenetv2-fpn step 10.40 / 10.32 / 10.27 /
+    // 10.30 ms, regnetx-600m-fpn 11.98 / 11.62 / 11.52 / 11.60)
+    long cap = 512 / g.gy;
     if (cap < 64) cap = 64;
     g.gx = (int)(want < cap ? want : cap);
     if (g.gx < 1) g.gx = 1;
