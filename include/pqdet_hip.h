@@ -301,6 +301,9 @@ typedef struct pq_gconv3x3_fwd_args {
     float* out;          /* raw, pitch ldo */
     float* partial;      /* [pq_gconv3x3_blocks(B, OH, OW)][2][ldp] or NULL */
     int32_t B, IH, IW, OH, OW, C, gw, stride, ldo, ldp;
+    int64_t* stat_acc;   /* statistics hand-over, as in pq_conv1x1_fwd_args; in.stat is honoured too */
+    uint32_t* stat_bad;
+    int32_t stat_slots;
 } pq_gconv3x3_fwd_args;
 int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream);
 /* partial-sum rows written by a launch over a (B, H, W) pixel grid: forward H,W = output plane; dgrad sink H,W = input plane */

@@ -75,7 +75,7 @@ class GemmPlan(C.Structure):
 class GconvFwd(C.Structure):
     _fields_ = [('inp', Src), ('w', c_fp), ('out', c_fp), ('partial', c_fp),
                 ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('gw', i32), ('stride', i32),
-                ('ldo', i32), ('ldp', i32)]
+                ('ldo', i32), ('ldp', i32), ('stat_acc', c_fp), ('stat_bad', c_fp), ('stat_slots', i32)]
 
 
 class GconvDgrad(C.Structure):

@@ -269,11 +269,13 @@ extern "C" int pq_run_ops2_timed(const pq_op* ops, int32_t n, void* stream, void
 // ---- BatchNorm statistics hand-over (pq_bn_stat)
 int conv1x1_fwd_stat_ok(const pq_conv1x1_fwd_args* a, int role);     // gemm.hip
 int dw_fwd_stat_ok(const pq_dw3x3_fwd_args* a, int role);           // dwtile.hip
+int gconv_fwd_stat_ok(const pq_gconv3x3_fwd_args* a, int role);     // gconv.hip
 extern "C" int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role) {
     if (!args || (role != 0 && role != 1)) return 0;
     switch (code) {
         case PQ_OP_CONV1X1_FWD: return conv1x1_fwd_stat_ok((const pq_conv1x1_fwd_args*)args, role);
         case PQ_OP_DW_FWD: return dw_fwd_stat_ok((const pq_dw3x3_fwd_args*)args, role);
+        case PQ_OP_GCONV_FWD: return gconv_fwd_stat_ok((const pq_gconv3x3_fwd_args*)args, role);
         case PQ_OP_COPY_FWD: {           // consumer only: shortcut / route / upsample read their operands through src_coef4
             const pq_copy_args* c = (const pq_copy_args*)args;
             return role == 1 && !c->a.qstate && !c->b.qstate && (c->C & 3) == 0;

@@ -27,6 +27,7 @@ struct GcP {
     float* out; float* partial; int ldo, ldp;
     pq_gsink sink;
     int B, AH, AW, OH, OW, C, gw, S, tilesH, tilesW;
+    int64_t* stat_acc; uint32_t* stat_bad; int stat_slots;      // forward: statistics into pq_bn_stat accumulators instead of rows
 };
 
 constexpr int GTH = 8, GTW = 16;          // output tile
@@ -37,16 +38,21 @@ __device__ __forceinline__ f32x16 gmfma(float a, float b, f32x16 c) { return __b
 // of four pixels are issued back to back at clamped (always valid) coordinates and masked afterwards -- a load inside an
 // `if` per element made the staging loop one memory latency per iteration, which dominated the stride-2 layers.
 constexpr int GUB = 4;
+// lcoef != NULL: the group's BatchNorm scale / shift ([2][32] floats in LDS) were derived from the producer's statistic
+// accumulators by the workgroup itself (pq_bn_stat hand-over: no finalize launch in front of this kernel)
 template <int ITW, int NPIX>
 __device__ __forceinline__ void gc_stage_src(float4* At, int pitch, int gq, int cbase, int b, int ay0, int ax0, int AH, int AW,
-                                             const pq_src& in, int t) {
+                                             const pq_src& in, int t, const float* lcoef = nullptr) {
     const int qd = t % gq, pl = t / gq, PL = 256 / gq;
     if (pl >= PL) return;
     const int c = cbase + 4 * qd;
     const ActParam aact = act_param(in.act);
     float sc[4], sh[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { sc[j] = in.scale ? in.scale[c + j] : 1.f; sh[j] = in.scale ? in.shift[c + j] : 0.f; }
+    for (int j = 0; j < 4; ++j) {
+        if (lcoef) { sc[j] = lcoef[4 * qd + j]; sh[j] = lcoef[32 + 4 * qd + j]; }
+        else { sc[j] = in.scale ? in.scale[c + j] : 1.f; sh[j] = in.scale ? in.shift[c + j] : 0.f; }
+    }
     const bool fq = in.qstate != nullptr;
     const float qs = fq ? in.qstate[2] : 1.f, qinv = fq ? 1.f / qs : 1.f, qzp = fq ? in.qstate[3] : 0.f;
     const float* base = in.x + (size_t)b * AH * AW * in.ld + c;
@@ -138,11 +144,23 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
     float4* At = reinterpret_cast<float4*>(smem);                       // [ITH*ITW][pitch]
     float* Bt = smem + (size_t)ITH * ITW * pitch * 4;                   // [32][KP]
     float* red = Bt + 32 * KP;                                          // [2][4][32]
+    float* lco = red + 2 * 4 * 32;                                      // [2][32]: scale, shift of the group (statistics hand-over)
 
     int tIdx, g;
     xcd_block(tIdx, g);
     const int cbase = g * gw;
     const int ntiles = p.B * p.tilesH * p.tilesW;
+    const bool from_stat = EMODE == 1 && !p.grad && p.in.stat.acc != nullptr;       // uniform
+    // one thread per channel quad derives the 4 coefficient pairs from the producer's accumulators: the loads are issued HERE, the
+    // arithmetic follows the weight staging below (the round trip hides behind it; every workgroup of the grid pays this
+    // prologue); the workgroup of logical tile 0 of every group also stores the vectors / running statistics
+    BnSums su[4];
+    unsigned sbad = 0;
+    if (from_stat && t < gq) {
+        sbad = *p.in.stat.bad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) su[i] = bn_stat_load(p.in.stat, min(cbase + 4 * t + i, p.C - 1));
+    }
     // ---- stage B (this group's weights, k = tap*gw + i): row n = t/8, eight lanes walk k; four loads in flight
     {
         const int n = t >> 3, kk = t & 7;
@@ -167,13 +185,24 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
         }
     }
     const int lrow = lane & 31, lh = lane >> 5;
+    if (from_stat) {
+        if (t < gq) {
+            const bool writer = tIdx == 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = cbase + 4 * t + i;
+                if (c < p.C) { const BnCoef bc = bn_stat_finish(p.in.stat, c, su[i], sbad != 0, writer); lco[4 * t + i] = bc.scale; lco[32 + 4 * t + i] = bc.shift; }
+            }
+        }
+        __syncthreads();               // the coefficient table
+    }
     do {                               // one pass unless PERSIST
     const int tw = tIdx % p.tilesW, th = (tIdx / p.tilesW) % p.tilesH, b = tIdx / (p.tilesW * p.tilesH);
     const int oy0 = th * GTH, ox0 = tw * GTW;
     const int ay0 = oy0 * S - 1, ax0 = ox0 * S - 1;
     if (PERSIST) __syncthreads();      // the previous tile's reads of At / red are done
     // ---- stage A (operand tile with halo)
-    if (!p.grad) gc_stage_src<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.in, t);
+    if (!p.grad) gc_stage_src<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.in, t, from_stat ? lco : nullptr);
     else gc_stage_gsrc<ITW, ITH * ITW>(At, pitch, gq, cbase, b, ay0, ax0, p.AH, p.AW, p.dy, p.up, p.DH, p.DW, t);
     __syncthreads();
 
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
     float s1 = 0.f, s2 = 0.f;
     bool want_stats = false;
     if (EMODE == 1) {
-        want_stats = p.partial != nullptr;
+        want_stats = p.partial != nullptr || p.stat_acc != nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -279,9 +308,14 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
             for (int q = 0; q < 4; ++q) { a += red[(0 * 4 + q) * 32 + t]; bsum += red[(1 * 4 + q) * 32 + t]; }
             float* part = (EMODE == 2) ? p.sink.partial : p.partial;
             const int ldp = (EMODE == 2) ? p.sink.ldp : p.ldp;
-            float* dst = part + (size_t)tIdx * 2 * ldp;
-            dst[cbase + t] = a;
-            dst[ldp + cbase + t] = bsum;
+            if (EMODE == 1 && p.stat_acc != nullptr) {       // no finalize launch: the first consumer derives the coefficients
+                bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, tIdx, 0, cbase + t, a);
+                bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, tIdx, 1, cbase + t, bsum);
+            } else {
+                float* dst = part + (size_t)tIdx * 2 * ldp;
+                dst[cbase + t] = a;
+                dst[ldp + cbase + t] = bsum;
+            }
         }
     }
     if (!PERSIST) break;
@@ -602,7 +636,7 @@ static int gc_check(int B, int IH, int IW, int OH, int OW, int C, int gw, int st
 }
 static size_t gc_lds_bytes(int gw, int S) {
     const int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3, pitch = gw / 4 + 1;
-    return ((size_t)ITH * ITW * pitch * 4 + 32 * (9 * gw + 4) + 2 * 4 * 32) * sizeof(float);
+    return ((size_t)ITH * ITW * pitch * 4 + 32 * (9 * gw + 4) + 2 * 4 * 32 + 2 * 32) * sizeof(float);
 }
 extern "C" int32_t pq_gconv3x3_blocks(int32_t B, int32_t H, int32_t W) { return B * ((H + GTH - 1) / GTH) * ((W + GTW - 1) / GTW); }
 
@@ -611,8 +645,11 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape (group width multiple of 4 and <= 32, stride 1|2, pad 1)");
     PQ_CHECK_ARG((a->in.ld & 3) == 0, "input pitch must be a multiple of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_gconv3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
+    PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->ldp >= a->C), "stat_acc needs stat_bad");
+    PQ_CHECK_ARG(a->in.stat.acc == nullptr || !a->in.qstate, "the statistics hand-over has no QAT path");
     GcP p{};
     p.in = a->in; p.grad = 0; p.up = 0; p.w = a->w; p.wmode = 0; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
+    p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
     p.B = a->B; p.AH = a->IH; p.AW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.gw = a->gw; p.S = a->stride;
     p.tilesH = (a->OH + GTH - 1) / GTH; p.tilesW = (a->OW + GTW - 1) / GTW;
     const size_t lds = gc_lds_bytes(a->gw, a->stride);
@@ -667,6 +704,12 @@ extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) 
     hipLaunchKernelGGL((gconv_kernel<2, 1>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
+}
+
+// pq_bn_stat_ok for PQ_OP_GCONV_FWD: both roles (statistics added per 8 x 16 tile; coefficients derived per group)
+int gconv_fwd_stat_ok(const pq_gconv3x3_fwd_args* a, int role) {
+    if (!a) return 0;
+    return role == 0 ? 1 : (a->in.qstate == nullptr);
 }
 
 static int gc_nsplit(int ntiles, int G) {

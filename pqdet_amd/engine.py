@@ -814,7 +814,7 @@ class Plan:
             if not f.train or f.planes == 4 or f.sf or f.nblk > maxblk or not f.partial:
                 continue
             prod, cons = self.fwd[k - 1], self.fwd[k + 1]
-            if prod.flags or cons.flags or prod.code not in (abi.OP_CONV1X1_FWD, abi.OP_DW_FWD):
+            if prod.flags or cons.flags or prod.code not in (abi.OP_CONV1X1_FWD, abi.OP_DW_FWD, abi.OP_GCONV_FWD):
                 continue
             pa = getattr(prod.u, abi.OP_FIELD[prod.code])
             if pa.partial != f.partial or not l.pq_bn_stat_ok(prod.code, C.byref(pa), 0):
@@ -823,6 +823,8 @@ class Plan:
                 srcs = [cons.u.c1f.inp]
             elif cons.code == abi.OP_DW_FWD:
                 srcs = [cons.u.dwf.inp]
+            elif cons.code == abi.OP_GCONV_FWD:
+                srcs = [cons.u.gcf.inp]
             elif cons.code == abi.OP_COPY_FWD:
                 srcs = [cons.u.cp.a, cons.u.cp.b]
             else:

@@ -184,6 +184,50 @@ def test_conv1x1_to_depthwise_to_conv1x1_handover(B, H, W, Cc, stride):
     K.close(yb, n2.detach().clamp(0, 6) @ wB.t(), rt=1e-3, at=2e-4, what='project conv')
 
 
+@pytest.mark.parametrize('B,H,W,Cc,gw,stride', [(2, 32, 32, 240, 24, 1), (2, 64, 64, 96, 24, 2), (3, 16, 16, 176, 16, 1)])
+def test_conv1x1_to_grouped3x3_to_conv1x1_handover(B, H, W, Cc, gw, stride):
+    """RegNetX block: 1x1 conv -> BN + ReLU -> grouped 3x3 (consumer AND producer of a hand-over) -> BN + ReLU -> 1x1 conv."""
+    l = abi.lib()
+    g = torch.Generator().manual_seed(B * H * W + Cc + gw)
+    I, O2 = 128, 64
+    M = B * H * W
+    x = K.rnd(M, I, g=g)
+    wA = K.rnd(Cc, I, g=g, scale=1 / math.sqrt(I))
+    wG = K.rnd(Cc, gw, 3, 3, g=g, scale=1 / math.sqrt(9 * gw))
+    wB = K.rnd(O2, Cc, g=g, scale=1 / math.sqrt(Cc))
+    xd, wAd, wGd, wBd = x.to(DEV), wA.to(DEV), wG.to(DEV), wB.to(DEV)
+    st1 = Stat(Cc, l.pq_conv1x1_blocks_k(M, Cc, I, 0), M, g)
+    ya = torch.zeros(M, Cc, device=DEV)
+    a = abi.Conv1x1Fwd(abi.Src(xd.data_ptr(), None, None, I, 0), wAd.data_ptr(), None, ya.data_ptr(), None, M, I, Cc, Cc, st1.ldp,
+                       1, 0, 0, 0, 0)
+    a.stat_acc, a.stat_bad, a.stat_slots = st1.acc.data_ptr(), st1.bad.data_ptr(), st1.slots
+    abi.check(l.pq_conv1x1_fwd(C.byref(a), K.stream()))
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    M2 = B * OH * OW
+    st2 = Stat(Cc, l.pq_gconv3x3_blocks(B, OH, OW), M2, g)
+    yg = torch.zeros(M2, Cc, device=DEV)
+    d = abi.GconvFwd(abi.Src(ya.data_ptr(), None, None, Cc, 1), wGd.data_ptr(), yg.data_ptr(), None, B, H, W, OH, OW, Cc, gw, stride,
+                     Cc, st2.ldp)
+    d.inp.stat = st1.struct()
+    d.stat_acc, d.stat_bad, d.stat_slots = st2.acc.data_ptr(), st2.bad.data_ptr(), st2.slots
+    assert l.pq_bn_stat_ok(abi.OP_GCONV_FWD, C.byref(d), 0) == 1 and l.pq_bn_stat_ok(abi.OP_GCONV_FWD, C.byref(d), 1) == 1
+    abi.check(l.pq_gconv3x3_fwd(C.byref(d), K.stream()))
+    yb = torch.zeros(M2, O2, device=DEV)
+    b = abi.Conv1x1Fwd(abi.Src(yg.data_ptr(), None, None, Cc, 1), wBd.data_ptr(), None, yb.data_ptr(), None, M2, Cc, O2, O2, 0,
+                       1, 0, 0, 0, 0)
+    b.inp.stat = st2.struct()
+    if not l.pq_bn_stat_ok(abi.OP_CONV1X1_FWD, C.byref(b), 1):
+        pytest.skip('second 1x1 conv shape is outside the ring kernels')
+    abi.check(l.pq_conv1x1_fwd(C.byref(b), K.stream()))
+    torch.cuda.synchronize()
+    n1 = st1.check_against(ya.cpu())
+    act1 = n1.detach().clamp(min=0).reshape(B, H, W, Cc).permute(0, 3, 1, 2)
+    yG = F.conv2d(act1, wG, stride=stride, padding=1, groups=Cc // gw).permute(0, 2, 3, 1).reshape(M2, Cc)
+    K.close(yg, yG, rt=1e-3, at=2e-4, what='grouped 3x3 on the handed-over BatchNorm')
+    n2 = st2.check_against(yg.cpu())
+    K.close(yb, n2.detach().clamp(min=0) @ wB.t(), rt=1e-3, at=2e-4, what='second 1x1 conv')
+
+
 def test_shortcut_handover_and_nan_poison():
     """project conv -> BN (linear) -> shortcut add (copy_fwd derives the coefficients); then a NaN in the producer's output
     must reach the statistics (the step's NaN trap depends on it)."""
