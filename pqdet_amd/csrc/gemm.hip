@@ -771,7 +771,9 @@ static int row_bm(int M, int N, int K, int kind) {
     if (force) return atoi(force) >= 128 ? 128 : 64;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
     if (kind == 0) return (t128 >= 400 || t12864 >= 400) ? 128 : 64;
-    return t128 >= 1024 ? 128 : 64;
+    // data gradient: 128-row tiles stage two tensors per row (126-150 KB of LDS: one workgroup per CU) -- only where 64-row tiles would
+    // mean more than ~16 rounds (threshold 512 / 1024 / 2048 / never: 10.35 / 10.20 / 10.12 / 10.13 ms per mobilenetv2-fpn step)
+    return t128 >= 2048 ? 128 : 64;
 }
 extern "C" int32_t pq_conv1x1_blocks_k(int32_t M, int32_t N, int32_t K, int32_t kind) {
     const int bm = row_bm(M, N, K, kind);
