@@ -62,6 +62,29 @@ typedef struct pq_bn_stat {
     float inv_count;         /* 1 / count */
 } pq_bn_stat;
 
+/* The same hand-over for the BACKWARD sums of a train-mode BatchNorm (S1 = sum dz, S2 = sum dz * xhat per channel): the kernel
+ * whose gradient sink finalises the tensor ADDS its per-row-block partials into `acc` (same exact fixed-point image, same slot
+ * rule as pq_bn_stat) instead of writing rows for pq_bn_bwd_finalize, and the ONE kernel that consumes the tensor's gradient
+ * operand derives  p = gamma*invstd,  q = -p*invstd*S2/count,  r = -p*S1/count  in its prologue (fp64 like the finalize
+ * kernel; the accumulated sums are exact, i.e. run-to-run deterministic); its first workgroup per channel chunk also stores
+ * dgamma = S2, dbeta = S1 (the parameter gradients) and the p / q / r vectors.  Producers: pq_conv1x1_dgrad, pq_conv1x1_bwd
+ * (dx_stat_*); consumer: pq_dw3x3_bwd parts 5 (dy_stat) -- the depthwise layers, whose gradient operand has exactly one reader.
+ * acc and *bad must be zero when the producer starts.  train == 0 (frozen statistics): q = r = 0. */
+typedef struct pq_bn_bstat {
+    int64_t* acc;            /* [slots][2][ldp][2]; NULL: unused (the gsrc's p / q / r vectors are read instead) */
+    uint32_t* bad;
+    const float* gamma;
+    const float* invstd;
+    float* dgamma;           /* out [C] */
+    float* dbeta;
+    float* p;                /* out [C] */
+    float* q;
+    float* r;
+    int32_t slots, ldp;
+    float count;             /* rows of the tensor */
+    int32_t train;
+} pq_bn_bstat;
+
 /* forward-value operand:  v[row][c] = act(scale[c] * x[row*ld + c] + shift[c]);  scale==NULL => identity affine;
  * with qstate the value is then fake-quantised (quint8 [0,255], per tensor): (clamp(rint(v/s)+zp) - zp) * s */
 typedef struct pq_src {
@@ -151,6 +174,11 @@ typedef struct pq_conv1x1_dgrad_args {
                                       sink must then be accumulate-only (finalize==0) -- untouched pixels keep their value */
     const float* wt;     /* optional transposed copy of w, [I][ceil4(O)] with zero pad columns (pq_transpose_batch writes that
                             layout): K-contiguous B operand, faster LDS path */
+    int64_t* dx_stat_acc;  /* != NULL: the sink's BatchNorm-backward sums are ADDED to this accumulator (pq_bn_bstat.acc, pitch
+                            * dx.ldp) instead of written as rows of dx.partial (not written then, but still non-NULL: it is what
+                            * marks a sink with statistics).  sub == 1 only */
+    uint32_t* dx_stat_bad;
+    int32_t dx_stat_slots;
 } pq_conv1x1_dgrad_args;
 int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream);
 
@@ -179,6 +207,9 @@ typedef struct pq_conv1x1_bwd_args {
     float* dw;           /* [O][I] */
     float* scratch;      /* >= pq_conv1x1_bwd_scratch_bytes(M,I,O) */
     int32_t M, I, O;
+    int64_t* dx_stat_acc;  /* as in pq_conv1x1_dgrad_args */
+    uint32_t* dx_stat_bad;
+    int32_t dx_stat_slots;
 } pq_conv1x1_bwd_args;
 int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream);
 int32_t pq_conv1x1_bwd_blocks(int32_t M, int32_t I, int32_t O);
@@ -260,6 +291,8 @@ typedef struct pq_dw3x3_bwd_args {
                                sink's statistics rows and the weight-gradient rows in `scratch` are one per workgroup
                                (pq_dw3x3_bwd_walk_blocks);
                             6: reduce the rows a part-5 launch left in `scratch` into dw */
+    pq_bn_bstat dy_stat; /* part 5, dy_stat.acc != NULL: the coefficients of dy are DERIVED from these sums (no pq_bn_bwd_finalize
+                            launch in front of this call; dy.p / dy.q / dy.r are ignored, dy.mu is still read) */
 } pq_dw3x3_bwd_args;
 int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream);
 int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t C, int32_t stride);
@@ -418,6 +451,9 @@ int64_t pq_bn_finalize_scratch_bytes(int32_t C);
  * has the atomic epilogue), role 1: as the first CONSUMER of its input operand (in.stat / a.stat derived in the prologue).
  * Pure host function. */
 int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role);
+/* the same question for the backward sums (pq_bn_bstat): role 0 = this call's sink can add into accumulators
+ * (PQ_OP_CONV1X1_DGRAD, PQ_OP_CONV1X1_BWD), role 1 = this call can derive its gradient operand's coefficients (PQ_OP_DW_BWD) */
+int32_t pq_bn_bstat_ok(int32_t code, const void* args, int32_t role);
 /* bytes of a pq_bn_stat.acc for C channels with pitch ldp and `slots` replicas, and the replica count to use for nblk row blocks */
 int64_t pq_bn_stat_bytes(int32_t ldp, int32_t slots);
 int32_t pq_bn_stat_slots(int32_t nblk);
@@ -495,7 +531,8 @@ typedef struct pq_yolo_loss_args {
     const float* boxes;  /* [B][M][4] zero padded */
     float* partial;      /* scratch: [B][nblk][3] floats, nblk = pq_yolo_loss_blocks(H,W,A) */
     float* losses;       /* out [4]: loss, box, conf, cls  (each already .mean over batch) */
-    int32_t* nan_flag;   /* out: set to 1 when loss is NaN (model/loss.py:110-114), may be NULL */
+    int32_t* nan_flag;   /* out: set to 1 when loss is NaN (model/loss.py:110-114), never cleared by the kernel; may be NULL.  May
+                          * point into pinned host memory (pq_host_device_pointer): the host then polls it without a copy */
     /* backward only */
     const float* gscale; /* [3] upstream weights for (box, conf, cls) */
     float* grad;         /* gradient w.r.t. `in` (same addressing as `in`) */
@@ -671,6 +708,10 @@ typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args
 #define PQ_OPF_JOIN 2   /* main-stream op that reads what side-stream ops wrote: `stream` waits for the side stream before it */
 #define PQ_OPF_LAZY 4   /* with PQ_OPF_SIDE: not urgent -- the op waits for the fork of the next side op (or the next join / the end of
                          * the call) instead of forcing a fork of its own (every fork costs the main queue ~5 us: small reductions) */
+#define PQ_OPF_NOFORK 8 /* with PQ_OPF_SIDE: everything the op reads was written by EARLIER SIDE ops of this call (or before the call):
+                         * it is queued behind them without a fork event, i.e. it does not wait for the main stream's position
+                         * (loss kernels of the side-stream detection heads: they start when their head conv is done, not when
+                         * the main stream reaches the end of the forward) */
 typedef struct pq_op {
     int32_t code;
     int32_t flags;
@@ -687,6 +728,9 @@ typedef struct pq_op {
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);
+/* device address of a PINNED host allocation (hipHostGetDevicePointer): lets a kernel write a flag the host polls without a
+ * device-to-host copy or an event on the stream (the NaN trap of the loss).  PQ_EUNSUPPORTED when the memory is not mapped. */
+int pq_host_device_pointer(void* host_ptr, void** device_ptr);
 /* two-stream replay: ops flagged PQ_OPF_SIDE are launched on `side_stream` after an event recorded on `stream` at their
  * position (they see everything launched before them); `stream` waits for the side stream at the end of the call.
  * Lets the weight-gradient GEMMs overlap the latency-bound data-gradient chain of the backward pass. */

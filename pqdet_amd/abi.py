@@ -27,6 +27,11 @@ class BnStat(C.Structure):
                 ('slots', i32), ('ldp', i32), ('count', f32), ('eps', f32), ('momentum', f32), ('inv_count', f32)]
 
 
+class BnBstat(C.Structure):
+    _fields_ = [('acc', c_fp), ('bad', c_fp), ('gamma', c_fp), ('invstd', c_fp), ('dgamma', c_fp), ('dbeta', c_fp),
+                ('p', c_fp), ('q', c_fp), ('r', c_fp), ('slots', i32), ('ldp', i32), ('count', f32), ('train', i32)]
+
+
 class Src(C.Structure):
     _fields_ = [('x', c_fp), ('scale', c_fp), ('shift', c_fp), ('ld', i32), ('act', i32), ('qstate', c_fp), ('stat', BnStat)]
 
@@ -50,7 +55,8 @@ class Conv1x1Fwd(C.Structure):
 
 class Conv1x1Dgrad(C.Structure):
     _fields_ = [('dy', GSrc), ('w', c_fp), ('dx', GSink), ('M', i32), ('I', i32), ('O', i32),
-                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('wt', c_fp)]
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('wt', c_fp),
+                ('dx_stat_acc', c_fp), ('dx_stat_bad', c_fp), ('dx_stat_slots', i32)]
 
 
 class Conv1x1Wgrad(C.Structure):
@@ -61,7 +67,7 @@ class Conv1x1Wgrad(C.Structure):
 
 class Conv1x1Bwd(C.Structure):
     _fields_ = [('dy', GSrc), ('w', c_fp), ('inp', Src), ('dx', GSink), ('dw', c_fp), ('scratch', c_fp),
-                ('M', i32), ('I', i32), ('O', i32)]
+                ('M', i32), ('I', i32), ('O', i32), ('dx_stat_acc', c_fp), ('dx_stat_bad', c_fp), ('dx_stat_slots', i32)]
 
 
 class GemmPlan(C.Structure):
@@ -106,7 +112,8 @@ class DwWgrad(C.Structure):
 
 class DwBwd(C.Structure):
     _fields_ = [('dy', GSrc), ('inp', Src), ('w', c_fp), ('dx', GSink), ('dw', c_fp), ('scratch', c_fp),
-                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('stride', i32), ('part', i32)]
+                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('C', i32), ('stride', i32), ('part', i32),
+                ('dy_stat', BnBstat)]
 
 
 class StemFwd(C.Structure):
@@ -259,6 +266,7 @@ class _OpU(C.Union):
 OPF_SIDE = 1
 OPF_JOIN = 2
 OPF_LAZY = 4
+OPF_NOFORK = 8
 
 
 class Op(C.Structure):
@@ -316,6 +324,7 @@ SIGNATURES = {
     'pq_bn_finalize_scratch_bytes': (i64, [i32]),
     'pq_bn_finalize_tickets': (i32, [i32]),
     'pq_bn_stat_ok': (i32, [i32, C.c_void_p, i32]),
+    'pq_bn_bstat_ok': (i32, [i32, C.c_void_p, i32]),
     'pq_bn_stat_bytes': (i64, [i32, i32]),
     'pq_bn_stat_slots': (i32, [i32]),
     'pq_copy_fwd': (C.c_int, [C.POINTER(Copy), C.c_void_p]),
@@ -347,6 +356,7 @@ SIGNATURES = {
     'pq_nms_scratch_bytes': (i64, [i32, i32]),
     'pq_nms_batch_scratch_bytes': (i64, [i32, i32, i32]),
     'pq_run_ops': (C.c_int, [C.POINTER(Op), i32, C.c_void_p]),
+    'pq_host_device_pointer': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'pq_run_ops2': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p]),
     'pq_run_ops2_nojoin': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p]),
     'pq_run_ops_timed': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.POINTER(C.c_float)]),

@@ -62,6 +62,18 @@ static int run_one(const pq_op& op, void* stream) {
     }
 }
 
+extern "C" int pq_host_device_pointer(void* host_ptr, void** device_ptr) {
+    if (!host_ptr || !device_ptr) { pq_set_error("pq_host_device_pointer: null pointer"); return PQ_EINVAL; }
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host_ptr, 0) != hipSuccess || !d) {
+        (void)hipGetLastError();
+        pq_set_error("pq_host_device_pointer: not a mapped pinned allocation");
+        return PQ_EUNSUPPORTED;
+    }
+    *device_ptr = d;
+    return PQ_OK;
+}
+
 extern "C" int pq_run_ops(const pq_op* ops, int32_t n, void* stream) {
     g_failed_op = -1;
     if (!ops || n < 0) { pq_set_error("pq_run_ops: bad arguments"); return PQ_EINVAL; }
@@ -107,7 +119,9 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
     hipEvent_t early_join = nullptr;     // join event already recorded behind the last side op (see flush)
     auto flush = [&]() -> int {          // one fork event, then every parked op in issue order
         if (nparked == 0) return PQ_OK;
-        if (main_dirty) {
+        bool need_fork = false;          // PQ_OPF_NOFORK ops are ordered by the side stream itself
+        for (int k = 0; k < nparked; ++k) need_fork |= !(ops[parked[k]].flags & PQ_OPF_NOFORK);
+        if (main_dirty && need_fork) {
             hipEvent_t e = bound;
             if (!e) { e = ev[next]; next = (next + 1) & 63; }
             if ((!bound && hipEventRecord(e, main_s) != hipSuccess) || hipStreamWaitEvent(side_s, e, 0) != hipSuccess) {
@@ -117,8 +131,13 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
         }
         bound = nullptr;
         const int last = parked[nparked - 1];
+        // the LAST side op of a joined call (the stem's weight gradient at the end of a backward): the main stream has nothing
+        // left to do but wait for it, so the lazy ops that rode along (small reductions of main-stream products) run THERE,
+        // beside it, instead of in front of it on the side stream (4 x 5 us ahead of the step's last kernel)
+        const bool tail = final_join && nparked > 1 && last == n - 1 && !(ops[last].flags & PQ_OPF_LAZY);
         for (int k = 0; k < nparked; ++k) {
-            const int rc = run_one(ops[parked[k]], side_stream);
+            const bool on_main = tail && (ops[parked[k]].flags & PQ_OPF_LAZY) && !(ops[parked[k]].flags & PQ_OPF_NOFORK);
+            const int rc = run_one(ops[parked[k]], on_main ? stream : side_stream);
             if (rc != PQ_OK) { g_failed_op = parked[k]; return rc; }
         }
         nparked = 0;
@@ -165,7 +184,7 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
         }
         if (ops[i].flags & PQ_OPF_JOIN) { const int rc = join(); if (rc != PQ_OK) return rc; }
         // the op after this one releases the parked group: offer the fork event to this op's kernel launch
-        const bool forks_next = bind && i + 1 < n && (ops[i + 1].flags & PQ_OPF_SIDE) && !(ops[i + 1].flags & PQ_OPF_LAZY) && nparked + 1 >= group;
+        const bool forks_next = bind && i + 1 < n && (ops[i + 1].flags & PQ_OPF_SIDE) && !(ops[i + 1].flags & (PQ_OPF_LAZY | PQ_OPF_NOFORK)) && nparked + 1 >= group;
         bound = nullptr;
         if (forks_next) g_stop_event = ev[next];
         const int rc = run_one(ops[i], stream);
@@ -239,7 +258,7 @@ extern "C" int pq_run_ops2_timed(const pq_op* ops, int32_t n, void* stream, void
         }
         if (side) {
             side_dirty = true;
-            if (main_dirty) {
+            if (main_dirty && !(ops[i].flags & PQ_OPF_NOFORK)) {
                 // one reusable fork event is enough here: hipStreamWaitEvent captures the record that precedes it
                 if (hipEventRecord(fork, main_s) != hipSuccess || hipStreamWaitEvent(side_s, fork, 0) != hipSuccess) {
                     pq_set_error("pq_run_ops2_timed: fork failed"); g_failed_op = i; return PQ_ELAUNCH;
@@ -283,6 +302,19 @@ extern "C" int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role) {
         default: return 0;
     }
 }
+// ---- the same for the backward sums (pq_bn_bstat): role 0 = the sink adds into the accumulators, 1 = the operand is derived
+int conv1x1_dgrad_bstat_ok(const pq_conv1x1_dgrad_args* a);       // gemm.hip
+int conv1x1_bwd_bstat_ok(const pq_conv1x1_bwd_args* a);           // pwbwd.hip
+int dw_bwd_bstat_ok(const pq_dw3x3_bwd_args* a);                  // dwwalk.hip
+extern "C" int32_t pq_bn_bstat_ok(int32_t code, const void* args, int32_t role) {
+    if (!args || (role != 0 && role != 1)) return 0;
+    switch (code) {
+        case PQ_OP_CONV1X1_DGRAD: return role == 0 && conv1x1_dgrad_bstat_ok((const pq_conv1x1_dgrad_args*)args);
+        case PQ_OP_CONV1X1_BWD: return role == 0 && conv1x1_bwd_bstat_ok((const pq_conv1x1_bwd_args*)args);
+        case PQ_OP_DW_BWD: return role == 1 && dw_bwd_bstat_ok((const pq_dw3x3_bwd_args*)args);
+        default: return 0;
+    }
+}
 extern "C" int64_t pq_bn_stat_bytes(int32_t ldp, int32_t slots) { return (int64_t)(slots > 0 ? slots : 1) * 2 * ldp * 2 * 8; }
 // replicas by the number of row blocks that add to one channel: ~64 same-address atomics in flight cost nothing, 512 cost 12 us
 // (scripts/probes/bnstat_probe.hip); never more than 4, because EVERY workgroup of the consumer reads slots x 2 x 16 bytes per
@@ -294,6 +326,7 @@ extern "C" int32_t pq_abi_sizeof(int32_t code) {
         case 0: return (int32_t)sizeof(pq_op);
         case 107: return (int32_t)sizeof(pq_bn_stat);
         case 108: return (int32_t)sizeof(pq_src);
+        case 109: return (int32_t)sizeof(pq_bn_bstat);
         case PQ_OP_CONV1X1_FWD: return (int32_t)sizeof(pq_conv1x1_fwd_args);
         case PQ_OP_CONV1X1_DGRAD: return (int32_t)sizeof(pq_conv1x1_dgrad_args);
         case PQ_OP_CONV1X1_WGRAD: return (int32_t)sizeof(pq_conv1x1_wgrad_args);

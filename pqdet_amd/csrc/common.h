@@ -64,25 +64,26 @@ __device__ __forceinline__ void bn_stat_add(int64_t* acc, uint32_t* bad, int slo
 // writer: also store the vectors and update the running statistics (exactly one thread of the grid per channel does that).
 struct BnCoef { float scale, shift, mean, inv; };
 struct BnSums { long long lo1, hi1, lo2, hi2; };
-__device__ __forceinline__ BnSums bn_stat_load(const pq_bn_stat& st, int c) {            // all loads of a channel, no use in between
-    if (st.slots == 1) {                                                                  // uniform
-        const longlong2 a = *reinterpret_cast<const longlong2*>(st.acc + ((size_t)0 * st.ldp + c) * 2);
-        const longlong2 b = *reinterpret_cast<const longlong2*>(st.acc + ((size_t)1 * st.ldp + c) * 2);
+__device__ __forceinline__ BnSums bn_acc_load(const int64_t* acc, int slots, int ldp, int c) {   // all loads of a channel, no use in between
+    if (slots == 1) {                                                                     // uniform
+        const longlong2 a = *reinterpret_cast<const longlong2*>(acc + ((size_t)0 * ldp + c) * 2);
+        const longlong2 b = *reinterpret_cast<const longlong2*>(acc + ((size_t)1 * ldp + c) * 2);
         return BnSums{a.x, a.y, b.x, b.y};
     }
     longlong2 a[4], b[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int ss = s < st.slots ? s : 0;                                              // slots <= 4 (pq_bn_stat_slots)
-        a[s] = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)ss * 2 + 0) * st.ldp + c) * 2);
-        b[s] = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)ss * 2 + 1) * st.ldp + c) * 2);
+        const int ss = s < slots ? s : 0;                                                 // slots <= 4 (pq_bn_stat_slots)
+        a[s] = *reinterpret_cast<const longlong2*>(acc + (((size_t)ss * 2 + 0) * ldp + c) * 2);
+        b[s] = *reinterpret_cast<const longlong2*>(acc + (((size_t)ss * 2 + 1) * ldp + c) * 2);
     }
     BnSums r{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-        if (s < st.slots) { r.lo1 += a[s].x; r.hi1 += a[s].y; r.lo2 += b[s].x; r.hi2 += b[s].y; }
+        if (s < slots) { r.lo1 += a[s].x; r.hi1 += a[s].y; r.lo2 += b[s].x; r.hi2 += b[s].y; }
     return r;
 }
+__device__ __forceinline__ BnSums bn_stat_load(const pq_bn_stat& st, int c) { return bn_acc_load(st.acc, st.slots, st.ldp, c); }
 __device__ __forceinline__ BnCoef bn_stat_finish(const pq_bn_stat& st, int c, const BnSums& u, bool bad, bool writer) {
     double t1 = (double)u.hi1 + (double)u.lo1 * 0x1p-50, t2 = (double)u.hi2 + (double)u.lo2 * 0x1p-50;
     if (bad) t1 = t2 = __builtin_nan("");
@@ -237,6 +238,26 @@ __device__ __forceinline__ GsrcCoef4 gsrc_coef4(const pq_gsrc& s, int c0, int C)
         k.mu[j] = ok ? s.mu[c] : 0.f;
         k.r[j] = ok ? s.r[c] : 0.f;
     }
+    return k;
+}
+// A gradient operand whose BatchNorm-backward sums were handed over by the sink kernel (pq_bn_bstat): p, q, r, mu of ONE channel
+// are derived by the calling thread (arithmetic of bn_bwd_finalize_kernel on the exactly accumulated sums; a multiplication by
+// 1 / count instead of its fp64 division); writer: this thread is the one of the whole grid that stores dgamma / dbeta and the
+// channel's entries of the vectors.  c must be < C.
+struct GsrcCoef1 { float p, q, mu, r; };
+__device__ __forceinline__ GsrcCoef1 gsrc_coef1_bstat(const pq_gsrc& s, const pq_bn_bstat& st, int c, bool writer) {
+    const unsigned bad = *st.bad;
+    const BnSums u = bn_acc_load(st.acc, st.slots, st.ldp, c);
+    const float ga = st.gamma[c], iv = st.invstd[c];
+    GsrcCoef1 k;
+    k.mu = s.mu[c];
+    double t1 = (double)u.hi1 + (double)u.lo1 * 0x1p-50, t2 = (double)u.hi2 + (double)u.lo2 * 0x1p-50;
+    if (bad) t1 = t2 = __builtin_nan("");
+    const double invn = 1.0 / (double)st.count;
+    k.p = ga * iv;
+    k.q = st.train ? (float)(-(double)k.p * (double)iv * t2 * invn) : 0.f;
+    k.r = st.train ? (float)(-(double)k.p * t1 * invn) : 0.f;
+    if (writer) { st.dbeta[c] = (float)t1; st.dgamma[c] = (float)t2; st.p[c] = k.p; st.q[c] = k.q; st.r[c] = k.r; }
     return k;
 }
 __device__ __forceinline__ float4 gsrc_apply4(float4 g, float4 y, const GsrcCoef4& k) {

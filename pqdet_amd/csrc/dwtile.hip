@@ -852,6 +852,11 @@ extern "C" int32_t pq_dw3x3_bwd_walk_blocks(int32_t B, int32_t IH, int32_t IW, i
 
 extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->part >= 0 && a->part <= 6, "null pointer / bad part");
+    if (a->dy_stat.acc) {     // BatchNorm-backward sums handed over by the sink kernel: only the walking kernel derives from them
+        PQ_CHECK_ARG(a->part == 5 && a->dy.y && a->dy.mu, "dy_stat: part 5 with a two-tensor gradient operand only");
+        PQ_CHECK_ARG(a->dy_stat.bad && a->dy_stat.gamma && a->dy_stat.invstd && a->dy_stat.dgamma && a->dy_stat.dbeta && a->dy_stat.p &&
+                     a->dy_stat.q && a->dy_stat.r && a->dy_stat.count > 0.f && a->dy_stat.ldp >= a->C && a->dy_stat.slots <= 4, "dy_stat: incomplete");
+    }
     if (a->part >= 5) {       // the walking kernel (dwwalk.hip): 5 = both gradients, rows left in scratch; 6 = their reduction
         PQ_CHECK_ARG(dwt_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1)");
         PQ_CHECK_ARG(a->scratch && (a->part == 5 || a->dw), "part 5 / 6 need scratch (6: and dw)");

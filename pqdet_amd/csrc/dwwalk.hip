@@ -30,6 +30,7 @@ struct WalkGeom2 {                                    // stride 2: a step = 8 in
 
 struct DwWP {
     pq_src in; pq_gsrc dy; const float* w; pq_gsink sink; float* wpartial;
+    pq_bn_bstat dys;                                   // dy's BatchNorm-backward sums (hand-over: no finalize launch in front)
     int B, IH, IW, OH, OW, C, C4;
     int strips, segs, seg_rows;
 };
@@ -65,13 +66,23 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s2_kernel(DwWP p) {
     const int cc = cok ? c0 : 0;
     const SrcCoef4 xk = src_coef4(p.in, cc, p.C);
     const bool two = p.dy.y != nullptr;
+    const bool dy_stat = p.dys.acc != nullptr;         // uniform: dy's coefficients from the sink kernel's accumulators (no finalize launch)
+    if (dy_stat && t < 4 * WKQ) {                      // one thread per channel of the chunk: one memory round trip, one fp64 chain
+        const int c = cq0 * 4 + t;
+        GsrcCoef1 k1{1.f, 0.f, 0.f, 0.f};
+        if (c < p.C) k1 = gsrc_coef1_bstat(p.dy, p.dys, c, tIdx == 0);
+        float* ct = reinterpret_cast<float*>(&ctab[t >> 2][0]) + (t & 3);
+        ct[0] = k1.p; ct[4] = k1.q; ct[8] = k1.mu; ct[12] = k1.r;
+    }
     if (pl == 0) {
-        const GsrcCoef4 g0 = gsrc_coef4(p.dy, cc, p.C);
         const SinkCoef4 k0 = sink_coef4(p.sink, cc, p.C);
-        ctab[q][0] = make_float4(g0.p[0], g0.p[1], g0.p[2], g0.p[3]);
-        ctab[q][1] = make_float4(g0.q[0], g0.q[1], g0.q[2], g0.q[3]);
-        ctab[q][2] = make_float4(g0.mu[0], g0.mu[1], g0.mu[2], g0.mu[3]);
-        ctab[q][3] = make_float4(g0.r[0], g0.r[1], g0.r[2], g0.r[3]);
+        if (!dy_stat) {
+            const GsrcCoef4 g0 = gsrc_coef4(p.dy, cc, p.C);
+            ctab[q][0] = make_float4(g0.p[0], g0.p[1], g0.p[2], g0.p[3]);
+            ctab[q][1] = make_float4(g0.q[0], g0.q[1], g0.q[2], g0.q[3]);
+            ctab[q][2] = make_float4(g0.mu[0], g0.mu[1], g0.mu[2], g0.mu[3]);
+            ctab[q][3] = make_float4(g0.r[0], g0.r[1], g0.r[2], g0.r[3]);
+        }
         ctab[q][4] = make_float4(k0.mean[0], k0.mean[1], k0.mean[2], k0.mean[3]);
         ctab[q][5] = make_float4(k0.inv[0], k0.inv[1], k0.inv[2], k0.inv[3]);
 #pragma unroll
@@ -328,13 +339,23 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s1_kernel(DwWP p) {
     const int cc = cok ? c0 : 0;
     const SrcCoef4 xk = src_coef4(p.in, cc, p.C);
     const bool two = p.dy.y != nullptr;
+    const bool dy_stat = p.dys.acc != nullptr;         // uniform: dy's coefficients from the sink kernel's accumulators (no finalize launch)
+    if (dy_stat && t < 4 * WKQ) {                      // one thread per channel of the chunk: one memory round trip, one fp64 chain
+        const int c = cq0 * 4 + t;
+        GsrcCoef1 k1{1.f, 0.f, 0.f, 0.f};
+        if (c < p.C) k1 = gsrc_coef1_bstat(p.dy, p.dys, c, tIdx == 0);
+        float* ct = reinterpret_cast<float*>(&ctab[t >> 2][0]) + (t & 3);
+        ct[0] = k1.p; ct[4] = k1.q; ct[8] = k1.mu; ct[12] = k1.r;
+    }
     if (pl == 0) {
-        const GsrcCoef4 g0 = gsrc_coef4(p.dy, cc, p.C);
         const SinkCoef4 k0 = sink_coef4(p.sink, cc, p.C);
-        ctab[q][0] = make_float4(g0.p[0], g0.p[1], g0.p[2], g0.p[3]);
-        ctab[q][1] = make_float4(g0.q[0], g0.q[1], g0.q[2], g0.q[3]);
-        ctab[q][2] = make_float4(g0.mu[0], g0.mu[1], g0.mu[2], g0.mu[3]);
-        ctab[q][3] = make_float4(g0.r[0], g0.r[1], g0.r[2], g0.r[3]);
+        if (!dy_stat) {
+            const GsrcCoef4 g0 = gsrc_coef4(p.dy, cc, p.C);
+            ctab[q][0] = make_float4(g0.p[0], g0.p[1], g0.p[2], g0.p[3]);
+            ctab[q][1] = make_float4(g0.q[0], g0.q[1], g0.q[2], g0.q[3]);
+            ctab[q][2] = make_float4(g0.mu[0], g0.mu[1], g0.mu[2], g0.mu[3]);
+            ctab[q][3] = make_float4(g0.r[0], g0.r[1], g0.r[2], g0.r[3]);
+        }
         ctab[q][4] = make_float4(k0.mean[0], k0.mean[1], k0.mean[2], k0.mean[3]);
         ctab[q][5] = make_float4(k0.inv[0], k0.inv[1], k0.inv[2], k0.inv[3]);
 #pragma unroll
@@ -760,6 +781,8 @@ int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream) {
     }
     DwWP p{};
     p.in = a->in; p.dy = a->dy; p.w = a->w; p.sink = a->dx; p.wpartial = a->scratch;
+    p.dys = a->dy_stat;
+    if (p.dys.slots < 1) p.dys.slots = 1;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
     p.strips = w.strips; p.segs = w.segs; p.seg_rows = w.seg_rows;
     dim3 grid(w.nblk, w.chunks), blk(256);
@@ -767,6 +790,9 @@ int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream) {
     else PQ_LAUNCH_BINDABLE(dw_bwd_walk_s2_kernel, grid, blk, 0, st, p);
     return PQ_OK;
 }
+
+// pq_bn_bstat_ok for PQ_OP_DW_BWD (consumer role): the walking kernels derive dy's coefficients per channel quad
+int dw_bwd_bstat_ok(const pq_dw3x3_bwd_args* a) { return a->part == 5 && a->dy.y != nullptr && a->dy.mu != nullptr; }
 
 // forward, stride 1 (pq_dw3x3_fwd in dwtile.hip checks the arguments and decides)
 int dw_fwd_walk_blocks(int B, int H, int W, int C) { return walk_plan(B, H, W, C, 1).nblk; }

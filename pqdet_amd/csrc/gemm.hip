@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
             for (int q = 0; q < BM / WM; ++q) { a += red[(0 * 4 + q) * 192 + t]; b += red[(1 * 4 + q) * 192 + t]; }
             const int n = n0 + t;
-            if (n < N && EMODE == 1 && p.stat_acc != nullptr) {   // no finalize launch: the first consumer derives the coefficients
+            if (n < N && (EMODE == 1 || EMODE == 2) && p.stat_acc != nullptr) {   // no finalize launch: the consumer derives the coefficients
                 bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 0, n, a);
                 bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 1, n, b);
             } else if (n < N) {
@@ -897,6 +897,11 @@ static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_g
     p.sub = a->sub > 1 ? a->sub : 1; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->I; p.K = a->O;
     p.sink = a->dx;
+    if (a->dx_stat_acc) {     // the sink's BatchNorm-backward sums go to accumulators (pq_bn_bstat), not to rows
+        PQ_CHECK_ARG(a->dx_stat_bad && a->sub <= 1 && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx_stat_slots <= 4,
+                     "dx_stat_acc needs dx_stat_bad, sub == 1 and a finalising sink with statistics");
+        p.stat_acc = a->dx_stat_acc; p.stat_bad = a->dx_stat_bad; p.stat_slots = a->dx_stat_slots > 0 ? a->dx_stat_slots : 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int bm = row_bm(a->M, a->I, a->O, 1);
     {
@@ -918,6 +923,11 @@ extern "C" int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream) { 
 extern "C" int pq_conv1x1_dgrad_plan(const pq_conv1x1_dgrad_args* a, pq_gemm_plan* out) {
     PQ_CHECK_ARG(out, "null pointer");
     return conv1x1_dgrad_impl(a, nullptr, out);
+}
+
+// pq_bn_bstat_ok for PQ_OP_CONV1X1_DGRAD (producer role): every kernel this entry dispatches to has the atomic sink epilogue
+int conv1x1_dgrad_bstat_ok(const pq_conv1x1_dgrad_args* a) {
+    return a->sub <= 1 && a->dx.finalize && a->dx.mean != nullptr && a->dx.partial != nullptr && !a->dx.qstate;
 }
 
 static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, int& rows) {

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
             const float b = red[(1 * 2 + 0) * BN + t] + red[(1 * 2 + 1) * BN + t];
             const int n = n0 + t;
             if (n < N) {
-                if (EMODE == 1 && p.stat_acc != nullptr) {       // no finalize launch: the first consumer derives the coefficients
+                if ((EMODE == 1 || EMODE == 2) && p.stat_acc != nullptr) {       // no finalize launch: the consumer derives the coefficients
                     bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 0, n, a);
                     bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 1, n, b);
                 } else {
@@ -638,6 +638,7 @@ int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st, pq_
     p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
     p.b = a->wt; p.ldb = a->O; p.M = a->M; p.N = a->I; p.K = a->O;      // O % 16 == 0: the transposed rows have no pad
     p.sink = a->dx;
+    p.stat_acc = a->dx_stat_acc; p.stat_bad = a->dx_stat_bad; p.stat_slots = a->dx_stat_slots > 0 ? a->dx_stat_slots : 1;   // (checked by the caller)
     const int rc = a->dy.y ? g2_dispatch_nt<2, 2>(p, bm, st, plan) : g2_dispatch_nt<0, 2>(p, bm, st, plan);
     return rc == PQ_OK ? 1 : rc;
 }
@@ -654,6 +655,8 @@ static G2WPlan g2_wgrad_plan(int M, int I, int O) {
     // one workgroup per CU (144 KiB of LDS): tiles x splits <= 256 in ONE round, and every workgroup must get a contraction
     // of at least 256 rows (8 k-tiles) or the fixed costs (ring fill, row-group reduction, slab) dominate: shorter ones stay
     // on gemm_tn
+    // (re-measured in round 3 with the main chain as the limiter: 128 workgroups, half the CUs, 10.08-10.11 ms against 10.09-10.11;
+    // 96 / 64: 10.2-10.26 / 10.41-10.46)
     const int target = 256;
     int splits = target / pl.tiles;
     const int maxs = M / 256;

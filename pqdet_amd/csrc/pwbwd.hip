@@ -20,6 +20,7 @@ struct PwP {
     pq_gsrc dy; pq_src x; pq_gsink dx;
     const float* w;      // [O][I]
     float* slab;         // [gridDim.x][O*I]
+    int64_t* stat_acc; uint32_t* stat_bad; int stat_slots;      // the sink's BatchNorm-backward sums into pq_bn_bstat accumulators
     int M, I, O, LDZ, LDX, tiles;
 };
 
@@ -286,9 +287,17 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += o[j];
             }
-            float* pr = p.dx.partial + (size_t)blockIdx.x * 2 * p.dx.ldp;
+            if (p.stat_acc != nullptr) {          // no finalize launch: the consumer of the tensor's gradient derives the coefficients
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { pr[4 * t + j] = acc[j]; pr[p.dx.ldp + 4 * t + j] = acc[4 + j]; }
+                for (int j = 0; j < 4; ++j) {
+                    bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, p.dx.ldp, blockIdx.x, 0, 4 * t + j, acc[j]);
+                    bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, p.dx.ldp, blockIdx.x, 1, 4 * t + j, acc[4 + j]);
+                }
+            } else {
+                float* pr = p.dx.partial + (size_t)blockIdx.x * 2 * p.dx.ldp;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pr[4 * t + j] = acc[j]; pr[p.dx.ldp + 4 * t + j] = acc[4 + j]; }
+            }
         }
     }
 }
@@ -414,6 +423,11 @@ extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
     PwP p{};
     p.dy = a->dy; p.x = a->in; p.dx = a->dx; p.w = a->w; p.slab = a->scratch;
     p.M = a->M; p.I = a->I; p.O = a->O; p.LDZ = pl.ldz; p.LDX = pl.ldx; p.tiles = pl.tiles;
+    if (a->dx_stat_acc) {
+        PQ_CHECK_ARG(a->dx_stat_bad && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx_stat_slots <= 4,
+                     "dx_stat_acc needs dx_stat_bad and a finalising sink with statistics");
+        p.stat_acc = a->dx_stat_acc; p.stat_bad = a->dx_stat_bad; p.stat_slots = a->dx_stat_slots > 0 ? a->dx_stat_slots : 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int i16 = (a->I + 15) / 16;
     int rc;
@@ -426,4 +440,9 @@ extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
     hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, n, pl.grid, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
+}
+
+// pq_bn_bstat_ok for PQ_OP_CONV1X1_BWD (producer role)
+int conv1x1_bwd_bstat_ok(const pq_conv1x1_bwd_args* a) {
+    return a->dx.finalize && a->dx.mean != nullptr && a->dx.partial != nullptr && !a->dx.qstate && (a->I & 3) == 0;
 }

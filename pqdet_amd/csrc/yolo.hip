@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void yolo_loss_finalize_kernel(const float* pa
         }
         const float total = term[0] + term[1] + term[2];
         losses[0] = total; losses[1] = term[0]; losses[2] = term[1]; losses[3] = term[2];
-        if (nan_flag) *nan_flag = (total != total) ? 1 : 0;
+        if (nan_flag && total != total) *nan_flag = 1;      // sticky: only ever SET here (the host clears it when it raises)
         if (totals) {            // the other heads' rows were written by earlier launches (stream order / PQ_OPF_JOIN)
             const float* table = losses - 4 * head_slot;
             float col[4] = {0.f, 0.f, 0.f, 0.f};

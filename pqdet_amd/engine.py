@@ -701,8 +701,24 @@ class Plan:
             # what the backward loss ops read outside a real backward (profiling replays of bwd_arr): d(total loss) = 1
             self._one = self._new(1, fill=1.0)
             self.default_upstream = [self._one] + [None] * (3 + nh)
+            # NaN trap (reference model/loss.py:110-114): one sticky flag per head.  In pinned host memory when the runtime maps
+            # it into the device's address space (the loss finalize kernels then set the flag the host polls: no device-to-host
+            # copy and no event on the stream between forward and backward); a device tensor the model copies back otherwise.
+            self.nan_host, nan_ptr = None, None
+            if os.environ.get('PQ_NAN_MAPPED', '1') != '0':
+                host = torch.zeros(nh, dtype=torch.int32).pin_memory()
+                dp = C.c_void_p()
+                if l.pq_host_device_pointer(C.c_void_p(host.data_ptr()), C.byref(dp)) == 0 and dp.value:
+                    self.nan_host, nan_ptr = host, dp.value
             self.nan_dev = torch.zeros(nh, device=self.device, dtype=torch.int32)
             self.keep.append(self.nan_dev)
+            if nan_ptr is None:
+                nan_ptr = self.nan_dev.data_ptr()
+            # reserved for the weight transposes of the backward (see _emit_backward: a side-stream op in front of the loss ops)
+            dummy = self._new(4)
+            self._fwd_tr_slot = self._op(self.fwd, abi.OP_FILL, abi.Fill(dummy.data_ptr(), 0.0, 0))
+            # ... and for clearing the accumulators of the backward statistics hand-over (_handover_bn_bwd)
+            self._fwd_bfill_slot = self._op(self.fwd, abi.OP_FILL, abi.Fill(dummy.data_ptr(), 0.0, 0))
             for slot, (i, m, a) in enumerate(heads):
                 opt = m.opt
                 A = a.C // (5 + opt['classes'])
@@ -712,7 +728,7 @@ class Plan:
                 if a.grad is None:
                     a.grad = self._new(a.rows, a.ld, fill=0.0)
                 la = abi.YoloLoss(view, None, None, ptr(partial), self.loss_buf[slot].data_ptr(),
-                                  self.nan_dev[slot:slot + 1].data_ptr(), None, ptr(a.grad),
+                                  nan_ptr + 4 * slot, None, ptr(a.grad),
                                   a.H * a.W * a.ld, a.W * a.ld, a.ld, 1,
                                   B, a.H, a.W, A, opt['classes'], 1, opt['stride'], abi.BOX_KIND[opt['bbox_loss']], 1,
                                   float(opt['ignore_thresh']), float(opt['l1_loss_gain']))
@@ -873,6 +889,13 @@ class Plan:
                 if r and r in side_written and not side:
                     raise RuntimeError('internal: forward op %d on the main stream reads a tensor written by side-stream op %d'
                                        % (k, side_written[r]))
+            if side and op.code == abi.OP_LOSS_FWD and reads and all(r in side_written for r in reads):
+                # the loss kernels of a side-stream head read their head conv (side stream), the labels and their own rows: no
+                # fork event -- they start when the head conv is done, not when the main stream reaches the end of the forward
+                op.flags |= abi.OPF_NOFORK
+            if op.flags & abi.OPF_NOFORK and op.code not in (abi.OP_TRANSPOSE, abi.OP_FILL) \
+                    and not (side and reads and all(r in side_written for r in reads)):
+                raise RuntimeError('internal: forward op %d is flagged NOFORK but reads a tensor the side stream did not write' % k)
             if side:
                 out = getattr(a, 'out', None)
                 if out:
@@ -930,6 +953,8 @@ class Plan:
         # slot 0: one batched transpose of the 1x1 weights whose data gradient is needed (filled in after the loop)
         tr_idx = self._op(self.bwd, abi.OP_TRANSPOSE, abi.Transpose(None, 0, 0))
         tr_items = []
+        # slot 1: clears the accumulators of the backward statistics hand-over when the forward cannot do it (_handover_bn_bwd)
+        self._bwd_bfill_slot = self._op(self.bwd, abi.OP_FILL, abi.Fill(self._new(4).data_ptr(), 0.0, 0))
 
         def transposed(conv, wsrc):
             """Device address of the [I][O] copy of a 1x1 weight, refreshed at the start of every backward."""
@@ -1153,7 +1178,23 @@ class Plan:
             dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
             self.keep.append(dev_table)
             self.bwd[tr_idx].u.tr = abi.Transpose(dev_table.data_ptr(), len(tr_items), tr_items[-1][4] + tr_items[-1][6])
-        else:                                   # nothing to transpose: turn slot 0 into a no-op
+        # Two-stream forward, plain weights: the transposed copies only depend on the parameters, so the launch moves off the
+        # critical chain (it was the first kernel of every backward, ~15 us with nothing beside it) into the forward
+        # list (slot in front of the loss ops) as a side-stream op without a fork: it runs behind the head branches while the
+        # main stream finishes the neck, and the join in front of the last head's finalize covers it.
+        # (QAT transposes the fake-quantised weights of the step, which are main-stream products: stays in the backward.)
+        # NOFORK is only safe behind a side op of THIS forward that did fork (the head-branch layers): the side stream is then
+        # past the previous step's optimiser update / backward, which a fork-less op at its head would not be.
+        self.fwd_side_slots_ok = getattr(self, 'fwd_two_streams', False) and bool(getattr(self, 'fwd_side_layers', []))
+        self.tr_in_forward = bool(tr_items) and self.fwd_side_slots_ok and not self.qat \
+            and os.environ.get('PQ_TR_FWD', '1') != '0'
+        if self.tr_in_forward:
+            op = abi.Op()
+            op.code = abi.OP_TRANSPOSE
+            op.u.tr = self.bwd[tr_idx].u.tr
+            op.flags = abi.OPF_SIDE | abi.OPF_NOFORK
+            self.fwd[self._fwd_tr_slot] = op
+        if not tr_items or self.tr_in_forward:      # nothing (left) to transpose here: turn slot 0 into a no-op
             dummy = self._new(4)
             nop = abi.Op()
             nop.code = abi.OP_FILL
@@ -1164,6 +1205,74 @@ class Plan:
             buf = self._new(max(need, 64) // 4 + 16)
             getattr(self.bwd[idx].u, field).scratch = buf.data_ptr()
             self.bwd[idx].flags = abi.OPF_SIDE
+        self._handover_bn_bwd()
+
+    def _handover_bn_bwd(self):
+        """Backward twin of _handover_bn_stats for the depthwise layers: drop the pq_bn_bwd_finalize launch between the kernel whose
+        sink finalises a depthwise conv's output gradient (the 1x1 projection's data gradient, plain or fused with its weight
+        gradient) and the walking depthwise backward, the ONE reader of that gradient operand.  The sink adds its BatchNorm-backward
+        sums into exact fixed-point accumulators (pq_bn_bstat), the walking kernel derives p / q / r in its prologue and its first
+        workgroup per channel chunk stores dgamma / dbeta.  These finalizes carry no fork (the depthwise weight gradient is part of
+        the same kernel), but they sit on the critical chain right where the previous layer's weight-gradient GEMM owns the CUs:
+        5-20 us each in the step's kernel trace.  The accumulators are cleared by a side-stream op at the end of the forward
+        (two-stream forward), else by the first op of the backward."""
+        self.bn_bwd_handover = 0
+        self.bn_bwd_handover_producers = set()          # op codes of the kernels that add (tests)
+        if not self.bn_train or self.qat or os.environ.get('PQ_BN_BWD_ATOMIC', '1') == '0':
+            return
+        l = lib()
+        maxblk = 640         # as in the forward; with every depthwise layer handed over (1024-row lists): 10.09-10.11 ms against 10.06-10.11
+        picks, total = [], 0
+        for k in range(1, len(self.bwd) - 1):
+            op = self.bwd[k]
+            if op.code != abi.OP_BN_BWD_FIN or op.flags:
+                continue
+            f = op.u.bnb
+            cons = self.bwd[k + 1]
+            if not f.train or f.nblk > maxblk or cons.code != abi.OP_DW_BWD or cons.flags:
+                continue
+            ca = cons.u.dwb
+            if ca.part != 5 or ca.dy.p != f.p or ca.dy_stat.acc or not l.pq_bn_bstat_ok(cons.code, C.byref(ca), 1):
+                continue
+            i = k - 1
+            while i >= 0 and (self.bwd[i].flags & abi.OPF_SIDE):
+                i -= 1
+            if i < 0 or self.bwd[i].flags or self.bwd[i].code not in (abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_BWD):
+                continue
+            pa = getattr(self.bwd[i].u, abi.OP_FIELD[self.bwd[i].code])
+            if pa.dx.partial != f.partial or not pa.dx.finalize or pa.dx.ldp != f.ldp or pa.dx_stat_acc \
+                    or not l.pq_bn_bstat_ok(self.bwd[i].code, C.byref(pa), 0):
+                continue
+            slots = l.pq_bn_stat_slots(f.nblk)
+            nbytes = _round_up(l.pq_bn_stat_bytes(f.ldp, slots), 64)
+            picks.append((k, pa, ca, f, slots, total, total + nbytes))
+            total += nbytes + 64
+            self.bn_bwd_handover_producers.add(self.bwd[i].code)
+        if not picks:
+            return
+        arena = torch.zeros(total // 8, device=self.device, dtype=torch.int64)
+        self.keep.append(arena)
+        base = arena.data_ptr()
+        for k, pa, ca, f, slots, off_acc, off_bad in picks:
+            pa.dx_stat_acc, pa.dx_stat_bad, pa.dx_stat_slots = base + off_acc, base + off_bad, slots
+            ca.dy_stat = abi.BnBstat(base + off_acc, base + off_bad, f.gamma, f.invstd, f.dgamma, f.dbeta, f.p, f.q, f.r,
+                                     slots, f.ldp, f.count, 1)
+            nop = abi.Op()
+            nop.code = abi.OP_FILL
+            nop.u.fill = abi.Fill(base, 0.0, 0)
+            self.bwd[k] = nop
+        fill = abi.Fill(base, 0.0, total // 4)
+        if self.fwd_side_slots_ok:
+            # behind the head branches on the forward's side stream (ordered after this forward's first fork, i.e. after the
+            # previous backward; covered by the join in front of the last head's finalize): nothing on the critical chain
+            op = abi.Op()
+            op.code = abi.OP_FILL
+            op.u.fill = fill
+            op.flags = abi.OPF_SIDE | abi.OPF_NOFORK
+            self.fwd[self._fwd_bfill_slot] = op
+        else:
+            self.bwd[self._bwd_bfill_slot].u.fill = fill
+        self.bn_bwd_handover = len(picks)
 
     # ------------------------------------------------------------------------------------------ run
     def _patch(self, x, target):
@@ -1185,6 +1294,10 @@ class Plan:
                     la.label = target[li].data_ptr()
                     la.boxes = target[bi].data_ptr()
                     la.M = target[bi].shape[1]
+
+    def set_totals(self, t):
+        """Where the last head's loss finalize writes the step's totals (4 + n_heads floats)."""
+        self.fwd_arr[self._last_loss_fin].u.loss.totals = t.data_ptr()
 
     def patch_upstream(self, grads):
         """Upstream gradient scalars of the step's 4 + n_heads outputs (device tensors of one float each, or None) -> the

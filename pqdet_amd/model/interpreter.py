@@ -43,11 +43,15 @@ class _StepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, plan, x, target):
+        # the last head's finalize writes the totals straight into this step's own tensor (a clone of a plan buffer was one
+        # more copy kernel on the chain between forward and backward)
+        res = torch.empty_like(plan.loss_total)
+        plan.set_totals(res)
         plan.run_forward(x, target)
+        plan.set_totals(plan.loss_total)        # launches carry their arguments: leave no pointer to `res` behind
         ctx.model, ctx.plan = model, plan
         ctx.x, ctx.target = x, target           # keep the batch alive until backward has consumed it
         ctx.set_materialize_grads(False)
-        res = plan.loss_total.clone()
         return tuple(res[k:k + 1] for k in range(res.numel()))
 
     @staticmethod
@@ -86,6 +90,8 @@ class AnyModel(nn.Module):
         self._reducer = None          # set by pqdet_amd.parallel.DistributedModel
         self._nan_event = None
         self._nan_host = None
+        self._nan_dev = None
+        self._nan_flags = []          # pinned host flags of the plans stepped since the last synchronous check
         self.nan_check = 'deferred'   # 'sync' | 'deferred' | 'off'
         self.overlap_wgrad = True     # run weight-gradient kernels on a side HIP stream during backward
         self._side = None
@@ -222,6 +228,17 @@ class AnyModel(nn.Module):
 
     # ---- NaN trap (reference model/loss.py:110-114), polled one step late unless nan_check == 'sync' ----
     def check_nan(self, wait: bool = True):
+        if self._nan_flags:                      # sticky flags the loss kernels set in pinned host memory: nothing was queued
+            if wait:
+                torch.cuda.current_stream().synchronize()
+            bad = [f for f in self._nan_flags if bool(f.any().item())]
+            if wait or bad:
+                self._nan_flags = []
+            for f in bad:
+                f.zero_()
+            if bad:
+                raise RuntimeError('NaN in loss')
+            return
         if self._nan_event is None:
             return
         if wait:
@@ -231,14 +248,22 @@ class AnyModel(nn.Module):
         bad = bool(self._nan_host.any().item())
         self._nan_event = None
         if bad:
+            self._nan_dev.zero_()                # the kernels only ever SET the flags
             raise RuntimeError('NaN in loss')
 
     def _arm_nan(self, plan):
         if self.nan_check == 'off':
             return
+        if plan.nan_host is not None:
+            if not any(f is plan.nan_host for f in self._nan_flags):
+                self._nan_flags.append(plan.nan_host)
+            if self.nan_check == 'sync':
+                self.check_nan(wait=True)
+            return
         if self._nan_host is None or self._nan_host.numel() != plan.nan_dev.numel():
             self._nan_host = torch.zeros(plan.nan_dev.numel(), dtype=torch.int32).pin_memory()
         self._nan_host.copy_(plan.nan_dev, non_blocking=True)
+        self._nan_dev = plan.nan_dev
         self._nan_event = torch.cuda.Event()
         self._nan_event.record()
         if self.nan_check == 'sync':

@@ -306,3 +306,48 @@ def test_step_with_handover_equals_step_with_finalize_launches(name, monkeypatch
     rel.sort()
     print('hand-over vs finalize: gradient difference median %.2e, max %.2e' % (rel[len(rel) // 2], rel[-1]))
     assert rel[len(rel) // 2] <= 6e-2
+
+
+@pytest.mark.parametrize('B,H,W', [(4, 256, 256), (3, 96, 160), (16, 512, 512)])
+def test_backward_handover_equals_backward_finalize_launches(B, H, W, monkeypatch):
+    """Backward twin (pq_bn_bstat, depthwise layers): PQ_BN_BWD_ATOMIC=0 (a pq_bn_bwd_finalize launch in front of every walking
+    depthwise backward) against the default (the projection's data-gradient sink adds its sums into accumulators, the walking
+    kernel derives p / q / r and stores dgamma / dbeta).  The forward is the same plan in both runs: losses and running
+    statistics are bit-identical; q and r come from the same partials summed exactly instead of in fp64 (an ulp at most), and
+    the backward has no discontinuity to amplify that: every parameter gradient agrees to 1e-5 norm-wise.  The hand-over plan
+    replays bit-identically (integer accumulation is order independent)."""
+    from test_model_gpu import _targets
+    from seedfill import seeded_images
+    runs = {}
+    for mode in ('1', '0', '1'):
+        monkeypatch.setenv('PQ_BN_BWD_ATOMIC', mode)
+        net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
+        seeded_fill(net, 4)
+        net = net.to(DEV)
+        net.train()
+        x = seeded_images(B, H, W, 3).to(DEV)
+        tgt = tuple(t.to(DEV) for t in _targets(B, H, W, 20, seed=9))
+        out = net(x, tgt)
+        out['loss'].mean().backward()
+        net.check_nan()
+        plan = list(net._plans.values())[0]
+        rec = (torch.stack([out[k] for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss')]).detach().clone(), net._flat.grad.clone(),
+               torch.cat([b_.detach().flatten().float() for b_ in net.buffers()]), plan.bn_bwd_handover, net)
+        runs.setdefault(mode, []).append(rec)
+    on, off = runs['1'][0], runs['0'][0]
+    assert on[3] >= 20 and off[3] == 0, (on[3], off[3])                  # 26 depthwise layers in the net
+    kinds = list(on[4]._plans.values())[0].bn_bwd_handover_producers
+    assert abi.OP_CONV1X1_DGRAD in kinds
+    if B * H * W >= 16 * 512 * 512:                                      # BASELINE config 2: the fused narrow-layer backward adds too
+        assert abi.OP_CONV1X1_BWD in kinds
+    assert torch.equal(runs['1'][0][1], runs['1'][1][1])                 # deterministic
+    assert torch.equal(on[0], off[0]) and torch.equal(on[2], off[2])     # same forward
+    flat = on[4]._flat
+    gmax = max(off[1][o:o + p.numel()].double().norm().item() for p, o in zip(flat.params, flat.offsets))
+    worst = 0.0
+    for p, o in zip(flat.params, flat.offsets):
+        da, db = on[1][o:o + p.numel()].double(), off[1][o:o + p.numel()].double()
+        err = (da - db).norm().item()
+        assert err <= 1e-5 * db.norm().item() + 1e-7 * gmax, (o, err, db.norm().item())
+        worst = max(worst, err / (db.norm().item() + 1e-7 * gmax))
+    print('backward hand-over vs finalize launches: worst gradient difference %.2e' % worst)

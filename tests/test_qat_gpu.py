@@ -464,6 +464,14 @@ def test_two_stream_forward_equals_the_single_stream_forward(monkeypatch):
                             torch.cat([b.detach().flatten().float() for b in net.buffers()])))
             plan = list(net._plans.values())[0]
             runs[side] = (rec, bool(getattr(plan, 'fwd_two_streams', False)))
+            # the two-stream float plan also moves the weight transposes of the backward into the forward's side stream and
+            # queues the side heads' loss kernels without a fork event (PQ_OPF_NOFORK): both are part of what is compared
+            nofork = [op.code for op in plan.fwd if op.flags & abi.OPF_NOFORK]
+            if side == '1':
+                assert nofork.count(abi.OP_LOSS_FWD) == 2 and plan.tr_in_forward == (not qat_plan)
+                assert (abi.OP_TRANSPOSE in nofork) == (not qat_plan)
+            else:
+                assert not nofork and not plan.tr_in_forward
         assert runs['1'][1] and not runs['0'][1]
         for (la, ga, ba), (lb, gb, bb) in zip(runs['1'][0], runs['0'][0]):
             assert torch.equal(la, lb) and torch.equal(ga, gb) and torch.equal(ba, bb), qat_plan
