@@ -170,6 +170,8 @@ def profile_kernels(plan, x, tgt, side=None, passes=3):
             for k in range(n):
                 tot[k] += ms[k] / passes
         for k in range(n):
+            if arr[k].code == abi.OP_FILL and arr[k].u.fill.n == 0:
+                continue                 # a place-holder op of the plan (no launch): its event pair is not device time
             name, bound = KERNEL_CLASS.get(arr[k].code, ('other', 'hbm'))
             fl, by = op_work(arr[k])
             e = acc.setdefault(name, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0, 'bound': bound})
