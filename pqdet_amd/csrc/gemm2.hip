@@ -236,6 +236,29 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
         const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats || qmask);
         want_stats = sk.finalize && stats;
         const int c4 = (lane & 7) * 4;
+        // Two-block tiles (64 x 128, 128 x 64): the sink operands of BOTH 32 x 32 blocks of the wave are requested before the
+        // first store -- loads and stores share one in-order counter, so a block's loads issued behind the previous block's
+        // stores wait for those stores to complete (one more exposed round trip per block).  Four-block tiles keep the
+        // per-block loads (128 more live registers).
+        constexpr bool HOIST = TI * TJ == 2;
+        float4 yh[HOIST ? TI * TJ : 1][4], gh[HOIST ? TI * TJ : 1][4];
+        if (HOIST) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int nn = n0 + wn * WN + 32 * j + c4;
+                const int nc = nn < N ? nn : 0;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int mb = m0 + wm * WM + 32 * i;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int mc = min(mb + (lane >> 3) + 8 * q, M - 1);
+                        yh[j * TI + i][q] = need_y ? ldg4(sk.y + (size_t)mc * sk.ldy + nc) : f4zero();
+                        gh[j * TI + i][q] = sk.accumulate ? ldg4(sk.g + (size_t)mc * sk.ldg + nc) : f4zero();
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int nb = n0 + wn * WN + 32 * j;
@@ -256,6 +279,7 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
                 float4 yq[4], gq[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    if (HOIST) { yq[q] = yh[HOIST ? j * TI + i : 0][q]; gq[q] = gh[HOIST ? j * TI + i : 0][q]; continue; }
                     const int mc = min(mb + (lane >> 3) + 8 * q, M - 1);
                     yq[q] = need_y ? ldg4(sk.y + (size_t)mc * sk.ldy + nc) : f4zero();
                     gq[q] = sk.accumulate ? ldg4(sk.g + (size_t)mc * sk.ldg + nc) : f4zero();
