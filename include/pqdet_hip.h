@@ -67,8 +67,9 @@ typedef struct pq_bn_stat {
  * rule as pq_bn_stat) instead of writing rows for pq_bn_bwd_finalize, and the ONE kernel that consumes the tensor's gradient
  * operand derives  p = gamma*invstd,  q = -p*invstd*S2/count,  r = -p*S1/count  in its prologue (fp64 like the finalize
  * kernel; the accumulated sums are exact, i.e. run-to-run deterministic); its first workgroup per channel chunk also stores
- * dgamma = S2, dbeta = S1 (the parameter gradients) and the p / q / r vectors.  Producers: pq_conv1x1_dgrad, pq_conv1x1_bwd
- * (dx_stat_*); consumer: pq_dw3x3_bwd parts 5 (dy_stat) -- the depthwise layers, whose gradient operand has exactly one reader.
+ * dgamma = S2, dbeta = S1 (the parameter gradients) and the p / q / r vectors.  Producers: pq_conv1x1_dgrad (the shapes
+ * that run on the ring kernels: pq_bn_bstat_ok), pq_conv1x1_bwd (dx_stat_*); consumer: pq_dw3x3_bwd part 5 (dy_stat) -- the
+ * depthwise layers, whose gradient operand has exactly one reader.
  * acc and *bad must be zero when the producer starts.  train == 0 (frozen statistics): q = r = 0. */
 typedef struct pq_bn_bstat {
     int64_t* acc;            /* [slots][2][ldp][2]; NULL: unused (the gsrc's p / q / r vectors are read instead) */

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
             for (int q = 0; q < BM / WM; ++q) { a += red[(0 * 4 + q) * 192 + t]; b += red[(1 * 4 + q) * 192 + t]; }
             const int n = n0 + t;
-            if (n < N && (EMODE == 1 || EMODE == 2) && p.stat_acc != nullptr) {   // no finalize launch: the consumer derives the coefficients
+            if (n < N && EMODE == 1 && p.stat_acc != nullptr) {   // no finalize launch: the first consumer derives the coefficients
                 bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 0, n, a);
                 bn_stat_add(p.stat_acc, p.stat_bad, p.stat_slots, ldp, bmy, 1, n, b);
             } else if (n < N) {
@@ -900,7 +900,6 @@ static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_g
     if (a->dx_stat_acc) {     // the sink's BatchNorm-backward sums go to accumulators (pq_bn_bstat), not to rows
         PQ_CHECK_ARG(a->dx_stat_bad && a->sub <= 1 && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx_stat_slots <= 4,
                      "dx_stat_acc needs dx_stat_bad, sub == 1 and a finalising sink with statistics");
-        p.stat_acc = a->dx_stat_acc; p.stat_bad = a->dx_stat_bad; p.stat_slots = a->dx_stat_slots > 0 ? a->dx_stat_slots : 1;
     }
     hipStream_t st = (hipStream_t)stream;
     const int bm = row_bm(a->M, a->I, a->O, 1);
@@ -909,6 +908,9 @@ static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_g
         if (rc < 0) return rc;
         if (rc == 1) { if (plan) return PQ_OK; PQ_CHECK_LAUNCH(); return PQ_OK; }
     }
+    // only the ring kernels (gemm2.hip) have the atomic sink epilogue: in the register-staged family the extra path made the
+    // 128 x 192 sink instantiations spill to scratch (the only scratch users of the library)
+    if (a->dx_stat_acc && !plan) { pq_set_error("pq_conv1x1_dgrad: dx_stat_acc is not supported for this shape (pq_bn_bstat_ok)"); return PQ_EUNSUPPORTED; }
     if (a->wt) {        // transposed weights [I][ceil4(O)] (pad columns zero): B rows are K-contiguous like the forward operand
         p.b = a->wt; p.ldb = (a->O + 3) & ~3;
         if (a->dy.y) launch_nt<2, false, 2>(p, st, bm, plan); else launch_nt<0, false, 2>(p, st, bm, plan);
@@ -925,9 +927,11 @@ extern "C" int pq_conv1x1_dgrad_plan(const pq_conv1x1_dgrad_args* a, pq_gemm_pla
     return conv1x1_dgrad_impl(a, nullptr, out);
 }
 
-// pq_bn_bstat_ok for PQ_OP_CONV1X1_DGRAD (producer role): every kernel this entry dispatches to has the atomic sink epilogue
+// pq_bn_bstat_ok for PQ_OP_CONV1X1_DGRAD (producer role): the shapes that dispatch to the ring kernels (family 2)
 int conv1x1_dgrad_bstat_ok(const pq_conv1x1_dgrad_args* a) {
-    return a->sub <= 1 && a->dx.finalize && a->dx.mean != nullptr && a->dx.partial != nullptr && !a->dx.qstate;
+    if (!(a->sub <= 1 && a->dx.finalize && a->dx.mean != nullptr && a->dx.partial != nullptr && !a->dx.qstate)) return 0;
+    pq_gemm_plan pl{};
+    return conv1x1_dgrad_impl(a, nullptr, &pl) == PQ_OK && pl.family == 2;
 }
 
 static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, int& rows) {

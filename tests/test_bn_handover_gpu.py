@@ -335,7 +335,9 @@ def test_backward_handover_equals_backward_finalize_launches(B, H, W, monkeypatc
                torch.cat([b_.detach().flatten().float() for b_ in net.buffers()]), plan.bn_bwd_handover, net)
         runs.setdefault(mode, []).append(rec)
     on, off = runs['1'][0], runs['0'][0]
-    assert on[3] >= 20 and off[3] == 0, (on[3], off[3])                  # 26 depthwise layers in the net
+    # 26 depthwise layers in the net; not handed over: lists of more than 640 rows (the stride-8 level at the benchmark shape) and
+    # projections whose data gradient runs on the register-staged GEMM family (192-channel layers): 19 at 512 x 512 batch 16
+    assert on[3] >= 15 and off[3] == 0, (on[3], off[3])
     kinds = list(on[4]._plans.values())[0].bn_bwd_handover_producers
     assert abi.OP_CONV1X1_DGRAD in kinds
     if B * H * W >= 16 * 512 * 512:                                      # BASELINE config 2: the fused narrow-layer backward adds too
@@ -351,3 +353,88 @@ def test_backward_handover_equals_backward_finalize_launches(B, H, W, monkeypatc
         assert err <= 1e-5 * db.norm().item() + 1e-7 * gmax, (o, err, db.norm().item())
         worst = max(worst, err / (db.norm().item() + 1e-7 * gmax))
     print('backward hand-over vs finalize launches: worst gradient difference %.2e' % worst)
+
+
+@pytest.mark.parametrize('B,H,W,Cc,O2,stride', [(2, 32, 32, 96, 64, 1), (2, 32, 32, 144, 64, 2), (1, 64, 64, 192, 96, 1)])
+def test_dgrad_sink_to_walking_depthwise_backward_handover(B, H, W, Cc, O2, stride):
+    """Kernel pair of the backward hand-over (pq_bn_bstat): the 1x1 projection's data gradient (ring kernel, gradient sink on
+    the depthwise conv's output) adds its BatchNorm-backward sums into accumulators, the walking depthwise backward derives
+    p / q / r in its prologue -- against the same two kernels with statistic rows + pq_bn_bwd_finalize in between: input
+    gradient, its statistic rows and the weight gradient within 1e-6 (same arithmetic on sums that are exact instead of fp64),
+    dgamma / dbeta / p / q / r as the finalize kernel writes them."""
+    l = abi.lib()
+    g = torch.Generator().manual_seed(B * H * W + Cc + stride)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    Mo, Mi = B * OH * OW, B * H * W
+    ldp = (Cc + 15) // 16 * 16
+    # tensors of the depthwise layer: raw input x (its own affine + relu6), raw output y (BatchNorm + relu6 in front of the 1x1)
+    x, y = K.rnd(Mi, Cc, g=g).to(DEV), K.rnd(Mo, Cc, g=g).to(DEV)
+    scx, shx = K.chan_vec(torch.rand(Cc, generator=g) + 0.5), K.chan_vec(K.rnd(Cc, g=g, scale=0.3))
+    mean_x, inv_x = K.chan_vec(x.mean(0).cpu()), K.chan_vec((1 / torch.sqrt(x.var(0, unbiased=False) + 1e-5)).cpu())
+    gamma = K.chan_vec(torch.rand(Cc, generator=g) + 0.5)
+    mu_y = y.mean(0).cpu()
+    inv_y = 1 / torch.sqrt(y.var(0, unbiased=False).cpu() + 1e-5)
+    mean_y, invstd_y = K.chan_vec(mu_y), K.chan_vec(inv_y)
+    scy = K.chan_vec(gamma[:Cc].cpu() * inv_y)
+    shy = K.chan_vec(K.rnd(Cc, g=g, scale=0.3))
+    wdw = K.rnd(Cc, 9, g=g, scale=0.4).to(DEV)
+    w2 = K.rnd(O2, Cc, g=g, scale=1 / math.sqrt(Cc))
+    w2d, w2t = w2.to(DEV), w2.t().contiguous().to(DEV)
+    dy2 = K.rnd(Mo, O2, g=g).to(DEV)
+    nblk = l.pq_conv1x1_blocks_k(Mo, Cc, O2, 1)
+    nbw = l.pq_dw3x3_bwd_walk_blocks(B, H, W, Cc, stride)
+
+    def run(handover):
+        gy = torch.full((Mo, Cc), float('nan'), device=DEV)
+        rows = torch.full((nblk * 2 * ldp,), float('nan'), device=DEV)
+        vec = {k: torch.full((ldp + 16,), float('nan'), device=DEV) for k in ('p', 'q', 'r', 'dgamma', 'dbeta')}
+        slots = l.pq_bn_stat_slots(nblk)
+        acc = torch.zeros(l.pq_bn_stat_bytes(ldp, slots) // 8, dtype=torch.int64, device=DEV)
+        bad = torch.zeros(16, dtype=torch.int32, device=DEV)
+        d = abi.Conv1x1Dgrad()
+        d.dy = abi.GSrc(dy2.data_ptr(), None, None, None, None, None, O2, 0)
+        d.w, d.wt = w2d.data_ptr(), w2t.data_ptr()
+        d.dx = abi.GSink(gy.data_ptr(), y.data_ptr(), scy.data_ptr(), shy.data_ptr(), mean_y.data_ptr(), invstd_y.data_ptr(),
+                         rows.data_ptr(), Cc, Cc, 2, 0, 1, ldp)
+        d.M, d.I, d.O, d.sub = Mo, Cc, O2, 1
+        plan = abi.GemmPlan()
+        abi.check(l.pq_conv1x1_dgrad_plan(C.byref(d), C.byref(plan)))
+        assert plan.family == 2 and l.pq_bn_bstat_ok(abi.OP_CONV1X1_DGRAD, C.byref(d), 0) == 1
+        if handover:
+            d.dx_stat_acc, d.dx_stat_bad, d.dx_stat_slots = acc.data_ptr(), bad.data_ptr(), slots
+        abi.check(l.pq_conv1x1_dgrad(C.byref(d), K.stream()))
+        if not handover:
+            f = abi.BnBwdFin(rows.data_ptr(), gamma.data_ptr(), invstd_y.data_ptr(), vec['dgamma'].data_ptr(), vec['dbeta'].data_ptr(),
+                             vec['p'].data_ptr(), vec['q'].data_ptr(), vec['r'].data_ptr(), nblk, ldp, Cc, 1, float(Mo), None, None)
+            abi.check(l.pq_bn_bwd_finalize(C.byref(f), K.stream()))
+        gx = torch.full((Mi, Cc), float('nan'), device=DEV)
+        srows = torch.full((nbw * 2 * ldp,), float('nan'), device=DEV)
+        scw = torch.full((nbw * Cc * 9 + 16,), float('nan'), device=DEV)
+        dww = torch.full((Cc, 9), float('nan'), device=DEV)
+        f5 = abi.DwBwd(abi.GSrc(gy.data_ptr(), y.data_ptr(), vec['p'].data_ptr(), vec['q'].data_ptr(), mean_y.data_ptr(), vec['r'].data_ptr(), Cc, Cc),
+                       abi.Src(x.data_ptr(), scx.data_ptr(), shx.data_ptr(), Cc, 2), wdw.data_ptr(),
+                       abi.GSink(gx.data_ptr(), x.data_ptr(), scx.data_ptr(), shx.data_ptr(), mean_x.data_ptr(), inv_x.data_ptr(),
+                                 srows.data_ptr(), Cc, Cc, 2, 0, 1, ldp),
+                       None, scw.data_ptr(), B, H, W, OH, OW, Cc, stride, 5)
+        assert l.pq_bn_bstat_ok(abi.OP_DW_BWD, C.byref(f5), 1) == 1
+        if handover:
+            f5.dy_stat = abi.BnBstat(acc.data_ptr(), bad.data_ptr(), gamma.data_ptr(), invstd_y.data_ptr(), vec['dgamma'].data_ptr(),
+                                     vec['dbeta'].data_ptr(), vec['p'].data_ptr(), vec['q'].data_ptr(), vec['r'].data_ptr(), slots, ldp,
+                                     float(Mo), 1)
+        abi.check(l.pq_dw3x3_bwd(C.byref(f5), K.stream()))
+        f6 = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), dww.data_ptr(), scw.data_ptr(), B, H, W, OH, OW, Cc, stride, 6)
+        abi.check(l.pq_dw3x3_bwd(C.byref(f6), K.stream()))
+        torch.cuda.synchronize()
+        assert int(bad[0]) == 0
+        return gy, gx, dww, srows, {k: v[:Cc].clone() for k, v in vec.items()}
+
+    gy0, gx0, dw0, s0, v0 = run(False)
+    gy1, gx1, dw1, s1, v1 = run(True)
+    assert torch.equal(gy0, gy1) and torch.isfinite(gx0).all()            # the sink's gradient itself does not depend on the hand-over
+    for k in ('dgamma', 'dbeta', 'p', 'q', 'r'):
+        K.close(v1[k], v0[k], rt=1e-6, at=1e-7 * float(v0[k].abs().max()), what=k)
+    scale = float(gx0.abs().max())
+    K.close(gx1, gx0, rt=1e-5, at=1e-6 * scale, what='input gradient of the depthwise layer')
+    K.close(dw1, dw0, rt=1e-5, at=1e-6 * float(dw0.abs().max()), what='depthwise weight gradient')
+    K.close(s1.view(nbw, 2, ldp)[:, :, :Cc].sum(0), s0.view(nbw, 2, ldp)[:, :, :Cc].sum(0), rt=1e-5,
+            at=1e-5 * float(s0.view(nbw, 2, ldp)[:, :, :Cc].sum(0).abs().max()), what='statistic rows of the input gradient')
