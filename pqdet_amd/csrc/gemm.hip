@@ -799,7 +799,11 @@ static TilePick pick_tile_bm(int M, int N, int bm) {
 }
 template <int AMODE, bool BKN, int EMODE>
 static void launch_nt(const GemmP& p, hipStream_t st, int bm, pq_gemm_plan* plan) {
-    const TilePick t = pick_tile_bm(p.M, p.N, bm);
+    TilePick t = pick_tile_bm(p.M, p.N, bm);
+    // the 128 x 192 streaming tile of a gradient sink keeps 96 accumulators + the sink's operands per lane and spills 448 bytes
+    // per lane (the only scratch user of the library): two 96-wide column tiles instead (the contraction of these layers is
+    // 32-64 long, so reading the A rows twice is cheap; the sink's columns are not duplicated): 10.07-10.10 -> 10.01-10.07 ms
+    if (EMODE == 2 && t.kind == 1 && t.bn == 192) { t.idx = 3; t.bn = 96; }
     if (plan) { *plan = pq_gemm_plan{1, t.bm, t.bn, t.kind == 0 ? 2 : 1, AMODE, EMODE, 0, BKN ? 1 : 0}; return; }   // query only
     dim3 blk(256);
     dim3 grid((p.N + t.bn - 1) / t.bn, (p.M + t.bm - 1) / t.bm);

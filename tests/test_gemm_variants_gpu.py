@@ -102,7 +102,7 @@ DGRAD = [
     (65536, 80, 75, False, 1, False, False, (1, 128, 96, 1, 0, 2, 0)),
     (65536, 256, 75, False, 2, False, True, (1, 128, 128, 2, 0, 2, 0)),
     (65536, 144, 32, True, 2, False, True, (1, 128, 160, 1, 2, 2, 0)),
-    (65536, 192, 32, True, 2, False, True, (1, 128, 192, 1, 2, 2, 0)),
+    (65536, 192, 32, True, 2, False, True, (1, 128, 96, 1, 2, 2, 0)),      # a 192-wide SINK runs as two 96-wide column tiles
 ]
 
 # ---- weight gradient: M, I, O, two-tensor operand, transformed input operand, expected (bm, bn, stages, amode, waves), splits
