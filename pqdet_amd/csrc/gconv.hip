@@ -38,6 +38,10 @@ __device__ __forceinline__ f32x16 gmfma(float a, float b, f32x16 c) { return __b
 // of four pixels are issued back to back at clamped (always valid) coordinates and masked afterwards -- a load inside an
 // `if` per element made the staging loop one memory latency per iteration, which dominated the stride-2 layers.
 constexpr int GUB = 4;
+// operand-tile staging: pixels a thread keeps in flight per batch.  A batch = one exposed memory round trip (its LDS stores sit
+// between it and the next batch's loads), so the 10 x 18 tile of the stride-1 kernels (at most 6 pixels per thread with >= 32
+// pixel lanes) goes in ONE batch; the 17 x 33 tile of the stride-2 kernels in batches of 8
+template <int NPIX> struct GcStageBatch { static constexpr int U = NPIX <= 6 * 32 ? 6 : 8; };
 // lcoef != NULL: the group's BatchNorm scale / shift ([2][32] floats in LDS) were derived from the producer's statistic
 // accumulators by the workgroup itself (pq_bn_stat hand-over: no finalize launch in front of this kernel)
 template <int ITW, int NPIX>
@@ -56,11 +60,12 @@ __device__ __forceinline__ void gc_stage_src(float4* At, int pitch, int gq, int 
     const bool fq = in.qstate != nullptr;
     const float qs = fq ? in.qstate[2] : 1.f, qinv = fq ? 1.f / qs : 1.f, qzp = fq ? in.qstate[3] : 0.f;
     const float* base = in.x + (size_t)b * AH * AW * in.ld + c;
-    for (int pix0 = pl; pix0 < NPIX; pix0 += GUB * PL) {
-        float4 r[GUB];
-        bool ok[GUB];
+    constexpr int UB = GcStageBatch<NPIX>::U;
+    for (int pix0 = pl; pix0 < NPIX; pix0 += UB * PL) {
+        float4 r[UB];
+        bool ok[UB];
 #pragma unroll
-        for (int u = 0; u < GUB; ++u) {
+        for (int u = 0; u < UB; ++u) {
             const int pix = pix0 + u * PL, pc = min(pix, NPIX - 1);
             const int py = pc / ITW, px = pc - py * ITW;
             const int ay = ay0 + py, ax = ax0 + px;
@@ -69,7 +74,7 @@ __device__ __forceinline__ void gc_stage_src(float4* At, int pitch, int gq, int 
             r[u] = ldg4(base + ((size_t)yy * AW + xx) * in.ld);
         }
 #pragma unroll
-        for (int u = 0; u < GUB; ++u) {
+        for (int u = 0; u < UB; ++u) {
             const int pix = pix0 + u * PL;
             if (pix < NPIX) {
                 float e4[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
@@ -99,11 +104,12 @@ __device__ __forceinline__ void gc_stage_gsrc(float4* At, int pitch, int gq, int
     const int PH = up ? DH : AH, PW = up ? DW : AW;
     const float* gb = dy.g + (size_t)b * PH * PW * dy.ldg + c;
     const float* yb = two ? dy.y + (size_t)b * PH * PW * dy.ldy + c : nullptr;
-    for (int pix0 = pl; pix0 < NPIX; pix0 += GUB * PL) {
-        float4 rg[GUB], ry[GUB];
-        bool ok[GUB];
+    constexpr int UB = GcStageBatch<NPIX>::U;
+    for (int pix0 = pl; pix0 < NPIX; pix0 += UB * PL) {
+        float4 rg[UB], ry[UB];
+        bool ok[UB];
 #pragma unroll
-        for (int u = 0; u < GUB; ++u) {
+        for (int u = 0; u < UB; ++u) {
             const int pix = pix0 + u * PL, pc = min(pix, NPIX - 1);
             const int py = pc / ITW, px = pc - py * ITW;
             const int ay = ay0 + py, ax = ax0 + px;
@@ -116,7 +122,7 @@ __device__ __forceinline__ void gc_stage_gsrc(float4* At, int pitch, int gq, int
             ry[u] = two ? ldg4(yb + row * dy.ldy) : f4zero();
         }
 #pragma unroll
-        for (int u = 0; u < GUB; ++u) {
+        for (int u = 0; u < UB; ++u) {
             const int pix = pix0 + u * PL;
             if (pix < NPIX) {
                 float e4[4] = {rg[u].x, rg[u].y, rg[u].z, rg[u].w};
