@@ -1,12 +1,12 @@
 #!/bin/bash
 # LDS bank-conflict share and wait share of every kernel of the train step (one rocprofv3 --pmc pass over a short bench run).
-# usage: scripts/pmc_step_lds.sh [out.csv]
+# usage: [BENCH_ARGS="--model regnetx-600m-fpn"] scripts/pmc_step_lds.sh [out.csv]
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$(realpath -m ${1:-$ROOT/gpurun_out/pmc_step_lds.csv})
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcl
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d /tmp/pmcl -o p -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pmcl.log 2>&1 || { tail -5 /tmp/pmcl.log; exit 1; }
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d /tmp/pmcl -o p -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline $BENCH_ARGS > /tmp/pmcl.log 2>&1 || { tail -5 /tmp/pmcl.log; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob('/tmp/pmcl/**/*counter_collection.csv', recursive=True)[0]
