@@ -552,6 +552,10 @@ typedef struct pq_yolo_loss_args {
     int32_t phase;       /* forward: 0 both launches; 1 the per-cell kernel only (block partials); 2 the finalize only (partials ->
                             losses row, totals) -- lets a caller put a stream join between the two (the finalize with totals reads
                             the other heads' rows) */
+    const struct pq_yolo_loss_args* also[2];   /* backward only: up to two more heads (HOST pointers to their argument structs, read
+                            at call time) whose gradients the SAME launch computes -- the per-head kernels are latency bound
+                            (~26 us each whatever the head size), three of them at the start of a backward cost one; same B.
+                            NULL: this head only */
 } pq_yolo_loss_args;
 int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream);
 int pq_yolo_loss_bwd(const pq_yolo_loss_args* a, void* stream);

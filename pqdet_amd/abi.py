@@ -188,7 +188,8 @@ class YoloLoss(C.Structure):
                 ('gsb', i64), ('gsh', i64), ('gsw', i64), ('gsc', i64),
                 ('B', i32), ('H', i32), ('W', i32), ('A', i32), ('C', i32), ('M', i32), ('stride', i32),
                 ('box_loss', i32), ('from_raw', i32), ('ignore_thresh', f32), ('l1_gain', f32),
-                ('totals', c_fp), ('head_slot', i32), ('n_heads', i32), ('gup', c_fp * 5), ('phase', i32)]
+                ('totals', c_fp), ('head_slot', i32), ('n_heads', i32), ('gup', c_fp * 5), ('phase', i32),
+                ('also', c_fp * 2)]
 
 
 class Adam(C.Structure):

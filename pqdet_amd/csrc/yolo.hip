@@ -291,16 +291,17 @@ __device__ __forceinline__ void lds_unstage(float* dstg, const float* src_lds, i
 // 16-byte loads (each lane walking its own 25-float record in global memory was pure load latency: 35 us for the 64 x 64 head
 // where the bytes take 8), the gradient records are written over the staged head values in LDS and leave in one coalesced sweep
 // (the pad floats between pixels carry their zeros through).
+// (bx: the block's index among the blocks of THIS head; the forward's block sums use blockIdx.x / gridDim.x themselves, i.e. the
+// forward is always a launch of one head)
 template <bool GRAD>
-__global__ __launch_bounds__(256) void yolo_loss_staged_kernel(pq_yolo_loss_args a, int span_cap, int lab_cap) {
+__device__ __forceinline__ void yolo_loss_staged_body(const pq_yolo_loss_args& a, int span_cap, int lab_cap, int bx, int b) {
     extern __shared__ __attribute__((aligned(16))) float ylds[];
     __shared__ float sbox[128 * 4];
     __shared__ float wred[4][3];
     float* s_in = ylds;                                   // span_cap floats (+4 for the alignment shift)
     float* s_lab = ylds + span_cap + 4;                   // lab_cap floats (+4)
-    const int b = blockIdx.y;
     const int cells = a.H * a.W * a.A;
-    const int c0 = blockIdx.x * 256;
+    const int c0 = bx * 256;
     const int c1 = min(c0 + 256, cells);                  // cells [c0, c1)
     const int nv = 5 + a.C, nl = 6 + a.C;
     const int ld = (int)a.in.sw;                          // floats per pixel (dense rows: sh == W * sw)
@@ -335,6 +336,19 @@ __global__ __launch_bounds__(256) void yolo_loss_staged_kernel(pq_yolo_loss_args
     } else {
         yolo_block_sums(a, b, lbox, lconf, lcls, wred);
     }
+}
+template <bool GRAD>
+__global__ __launch_bounds__(256) void yolo_loss_staged_kernel(pq_yolo_loss_args a, int span_cap, int lab_cap) {
+    yolo_loss_staged_body<GRAD>(a, span_cap, lab_cap, blockIdx.x, blockIdx.y);
+}
+// gradients of up to three heads from ONE launch (pq_yolo_loss_args.also): the blocks of the heads are laid end to end on
+// grid.x; the argument structs are picked by an if-chain (indexing a by-value array of structs would put it in scratch memory)
+struct LossMulti { pq_yolo_loss_args a0, a1, a2; int span_cap[3], lab_cap[3], blk1, blk2; };
+__global__ __launch_bounds__(256) void yolo_loss_bwd_multi_kernel(LossMulti m) {
+    const int bx = blockIdx.x, b = blockIdx.y;
+    if (bx < m.blk1) yolo_loss_staged_body<true>(m.a0, m.span_cap[0], m.lab_cap[0], bx, b);
+    else if (bx < m.blk2) yolo_loss_staged_body<true>(m.a1, m.span_cap[1], m.lab_cap[1], bx - m.blk1, b);
+    else yolo_loss_staged_body<true>(m.a2, m.span_cap[2], m.lab_cap[2], bx - m.blk2, b);
 }
 
 __global__ __launch_bounds__(256) void yolo_loss_finalize_kernel(const float* partial, int B, int nblk, float* losses, int32_t* nan_flag,
@@ -501,6 +515,42 @@ extern "C" int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream) {
 
 extern "C" int pq_yolo_loss_bwd(const pq_yolo_loss_args* a, void* stream) {
     PQ_CHECK_ARG(loss_check(a, true), "bad arguments");
+    if (a->also[0]) {          // several heads: one launch when every head fits the staged kernel, else one launch per head
+        const pq_yolo_loss_args* hd[3] = {a, a->also[0], a->also[1]};
+        const int nh = a->also[1] ? 3 : 2;
+        LossMulti m{};
+        size_t bytes = 0;
+        int blk[3] = {0, 0, 0};
+        bool fused = true;
+        for (int h = 0; h < nh; ++h) {
+            PQ_CHECK_ARG(loss_check(hd[h], true) && hd[h]->B == a->B, "also[]: bad arguments / different batch");
+            const size_t by = loss_staged_lds(hd[h], true, &m.span_cap[h], &m.lab_cap[h]);
+            fused = fused && by != 0;
+            bytes = by > bytes ? by : bytes;
+            blk[h] = pq_yolo_loss_blocks(hd[h]->H, hd[h]->W, hd[h]->A);
+        }
+        if (fused) {
+            static bool raised = false;
+            if (!raised) {
+                if (hipFuncSetAttribute((const void*)yolo_loss_bwd_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) fused = false;
+                raised = fused;
+            }
+        }
+        if (fused) {
+            m.a0 = *hd[0]; m.a1 = *hd[1]; m.a2 = *hd[nh - 1];
+            m.blk1 = blk[0]; m.blk2 = blk[0] + blk[1];
+            const int total = blk[0] + blk[1] + (nh == 3 ? blk[2] : 0);
+            hipLaunchKernelGGL(yolo_loss_bwd_multi_kernel, dim3(total, a->B), dim3(256), bytes, (hipStream_t)stream, m);
+            PQ_CHECK_LAUNCH();
+            return PQ_OK;
+        }
+        for (int h = 1; h < nh; ++h) {
+            pq_yolo_loss_args one = *hd[h];
+            one.also[0] = one.also[1] = nullptr;
+            const int rc = pq_yolo_loss_bwd(&one, stream);
+            if (rc != PQ_OK) return rc;
+        }
+    }
     const int nblk = pq_yolo_loss_blocks(a->H, a->W, a->A);
     if (!loss_launch_staged<true>(a, nblk, (hipStream_t)stream))
         hipLaunchKernelGGL((yolo_loss_kernel<true>), dim3(nblk, a->B), dim3(256), 0, (hipStream_t)stream, *a);

@@ -550,6 +550,13 @@ class Plan:
             self._emit_backward(flat, mods, heads, resolve)
         self.fwd_arr = (abi.Op * len(self.fwd))(*self.fwd)
         self.bwd_arr = (abi.Op * len(self.bwd))(*self.bwd) if self.bwd else None
+        self.loss_bwd_extra = None
+        if self.bwd_arr is not None and getattr(self, '_loss_extra', None):
+            # argument structs of the heads whose gradients ride in the first head's launch: host memory the call reads
+            self.loss_bwd_extra = (abi.YoloLoss * len(self._loss_extra))(*self._loss_extra)
+            first = self.bwd_arr[self._loss_fused_at].u.loss
+            for j in range(len(self._loss_extra)):
+                first.also[j] = C.addressof(self.loss_bwd_extra[j])
         if self.bwd_arr is not None and self.loss_ops_b:
             self.patch_upstream(self.default_upstream)
         self.post_arr = (abi.Op * len(self.post_bwd))(*self.post_bwd) if self.post_bwd else None
@@ -950,6 +957,8 @@ class Plan:
                 o = flat.index[id(p)]
                 self._op(self.bwd, abi.OP_FILL, abi.Fill(flat.grad_views[o].data_ptr(), 0.0, p.numel()))
 
+        self._loss_fused_at, self._loss_extra = None, []
+        fuse_loss = 2 <= len(heads) <= 3 and os.environ.get('PQ_LOSS_FUSE', '1') != '0'
         # slot 0: one batched transpose of the 1x1 weights whose data gradient is needed (filled in after the loop)
         tr_idx = self._op(self.bwd, abi.OP_TRANSPOSE, abi.Transpose(None, 0, 0))
         tr_items = []
@@ -973,8 +982,16 @@ class Plan:
                 slot, hm, a = head_at[i]
                 la, _, stride, _ = self._head_loss_args[slot]
                 a.received += 1
-                idx = self._op(self.bwd, abi.OP_LOSS_BWD, la)
-                self.loss_ops_b.append((idx, slot, stride))
+                if self._loss_fused_at is None or not fuse_loss:
+                    idx = self._op(self.bwd, abi.OP_LOSS_BWD, la)
+                    self.loss_ops_b.append((idx, slot, stride))
+                    if fuse_loss:
+                        self._loss_fused_at = idx
+                else:
+                    # the gradients of this head come out of the FIRST head's launch (pq_yolo_loss_args.also): the per-head kernels
+                    # are latency bound, ~26 us each on the critical chain whatever the head size
+                    self._loss_extra.append(la)
+                    self.loss_ops_b.append((-len(self._loss_extra), slot, stride))
             elif t == 'convolutional':
                 out = T[i]
                 conv = m.conv
@@ -1290,7 +1307,7 @@ class Plan:
             for lst, arr in ((self.loss_ops_f, self.fwd_arr), (self.loss_ops_b, self.bwd_arr)):
                 for idx, slot, stride in lst:
                     li, bi = pick[stride]
-                    la = arr[idx].u.loss
+                    la = arr[idx].u.loss if idx >= 0 else self.loss_bwd_extra[-idx - 1]
                     la.label = target[li].data_ptr()
                     la.boxes = target[bi].data_ptr()
                     la.M = target[bi].shape[1]
@@ -1304,7 +1321,7 @@ class Plan:
         backward loss ops read them in place: no host-side arithmetic, no copy."""
         ptrs = [None if g is None else g.data_ptr() for g in grads]
         for idx, slot, _ in self.loss_ops_b:
-            la = self.bwd_arr[idx].u.loss
+            la = self.bwd_arr[idx].u.loss if idx >= 0 else self.loss_bwd_extra[-idx - 1]
             for k in range(4):
                 la.gup[k] = ptrs[k]
             la.gup[4] = ptrs[4 + slot]
