@@ -271,37 +271,28 @@ typedef struct pq_dw3x3_wgrad_args {
 int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream);
 int64_t pq_dw3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_t OW, int32_t C);
 
-/* fused, LDS-tiled backward: ONE kernel stages (g_out, y_out) and y_in once and produces both the input gradient (through
- * the sink, statistics rows = pq_dw3x3_bwd_blocks) and dw -- 3 tensor reads + 1 write instead of the 7 passes of
- * pq_dw3x3_dgrad + pq_dw3x3_wgrad (which remain available as the streaming variants). */
+/* depthwise backward, both gradients from ONE pass over (g_out, y_out, y_in): the WALKING kernel (any plane size, stride 1|2,
+ * even input sizes at stride 2; needs in.x == dx.y, i.e. the sink is the conv's input tensor).  A workgroup walks down a
+ * 16-column strip with (dy', input) row rings in LDS; the sink's statistics rows and the weight-gradient rows in `scratch` are
+ * one per workgroup (pq_dw3x3_bwd_walk_blocks).  4 tensor passes instead of the 7 of pq_dw3x3_dgrad + pq_dw3x3_wgrad, which stay
+ * as the fallback for the planes this kernel does not take.  (Parts 0-4, the LDS-tiled kernels of round 2, were removed.) */
 typedef struct pq_dw3x3_bwd_args {
     pq_gsrc dy;
     pq_src in;
     const float* w;
     pq_gsink dx;
     float* dw;
-    float* scratch;      /* >= pq_dw3x3_bwd_scratch_bytes */
+    float* scratch;      /* >= pq_dw3x3_bwd_walk_blocks * C * 9 floats */
     int32_t B, IH, IW, OH, OW, C, stride;
-    int32_t part;        /* 0: both gradients in one kernel; stride 1 also 1: input gradient only (dw, scratch, in unused),
-                            2: weight gradient only (w, dx unused) -- lets the weight half run on another stream;
-                            3: both gradients from ONE staging of (g, y_out) and of the layer input (needs in.x == dx.y, i.e. the
-                               sink is the conv's input tensor): per-block weight-gradient rows are left in `scratch`;
-                            4: reduce those rows into dw (the only launch that may then run on another stream);
-                            5: both gradients by the WALKING kernel (any plane size, stride 1|2; needs in.x == dx.y): a workgroup
-                               walks down a 16-column strip with (dy', input) row rings in LDS, every tensor is read once; the
-                               sink's statistics rows and the weight-gradient rows in `scratch` are one per workgroup
-                               (pq_dw3x3_bwd_walk_blocks);
-                            6: reduce the rows a part-5 launch left in `scratch` into dw */
+    int32_t part;        /* 5: both gradients, per-workgroup weight-gradient rows left in `scratch` (dw unused);
+                            6: reduce the rows a part-5 launch left in `scratch` into dw (the only launch that may run on
+                               another stream; dy, in, w, dx unused) */
     pq_bn_bstat dy_stat; /* part 5, dy_stat.acc != NULL: the coefficients of dy are DERIVED from these sums (no pq_bn_bwd_finalize
                             launch in front of this call; dy.p / dy.q / dy.r are ignored, dy.mu is still read) */
 } pq_dw3x3_bwd_args;
 int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream);
-int64_t pq_dw3x3_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t C, int32_t stride);
-int32_t pq_dw3x3_bwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t stride);
-/* parts 5 / 6: workgroups of the walking kernel = rows of the sink's statistics = rows [C][9] of `scratch` */
+/* workgroups of the walking kernel = rows of the sink's statistics = rows [C][9] of `scratch` */
 int32_t pq_dw3x3_bwd_walk_blocks(int32_t B, int32_t IH, int32_t IW, int32_t C, int32_t stride);
-/* 1 when the fused tiled backward beats pq_dw3x3_dgrad + pq_dw3x3_wgrad for this plane size (measured heuristic) */
-int32_t pq_dw3x3_bwd_fused_pays(int32_t IH, int32_t IW, int32_t stride);
 
 /* ------------------------------------------------------------------ forward-only layers of the classifier cfgs
  * replaces FC (model/parser.py:122-137), nn.MaxPool2d / nn.AdaptiveAvgPool2d (:441-449), dense k x k nn.Conv2d beyond the grouped

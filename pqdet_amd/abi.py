@@ -302,14 +302,11 @@ SIGNATURES = {
     'pq_dw3x3_fwd': (C.c_int, [C.POINTER(DwFwd), C.c_void_p]),
     'pq_dw3x3_blocks': (i32, [i32, i32, i32, i32]),
     'pq_dw3x3_fwd_blocks': (i32, [i32, i32, i32, i32, i32]),
-    'pq_dw3x3_bwd_fused_pays': (i32, [i32, i32, i32]),
-    'pq_dw3x3_bwd_blocks': (i32, [i32, i32, i32, i32]),
     'pq_dw3x3_bwd_walk_blocks': (i32, [i32, i32, i32, i32, i32]),
     'pq_dw3x3_dgrad': (C.c_int, [C.POINTER(DwDgrad), C.c_void_p]),
     'pq_dw3x3_wgrad': (C.c_int, [C.POINTER(DwWgrad), C.c_void_p]),
     'pq_dw3x3_wgrad_scratch_bytes': (i64, [i32, i32, i32, i32]),
     'pq_dw3x3_bwd': (C.c_int, [C.POINTER(DwBwd), C.c_void_p]),
-    'pq_dw3x3_bwd_scratch_bytes': (i64, [i32, i32, i32, i32, i32, i32, i32]),
     'pq_gconv3x3_fwd': (C.c_int, [C.POINTER(GconvFwd), C.c_void_p]),
     'pq_gconv3x3_blocks': (i32, [i32, i32, i32]),
     'pq_gconv3x3_dgrad': (C.c_int, [C.POINTER(GconvDgrad), C.c_void_p]),

@@ -800,8 +800,9 @@ static TilePick pick_tile_bm(int M, int N, int bm) {
 template <int AMODE, bool BKN, int EMODE>
 static void launch_nt(const GemmP& p, hipStream_t st, int bm, pq_gemm_plan* plan) {
     TilePick t = pick_tile_bm(p.M, p.N, bm);
-    // the 128 x 192 streaming tile of a gradient sink keeps 96 accumulators + the sink's operands per lane and spills 448 bytes
-    // per lane (the only scratch user of the library): two 96-wide column tiles instead (the contraction of these layers is
+    // the 128 x 192 streaming tile of a gradient sink keeps 96 accumulators + the sink's operands per lane; its epilogue indexed the
+    // accumulator array by a loop variable the compiler did not unroll, so the whole array lived in a 448-byte private segment
+    // (scratch): two 96-wide column tiles instead (the contraction of these layers is
     // 32-64 long, so reading the A rows twice is cheap; the sink's columns are not duplicated): 10.07-10.10 -> 10.01-10.07 ms
     if (EMODE == 2 && t.kind == 1 && t.bn == 192) { t.idx = 3; t.bn = 96; }
     if (plan) { *plan = pq_gemm_plan{1, t.bm, t.bn, t.kind == 0 ? 2 : 1, AMODE, EMODE, 0, BKN ? 1 : 0}; return; }   // query only
@@ -821,7 +822,11 @@ static void launch_nt(const GemmP& p, hipStream_t st, int bm, pq_gemm_plan* plan
             case 3: hipLaunchKernelGGL((gemm_nt_kernel<128, 96, 32, 96, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
             case 4: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, 128, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
             case 5: hipLaunchKernelGGL((gemm_nt_kernel<128, 160, 32, 160, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
-            default: hipLaunchKernelGGL((gemm_nt_kernel<128, 192, 32, 192, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            default:
+                // (never reached with a gradient sink, see above: not instantiated either -- tests/test_codeobj.py asserts that no kernel
+                // of the library has a private segment)
+                if constexpr (EMODE != 2) hipLaunchKernelGGL((gemm_nt_kernel<128, 192, 32, 192, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p);
+                break;
         }
     }
 }

@@ -24,6 +24,21 @@
 
 namespace pq {
 
+// Diagnostic build only (python -m pqdet_amd.build -DPQ_STAMPS --tag=stamps; scripts/gemm_stamps.py): s_memtime at four points of
+// every workgroup (entry, first k-tile landed, main loop done, epilogue done) + s_memrealtime at both ends, into a buffer the
+// kernel never reads.  The shipped library has none of it.
+#ifdef PQ_STAMPS
+__device__ unsigned long long* pq_stamp_buf = nullptr;
+#define PQ_STAMP(i)                                                                                                        \
+    do {                                                                                                                   \
+        if (threadIdx.x == 0 && pq_stamp_buf)                                                                              \
+            pq_stamp_buf[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] =                                        \
+                ((i) >= 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime());                              \
+    } while (0)
+#else
+#define PQ_STAMP(i)
+#endif
+
 // wait until at most `tiles` k-tiles (NL loads each) of this wave are still in flight; tiles in 0..2
 template <int NL>
 __device__ __forceinline__ void wait_tiles(int tiles) {
@@ -74,6 +89,7 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w >> 1, wn = w & 1;
     const int lrow = lane & 31, lh = lane >> 5;
+    PQ_STAMP(0); PQ_STAMP(4);
     int bnx, bmy;
     xcd_block(bnx, bmy);
     const int m0 = bmy * BM, n0 = bnx * BN;
@@ -215,10 +231,14 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
         const int issued = min(nk, kt + D);
         wait_tiles<NL>(issued - kt - 1);
         __builtin_amdgcn_s_barrier();
+#ifdef PQ_STAMPS
+        if (kt == 0) PQ_STAMP(1);
+#endif
         if (kt + D < nk) issue((kt + D) % S, kt + D);
         compute(kt % S, kt);
     }
     __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring: it becomes epilogue scratch
+    PQ_STAMP(2);
 
     // ---------------------------------------------------------------- epilogue (same row-major LDS patches as gemm.hip)
     float* patch = lds + w * (32 * 36);
@@ -389,6 +409,10 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
             }
         }
     }
+#ifdef PQ_STAMPS
+    __syncthreads();
+    PQ_STAMP(3); PQ_STAMP(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad (TN)
@@ -568,6 +592,11 @@ __global__ __launch_bounds__(NW * 64) void gemm2_tn_kernel(G2TP p) {
 using namespace pq;
 
 // ------------------------------------------------------------------------------------------------ host side
+#ifdef PQ_STAMPS
+extern "C" int pq_debug_set_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(pq::pq_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 static bool g2_enabled() {
     static const char* e = getenv("PQ_G2");
     return !(e && e[0] == '0');

@@ -1085,7 +1085,8 @@ class Plan:
                                 # the WALKING backward (dwwalk.hip): both gradients from one pass over (g, y_out, y_in) on the main
                                 # stream -- 4 tensor passes instead of the 7 of a data- and a weight-gradient kernel -- with one
                                 # statistics / weight-gradient row per workgroup; only the reduction of those few rows goes to the
-                                # weight-gradient stream.  (PQ_DW_WALK=0: the round-2 split, A/B and tests.)
+                                # weight-gradient stream.  (PQ_DW_WALK=0: separate data / weight gradient kernels, the fallback for
+                                # odd stride-2 planes -- A/B and tests.)
                                 buf = self._new(nblk * out.C * 9 + 16)
                                 a = abi.DwBwd(dy, sin, wsrc, sink, None, ptr(buf), B, src.H, src.W, out.H, out.W, out.C, s, 5)
                                 self._op(self.bwd, abi.OP_DW_BWD, a)
@@ -1094,28 +1095,6 @@ class Plan:
                                 idx = self._op(self.bwd, abi.OP_DW_BWD, a)
                                 # the reduction of a few rows is not urgent: it rides with the next weight gradient's fork
                                 self.bwd[idx].flags = abi.OPF_SIDE | (abi.OPF_LAZY if os.environ.get('PQ_LAZY_REDUCE', '1') != '0' else 0)
-                            elif l.pq_dw3x3_bwd_fused_pays(src.H, src.W, s) and (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0)):
-                                # fused LDS-tiled backward: input gradient + weight gradient in one pass (main stream)
-                                need = l.pq_dw3x3_bwd_scratch_bytes(B, src.H, src.W, out.H, out.W, out.C, s)
-                                sink = self._sink(src, l.pq_dw3x3_bwd_blocks(B, src.H, src.W, s))
-                                if s == 1:
-                                    # the input-gradient chain is the critical path: the weight half of the tiled kernel goes to
-                                    # the weight-gradient stream (emitted first so that it starts early).  The single-staging
-                                    # variant (pq_dw3x3_bwd part 3 + 4: both gradients from one read of the tensors, all on the
-                                    # main stream) moves 37 % fewer bytes and still measured +0.22 ms per step: it lengthens
-                                    # the chain the step waits for.
-                                    a = abi.DwBwd(dy, src.src(), None, abi.GSink(), wdst, None, B, src.H, src.W, out.H,
-                                                  out.W, out.C, s, 2)
-                                    idx = self._op(self.bwd, abi.OP_DW_BWD, a)
-                                    wg_ops.append((idx, 'dwb', need))
-                                    a = abi.DwBwd(dy, abi.Src(), wsrc, sink, None, None, B, src.H, src.W, out.H, out.W,
-                                                  out.C, s, 1)
-                                    self._op(self.bwd, abi.OP_DW_BWD, a)
-                                else:
-                                    buf = self._new(max(need, 64) // 4 + 16)
-                                    a = abi.DwBwd(dy, src.src(), wsrc, sink, wdst, ptr(buf), B, src.H, src.W, out.H, out.W,
-                                                  out.C, s, 0)
-                                    self._op(self.bwd, abi.OP_DW_BWD, a)
                             else:
                                 need = l.pq_dw3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C)
                                 a = abi.DwWgrad(dy, src.src(), wdst, None, B, src.H, src.W, out.H, out.W,

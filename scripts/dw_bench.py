@@ -21,12 +21,12 @@ for (B, H, W, Cc, s) in SHAPES:
     x = torch.randn(B, H, W, Cc, device=dev); yo = torch.randn(B, OH, OW, Cc, device=dev); g = torch.randn(B, OH, OW, Cc, device=dev)
     w = torch.randn(Cc, 9, device=dev); gin = torch.empty(B, H, W, Cc, device=dev); dw = torch.empty(Cc, 9, device=dev)
     a, b2, mn, iv, p, q, mu, r = (vec(Cc) for _ in range(8))
-    nb = max(l.pq_ew_blocks(B * H * W, Cc), l.pq_dw3x3_bwd_blocks(B, H, W, s))
+    nb = max(l.pq_ew_blocks(B * H * W, Cc), l.pq_dw3x3_bwd_walk_blocks(B, H, W, Cc, s))
     part = torch.empty(nb * 2 * Cc, device=dev)
     gs = abi.GSrc(g.data_ptr(), yo.data_ptr(), p.data_ptr(), q.data_ptr(), mu.data_ptr(), r.data_ptr(), Cc, Cc)
     src = abi.Src(x.data_ptr(), a.data_ptr(), b2.data_ptr(), Cc, 2)
     sink = abi.GSink(gin.data_ptr(), x.data_ptr(), a.data_ptr(), b2.data_ptr(), mn.data_ptr(), iv.data_ptr(), part.data_ptr(), Cc, Cc, 2, 0, 1, Cc)
-    sc = torch.empty(max(l.pq_dw3x3_wgrad_scratch_bytes(B, OH, OW, Cc), l.pq_dw3x3_bwd_scratch_bytes(B, H, W, OH, OW, Cc, s)) // 4 + 16, device=dev)
+    sc = torch.empty(max(l.pq_dw3x3_wgrad_scratch_bytes(B, OH, OW, Cc), l.pq_dw3x3_bwd_walk_blocks(B, H, W, Cc, s) * Cc * 9 * 4) // 4 + 16, device=dev)
     d = abi.DwDgrad(gs, w.data_ptr(), sink, B, H, W, OH, OW, Cc, s)
     wg = abi.DwWgrad(gs, src, dw.data_ptr(), sc.data_ptr(), B, H, W, OH, OW, Cc, s)
     fb = abi.DwBwd(gs, src, w.data_ptr(), sink, dw.data_ptr(), sc.data_ptr(), B, H, W, OH, OW, Cc, s)

@@ -474,8 +474,8 @@ def test_conv1x1_bwd_fused_rejects_shapes_outside_its_range():
                                              # pruned nets: channel counts that are not multiples of 4 (pitch = ceil4)
                                              (2, 9, 13, 25, 1), (2, 10, 14, 95, 2), (1, 12, 12, 142, 1), (2, 70, 66, 25, 1),
                                              (1, 72, 68, 95, 2),
-                                             # plane sizes of the 512 x 512 benchmark step: the dispatch picks its streaming / column-walk
-                                             # (>= 256 x 256, dw_dgrad_s1_walk_kernel) / LDS-tiled kernels by plane size
+                                             # plane sizes of the 512 x 512 benchmark step: the forward dispatch picks its walking (stride 1) /
+                                             # streaming / LDS-tiled kernels by plane size
                                              (1, 256, 256, 32, 1), (1, 256, 256, 96, 2), (1, 128, 128, 144, 1), (1, 128, 128, 144, 2),
                                              (2, 64, 64, 192, 1), (2, 64, 64, 192, 2), (2, 32, 32, 384, 1), (2, 16, 16, 960, 1)])
 def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
@@ -553,24 +553,10 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     torch.cuda.synchronize()
     close(dw.view(Cc, 1, 3, 3), wr.grad, rt=1e-3, at=1e-3, what='dw wgrad')
 
-    # fused, LDS-tiled backward entry point: same results from one kernel (stride 2 needs even input sizes)
+    # both gradients from one kernel (stride 2 needs even input sizes)
     if stride == 2 and (H % 2 or W % 2):
         return
-    gdst2 = torch.full((B, H, W, P), float('nan'), device=DEV)
-    nb3 = l.pq_dw3x3_bwd_blocks(B, H, W, stride)
-    part3 = torch.zeros(nb3 * 2 * ldp, device=DEV)
-    dw2 = torch.full((Cc, 9), float('nan'), device=DEV)
-    sc2 = torch.empty(l.pq_dw3x3_bwd_scratch_bytes(B, H, W, OH, OW, Cc, stride) // 4 + 16, device=DEV)
-    fb = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(gdst2.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
-                                                         sv[1].data_ptr(), part3.data_ptr(), P, P, 2, 0, 1, ldp),
-                   dw2.data_ptr(), sc2.data_ptr(), B, H, W, OH, OW, Cc, stride)
-    abi.check(l.pq_dw3x3_bwd(C.byref(fb), stream()))
-    torch.cuda.synchronize()
-    close(gdst2[..., :Cc], gwant, what='fused dw dgrad')
-    close(dw2.view(Cc, 1, 3, 3), wr.grad, rt=1e-3, at=1e-3, what='fused dw wgrad')
-    t1, t2 = reduce_partial(part3, nb3, ldp, Cc)
-    close(t1.float(), gwant.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum')
-    close(t2.float(), (gwant.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='fused dw sum xhat')
+    xh = (x.double() - mean_in.double()) * inv_in.double()
     # the WALKING kernel (parts 5 + 6, the engine's default): row rings in LDS, every tensor read once, one statistics / weight-
     # gradient row per workgroup; any plane size, both strides; plain and accumulating sink
     nbw = l.pq_dw3x3_bwd_walk_blocks(B, H, W, Cc, stride)
@@ -597,45 +583,9 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
         t1, t2 = reduce_partial(pw, nbw, ldp, Cc)
         close(t1.float(), want.double().sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='walking dw sum')
         close(t2.float(), (want.double() * xh).sum((0, 1, 2)).float(), rt=1e-3, at=1e-2, what='walking dw sum xhat')
-    if stride == 1:
-        # the two halves on their own (the engine runs the weight half on the weight-gradient stream): bit-identical
-        g3 = torch.full((B, H, W, P), float('nan'), device=DEV)
-        p3 = torch.zeros(nb3 * 2 * ldp, device=DEV)
-        h1 = abi.DwBwd(d.dy, abi.Src(), wd.data_ptr(), abi.GSink(g3.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
-                                                                  sv[1].data_ptr(), p3.data_ptr(), P, P, 2, 0, 1, ldp),
-                       None, None, B, H, W, OH, OW, Cc, stride, 1)
-        abi.check(l.pq_dw3x3_bwd(C.byref(h1), stream()))
-        dw3 = torch.full((Cc, 9), float('nan'), device=DEV)
-        h2 = abi.DwBwd(d.dy, a.inp, None, abi.GSink(), dw3.data_ptr(), sc2.data_ptr(), B, H, W, OH, OW, Cc, stride, 2)
-        abi.check(l.pq_dw3x3_bwd(C.byref(h2), stream()))
-        torch.cuda.synchronize()
-        assert torch.equal(g3, gdst2) and torch.equal(p3, part3) and torch.equal(dw3, dw2)
-        # part 3 + 4 (the engine's default): ONE staging of (g, y_out) and of the raw layer input for both gradients (the sink's y
-        # comes out of the same LDS tile), then the reduction of the per-block weight-gradient rows as its own launch.  Same
-        # arithmetic in the same order: bit-identical.
-        g4 = torch.full((B, H, W, P), float('nan'), device=DEV)
-        p4 = torch.zeros(nb3 * 2 * ldp, device=DEV)
-        dw4 = torch.full((Cc, 9), float('nan'), device=DEV)
-        sc4 = torch.full_like(sc2, float('nan'))
-        f3 = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(g4.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
-                                                              sv[1].data_ptr(), p4.data_ptr(), P, P, 2, 0, 1, ldp),
-                       None, sc4.data_ptr(), B, H, W, OH, OW, Cc, stride, 3)
-        abi.check(l.pq_dw3x3_bwd(C.byref(f3), stream()))
-        f4 = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), dw4.data_ptr(), sc4.data_ptr(), B, H, W, OH, OW, Cc, stride, 4)
-        abi.check(l.pq_dw3x3_bwd(C.byref(f4), stream()))
-        torch.cuda.synchronize()
-        assert torch.equal(g4, gdst2) and torch.equal(p4, part3) and torch.equal(dw4, dw2)
-        # ... with an accumulating sink (the tensor has another consumer that ran before)
-        prev = rnd(B, H, W, Cc, g=g)
-        g5, g6 = padc(prev), padc(prev)
-        for gbuf, part in ((g5, 3), (g6, 0)):
-            fb2 = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(gbuf.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(),
-                                                                   sv[0].data_ptr(), sv[1].data_ptr(), p4.data_ptr(), P, P, 2, 1, 1, ldp),
-                            dw4.data_ptr(), sc4.data_ptr(), B, H, W, OH, OW, Cc, stride, part)
-            abi.check(l.pq_dw3x3_bwd(C.byref(fb2), stream()))
-        torch.cuda.synchronize()
-        assert torch.equal(g5, g6)
-        close(g5[..., :Cc], (dxin + prev) * ((u > 0) & (u < 6)).float(), what='fused dw dgrad, accumulating sink')
+    # the removed parts 0-4 (LDS-tiled backward of round 2) are refused loudly
+    f0 = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), f5.dx, dww.data_ptr(), scw.data_ptr(), B, H, W, OH, OW, Cc, stride, 0)
+    assert l.pq_dw3x3_bwd(C.byref(f0), stream()) != 0 and b'removed' in l.pq_last_error()
 
 
 # ----------------------------------------------------------------------------------------------- stem
