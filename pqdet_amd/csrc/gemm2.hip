@@ -19,6 +19,7 @@
 //   WAR  a stage is refilled only after the barrier that follows its last ds_read (whose data the MFMAs have consumed).
 //
 // mirrors: nn.Conv2d(k=1) forward / backward inside the conv blocks of the reference, model/parser.py:389-410.
+#include <type_traits>
 #include "common.h"
 #include "ldsdma.h"
 
@@ -33,7 +34,7 @@ __device__ unsigned long long* pq_stamp_buf = nullptr;
     do {                                                                                                                   \
         if (threadIdx.x == 0 && pq_stamp_buf)                                                                              \
             pq_stamp_buf[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] =                                        \
-                ((i) >= 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime());                              \
+                ((i) == 4 || (i) == 5 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime());                              \
     } while (0)
 #else
 #define PQ_STAMP(i)
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
         else for (int k0 = t; k0 < K; k0 += 512) bn_stat_coefs<2>(p.stat, k0, 256, K, writer, put);
         __syncthreads();
     }
-    for (int kt = 0; kt < nk; ++kt) {
+    // ---- main loop; the last k-tile is peeled so that the loads of the epilogue can be requested under its MFMAs
+    for (int kt = 0; kt < nk - 1; ++kt) {
         const int issued = min(nk, kt + D);
         wait_tiles<NL>(issued - kt - 1);
         __builtin_amdgcn_s_barrier();
@@ -237,159 +239,175 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
         if (kt + D < nk) issue((kt + D) % S, kt + D);
         compute(kt % S, kt);
     }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#ifdef PQ_STAMPS
+    if (nk == 1) PQ_STAMP(1);
+#endif
+
+    // ---------------------------------------------------------------- epilogue
+    // The accumulators leave in their NATIVE layout: lane = output column (lrow), 16 rows per lane and 32 x 32 block,
+    // row(r) = (r & 3) + 8 * (r >> 2) + 4 * lh.  Every global access of a wave instruction is then two 128-byte row segments
+    // (full-rate dword stores / loads), there is no LDS transpose, the per-column coefficients and statistics are one value per
+    // lane, and a tile that lies inside the matrix takes a path without masks or branches (round 3's epilogue went through LDS
+    // patches and tested row / column / alignment flags per element: 6-15 k of a tile's 35-95 k cycles, scripts/gemm_stamps.py).
+    // EMODE 2, one or two blocks per wave: the gradient sink's operands (the layer input y for the activation derivative and the
+    // BatchNorm-backward sums, the running gradient of an accumulating sink) and its coefficients are requested HERE, in front of
+    // the last k-tile's MFMAs, so that their HBM round trip does not open the epilogue.
+    constexpr int NB = TI * TJ;
+    constexpr bool HOIST = EMODE == 2 && NB <= 2;
+    const pq_gsink& sk = p.sink;
+    const bool sk_affine = EMODE == 2 && sk.scale != nullptr;
+    const bool sk_stats = EMODE == 2 && sk.mean != nullptr && sk.partial != nullptr;
+    // QAT: the tensor is consumed as fake_quant(act(...)): straight-through mask of its activation observer (arithmetic of
+    // qat.hip / sink_apply4: the multiply sits inside rintf, nothing here can contract)
+    const bool qmask = EMODE == 2 && sk.finalize && sk.qstate != nullptr;
+    const bool need_y = EMODE == 2 && sk.finalize && (sk.act != PQ_ACT_LINEAR || sk_stats || qmask);
+    const bool sk_acc = EMODE == 2 && sk.accumulate;
+    const bool full = m0 + BM <= M && n0 + BN <= N;           // uniform
+    float yv[HOIST ? NB : 1][16], gv[HOIST ? NB : 1][16];
+    float ca[TJ], cb[TJ], cm[TJ], ci[TJ];
+    auto sink_coefs = [&]() {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int n = n0 + wn * WN + 32 * j + lrow;
+            const int nc = n < N ? n : 0;
+            ca[j] = sk_affine ? sk.scale[nc] : 1.f; cb[j] = sk_affine ? sk.shift[nc] : 0.f;
+            cm[j] = sk_stats ? sk.mean[nc] : 0.f; ci[j] = sk_stats ? sk.invstd[nc] : 0.f;
+        }
+    };
+    // Addressing of a 32 x 32 block: a wave-uniform pointer to (first row + rowc(r), first column) -- SGPR pair, SALU arithmetic --
+    // plus ONE 32-bit per-lane element offset (4 * lh rows down, lrow columns right) for all 16 accesses: no 64-bit VGPR address
+    // per row.  Tiles that stick out of the matrix clamp per lane instead (slow path, edge tiles only).
+    const int wmu = __builtin_amdgcn_readfirstlane(wm), wnu = __builtin_amdgcn_readfirstlane(wn);
+    auto urow = [&](const float* base, int ld, int i, int j, int rowc) -> const float* {
+        return base + (size_t)(m0 + wmu * WM + 32 * i + rowc) * (size_t)ld + (n0 + wnu * WN + 32 * j);
+    };
+    auto sink_block_loads = [&](auto full_c, int i, int j, float* yd, float* gd) {
+        if (decltype(full_c)::value) {
+            const unsigned oy = 4u * lh * (unsigned)sk.ldy + lrow, og = 4u * lh * (unsigned)sk.ldg + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowc = (r & 3) + 8 * (r >> 2);
+                yd[r] = need_y ? urow(sk.y, sk.ldy, i, j, rowc)[oy] : 0.f;
+                gd[r] = sk_acc ? urow(sk.g, sk.ldg, i, j, rowc)[og] : 0.f;
+            }
+        } else {
+            const int n = n0 + wn * WN + 32 * j + lrow;
+            const int nc = n < N ? n : 0;
+            const int mb = m0 + wm * WM + 32 * i + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mc = min(mb + (r & 3) + 8 * (r >> 2), M - 1);
+                yd[r] = need_y ? sk.y[(size_t)mc * sk.ldy + nc] : 0.f;
+                gd[r] = sk_acc ? sk.g[(size_t)mc * sk.ldg + nc] : 0.f;
+            }
+        }
+    };
+    if (EMODE == 2) {
+        sink_coefs();
+        if (HOIST && full) {                       // (edge tiles load in the epilogue: their clamped per-lane addresses are not worth keeping)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int i = 0; i < TI; ++i) sink_block_loads(std::true_type{}, i, j, yv[HOIST ? j * TI + i : 0], gv[HOIST ? j * TI + i : 0]);
+        }
+    }
+    compute((nk - 1) % S, nk - 1);
     __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring: it becomes epilogue scratch
     PQ_STAMP(2);
 
-    // ---------------------------------------------------------------- epilogue (same row-major LDS patches as gemm.hip)
-    float* patch = lds + w * (32 * 36);
-    float* red = lds + 4 * (32 * 36);              // [2][2][BN]
+    float* red = lds;                              // [2][2][BN]
     bool want_stats = false;
+    float t1[TJ], t2[TJ];                          // per-column sums of this lane
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) t1[j] = t2[j] = 0.f;
     if (EMODE == 2) {
-        const pq_gsink& sk = p.sink;
-        const bool affine = sk.scale != nullptr;
-        const bool stats = sk.mean != nullptr && sk.partial != nullptr;
         const ActParam sact = act_param(sk.act);
-        // QAT: the tensor is consumed as fake_quant(act(...)): straight-through mask of its activation observer (arithmetic of
-        // qat.hip / sink_apply4: the multiply sits inside rintf, nothing here can contract)
-        const bool qmask = sk.finalize && sk.qstate != nullptr;
         const float qinv = qmask ? 1.f / sk.qstate[2] : 0.f, qzp = qmask ? sk.qstate[3] : 0.f;
-        const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats || qmask);
-        want_stats = sk.finalize && stats;
-        const int c4 = (lane & 7) * 4;
-        // Two-block tiles (64 x 128, 128 x 64): the sink operands of BOTH 32 x 32 blocks of the wave are requested before the
-        // first store -- loads and stores share one in-order counter, so a block's loads issued behind the previous block's
-        // stores wait for those stores to complete (one more exposed round trip per block).  Four-block tiles keep the
-        // per-block loads (128 more live registers).
-        constexpr bool HOIST = TI * TJ == 2;
-        float4 yh[HOIST ? TI * TJ : 1][4], gh[HOIST ? TI * TJ : 1][4];
-        if (HOIST) {
+        want_stats = sk.finalize && sk_stats;
+        auto emit = [&](auto full_c, auto q_c) {
+            constexpr bool F = decltype(full_c)::value, Q = decltype(q_c)::value;
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const int nn = n0 + wn * WN + 32 * j + c4;
-                const int nc = nn < N ? nn : 0;
+                const int n = n0 + wn * WN + 32 * j + lrow;
+                const bool nok = F || n < N;
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
-                    const int mb = m0 + wm * WM + 32 * i;
+                    const int mb = m0 + wm * WM + 32 * i + 4 * lh;
+                    float yl[16], gl[16];
+                    constexpr bool PRE = HOIST && F;           // this block's operands were requested in front of the last k-tile
+                    if (!PRE) sink_block_loads(full_c, i, j, yl, gl);
+                    const float* yy = PRE ? yv[PRE ? j * TI + i : 0] : yl;
+                    const float* gg = PRE ? gv[PRE ? j * TI + i : 0] : gl;
+                    float* dst = sk.g + (size_t)mb * sk.ldg + n;
+                    const unsigned og = 4u * lh * (unsigned)sk.ldg + lrow;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int mc = min(mb + (lane >> 3) + 8 * q, M - 1);
-                        yh[j * TI + i][q] = need_y ? ldg4(sk.y + (size_t)mc * sk.ldy + nc) : f4zero();
-                        gh[j * TI + i][q] = sk.accumulate ? ldg4(sk.g + (size_t)mc * sk.ldg + nc) : f4zero();
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int nb = n0 + wn * WN + 32 * j;
-            const int nn = nb + c4;
-            const bool nok = nn < N;
-            const int nc = nok ? nn : 0;
-            float ca[4], cb[4], cm[4], ci[4], t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ca[u] = affine ? sk.scale[nc + u] : 1.f; cb[u] = affine ? sk.shift[nc + u] : 0.f;
-                cm[u] = stats ? sk.mean[nc + u] : 0.f; ci[u] = stats ? sk.invstd[nc + u] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int mb = m0 + wm * WM + 32 * i;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lrow] = acc[i][j][r];
-                float4 yq[4], gq[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (HOIST) { yq[q] = yh[HOIST ? j * TI + i : 0][q]; gq[q] = gh[HOIST ? j * TI + i : 0][q]; continue; }
-                    const int mc = min(mb + (lane >> 3) + 8 * q, M - 1);
-                    yq[q] = need_y ? ldg4(sk.y + (size_t)mc * sk.ldy + nc) : f4zero();
-                    gq[q] = sk.accumulate ? ldg4(sk.g + (size_t)mc * sk.ldg + nc) : f4zero();
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = (lane >> 3) + 8 * q, m = mb + row;
-                    const float4 a4 = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
-                    float dz[4] = {a4.x + gq[q].x, a4.y + gq[q].y, a4.z + gq[q].z, a4.w + gq[q].w};
-                    const float yy[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w};
-                    if (need_y) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float uu = fmaf(ca[u], yy[u], cb[u]);
-                            dz[u] *= act_bwd(uu, sact);
-                            if (qmask) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz[u] = (qv >= 0.f && qv <= 255.f) ? dz[u] : 0.f; }
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2);
+                        float dz = acc[i][j][r] + gg[r];
+                        const float uu = fmaf(ca[j], yy[r], cb[j]);
+                        dz *= need_y ? act_bwd(uu, sact) : 1.f;
+                        if (Q) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz = (qv >= 0.f && qv <= 255.f) ? dz : 0.f; }
+                        if (F) const_cast<float*>(urow(sk.g, sk.ldg, i, j, row))[og] = dz;
+                        else if (mb + row < M && nok) dst[(size_t)row * sk.ldg] = dz;
+                        if (F || (mb + row < M && nok)) {
+                            t1[j] += dz;
+                            t2[j] = fmaf(dz, (yy[r] - cm[j]) * ci[j], t2[j]);
                         }
                     }
-                    if (m < M && nok) {
-                        stg4(sk.g + (size_t)m * sk.ldg + nn, make_float4(dz[0], dz[1], dz[2], dz[3]));
-                        if (stats) {
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) { t1[u] += dz[u]; t2[u] = fmaf(dz[u], (yy[u] - cm[u]) * ci[u], t2[u]); }
-                        }
-                    }
+                    if (!PRE) __builtin_amdgcn_sched_barrier(0);        // one block's operands live at a time
                 }
             }
-            if (want_stats) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                    for (int off = 8; off <= 32; off <<= 1) { t1[u] += __shfl_xor(t1[u], off); t2[u] += __shfl_xor(t2[u], off); }
-                    if (lane < 8) {
-                        red[(0 * 2 + wm) * BN + wn * WN + 32 * j + c4 + u] = t1[u];
-                        red[(1 * 2 + wm) * BN + wn * WN + 32 * j + c4 + u] = t2[u];
-                    }
-                }
-            }
-        }
+        };
+        if (qmask) { if (full) emit(std::true_type{}, std::true_type{}); else emit(std::false_type{}, std::true_type{}); }
+        else if (full) emit(std::true_type{}, std::false_type{});
+        else emit(std::false_type{}, std::false_type{});
     } else {
         want_stats = (EMODE == 1) && (p.partial != nullptr || p.stat_acc != nullptr);
-        const bool vec_out = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
-        float s1[TJ], s2[TJ];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) s1[j] = s2[j] = 0.f;
+        float bias[TJ];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            const int nb = n0 + wn * WN + 32 * j;
-            const int n = nb + lrow;
-            const bool nok = n < N;
-            const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+            const int n = n0 + wn * WN + 32 * j + lrow;
+            bias[j] = (p.bias != nullptr && n < N) ? p.bias[n] : 0.f;
+        }
+        auto emit = [&](auto full_c) {
+            constexpr bool F = decltype(full_c)::value;
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int mb = m0 + wm * WM + 32 * i;
+            for (int j = 0; j < TJ; ++j) {
+                const int n = n0 + wn * WN + 32 * j + lrow;
+                const bool nok = F || n < N;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float v = acc[i][j][r] + bias;
-                    if (vec_out) patch[row * 36 + lrow] = v;
-                    else if (mb + row < M && nok) p.out[(size_t)(mb + row) * p.ldo + n] = v;
-                    if (EMODE == 1 && mb + row < M && nok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
-                }
-                if (vec_out) {
+                for (int i = 0; i < TI; ++i) {
+                    const int mb = m0 + wm * WM + 32 * i + 4 * lh;
+                    float* dst = p.out + (size_t)mb * p.ldo + n;
+                    const unsigned oo = 4u * lh * (unsigned)p.ldo + lrow;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
-                        const int m = mb + row, nn = nb + c4;
-                        if (m < M && nn < N) {
-                            const float4 v4 = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
-                            float* dst = p.out + (size_t)m * p.ldo + nn;
-                            if (nn + 3 < N) stg4(dst, v4);
-                            else { const float e[4] = {v4.x, v4.y, v4.z, v4.w}; for (int u = 0; u < 4 && nn + u < N; ++u) dst[u] = e[u]; }
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2);
+                        const float v = acc[i][j][r] + bias[j];
+                        if (F) const_cast<float*>(urow(p.out, p.ldo, i, j, row))[oo] = v;
+                        else if (mb + row < M && nok) dst[(size_t)row * p.ldo] = v;
+                        if (F || (mb + row < M && nok)) {
+                            if (EMODE == 1) { t1[j] += v; t2[j] = fmaf(v, v, t2[j]); }
                         }
                     }
                 }
             }
-        }
-        if (want_stats) {
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                s1[j] += __shfl_xor(s1[j], 32);
-                s2[j] += __shfl_xor(s2[j], 32);
-                if (lh == 0) {
-                    red[(0 * 2 + wm) * BN + wn * WN + 32 * j + lrow] = s1[j];
-                    red[(1 * 2 + wm) * BN + wn * WN + 32 * j + lrow] = s2[j];
-                }
-            }
-        }
+        };
+        if (full) emit(std::true_type{}); else emit(std::false_type{});
     }
     if (want_stats) {   // uniform across the block
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            t1[j] += __shfl_xor(t1[j], 32);
+            t2[j] += __shfl_xor(t2[j], 32);
+            if (lh == 0) {
+                red[(0 * 2 + wm) * BN + wn * WN + 32 * j + lrow] = t1[j];
+                red[(1 * 2 + wm) * BN + wn * WN + 32 * j + lrow] = t2[j];
+            }
+        }
+        PQ_STAMP(6);
         float* part = (EMODE == 2) ? p.sink.partial : p.partial;
         const int ldp = (EMODE == 2) ? p.sink.ldp : p.ldp;
         __syncthreads();
@@ -611,7 +629,7 @@ static int g2_launch_nt(const G2P& p, hipStream_t st, pq_gemm_plan* plan) {
     constexpr int NA = AMODE == 2 ? 2 : 1;
     constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);
     constexpr int STAGE = NA * BM * 32 + BN * 32 + 4 * CW;
-    constexpr size_t ring0 = (size_t)S * STAGE * 4, epi = (size_t)(4 * 32 * 36 + 4 * BN) * 4;
+    constexpr size_t ring0 = (size_t)S * STAGE * 4, epi = (size_t)(4 * BN) * 4;
     constexpr size_t ring_max = ring0 + (AMODE == 3 ? (size_t)2 * G2_STAT_KMAX * 4 : 0);
     constexpr size_t bytes_max = ring_max > epi ? ring_max : epi;
     static bool ok = g2_raise_lds((const void*)gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>, bytes_max);
@@ -639,9 +657,12 @@ template <int AMODE, int EMODE>
 static int g2_dispatch_nt(const G2P& p, int bm, hipStream_t st, pq_gemm_plan* plan) {
     const int bn = g2_pick_bn(p.M, p.N, bm);
     // ring depth by LDS budget: two workgroups per CU (<= 80 KB each)
-    if (AMODE == 2) {
-        if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
-        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
+    if (EMODE == 2) {
+        // gradient sink: tiles of at most two 32 x 32 blocks per wave (the sink's operands of a whole tile are prefetched into
+        // registers; a 128 x 128 sink tile would need 288 of them: one wave per SIMD)
+        if (bm == 128) return g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
+        if (AMODE == 2) return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
+        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
     }
     if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
     return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);

@@ -49,11 +49,15 @@ def report(tag, fn, flops):
     def q(v, f):
         return v.kthvalue(max(1, int(f * n)))[0].item()
     us = lambda cyc: cyc / clk
+    t6, t7 = s[:, 6].double(), s[:, 7].double()
+    extra = ''
+    if (t6 > 0).all():
+        extra = ' | epilogue split: loads landed +%.0f, blocks stored +%.0f, statistics +%.0f' % (q((t7 - t2).clamp(min=0), .5) if (t7 > 0).all() else -1, q(t6 - torch.maximum(t7, t2), .5), q(t3 - t6, .5))
     print('%-30s wgs %5d  event %6.1f us  span %6.1f us  %5.1f TF  clk %4.0f MHz | cycles med(p90): prologue %5.0f(%5.0f) main %6.0f(%6.0f) '
           'epilogue %5.0f(%5.0f) | us: %.1f + %.1f + %.1f = %.1f per wg | starts: p50 %.1f p90 %.1f us, %d wgs started after the first ended'
           % (tag, n, ev_us, span, flops / span / 1e6, clk, q(pro, .5), q(pro, .9), q(main, .5), q(main, .9), q(epi, .5), q(epi, .9),
              us(q(pro, .5)), us(q(main, .5)), us(q(epi, .5)), us(q(pro, .5) + q(main, .5) + q(epi, .5)),
-             q(starts, .5), q(starts, .9), late), flush=True)
+             q(starts, .5), q(starts, .9), late) + extra, flush=True)
 
 
 for (M, I, O) in SHAPES:
