@@ -10,6 +10,7 @@
 // The k index inside an 8-wide group is permuted identically for A and B (lane half h owns k = 4h..4h+3), which
 // leaves the contraction unchanged.
 #include "common.h"
+#include "gemm_epi.h"
 
 namespace pq {
 
@@ -290,13 +291,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         }
     }
 
-    // ---------------------------------------------------------------- epilogue
+    // ---------------------------------------------------------------- epilogue (gemm_epi.h: the accumulators leave in their native
+    // layout -- lane = column, two 128-byte row segments per access -- without the LDS patches and per-element flag tests of round 3)
     float s1[TJ], s2[TJ];
     float mn[TJ], mx[TJ];                        // EMODE 3 only
 #pragma unroll
     for (int j = 0; j < TJ; ++j) { s1[j] = s2[j] = 0.f; mn[j] = __builtin_huge_valf(); mx[j] = -__builtin_huge_valf(); }
     bool want_stats = false;
-    bool sums_in_red = false;          // the row-major sink already left its column sums in `red`
+    EpiGeom eg;
+    eg.m0w = m0 + __builtin_amdgcn_readfirstlane(wm) * WM; eg.n0w = n0 + __builtin_amdgcn_readfirstlane(wn) * WN;
+    eg.lrow = lrow; eg.lh = lh; eg.M = M; eg.N = N;
+    eg.full = m0 + BM <= M && n0 + BN <= N;
 
     if (EMODE == 2) {
         const pq_gsink& sk = p.sink;
@@ -307,79 +312,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         const float qinv = qmask ? 1.f / sk.qstate[2] : 0.f, qzp = qmask ? sk.qstate[3] : 0.f;
         const bool need_y = sk.finalize && (sk.act != PQ_ACT_LINEAR || stats || qmask);
         want_stats = sk.finalize && stats;
-        // Row-major sink through LDS (same patch trick as the forward store): every lane then handles 4 consecutive columns of
-        // 4 rows, so the forward values y, the accumulated gradient and the result move as 16-byte accesses; the per-column
-        // BatchNorm-backward sums are folded over the 8 lanes that share a column quad.
-        const bool vec_sink = p.sub <= 1 && (N & 3) == 0 && (sk.ldg & 3) == 0 && (((uintptr_t)sk.g) & 15) == 0 &&
-                              (!need_y || ((sk.ldy & 3) == 0 && (((uintptr_t)sk.y) & 15) == 0));
-        if (vec_sink) {
-            sums_in_red = true;
-            __syncthreads();
-            float* patch = As2 + w * (32 * 36);
-            const int c4 = (lane & 7) * 4;
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int nb = n0 + wn * WN + 32 * j;
-                const int nn = nb + c4;
-                const bool nok = nn < N;                      // N % 4 == 0: a quad is inside or outside as a whole
-                const int nc = nok ? nn : 0;
-                float ca[4], cb[4], cm[4], ci[4], t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ca[u] = affine ? sk.scale[nc + u] : 1.f; cb[u] = affine ? sk.shift[nc + u] : 0.f;
-                    cm[u] = stats ? sk.mean[nc + u] : 0.f; ci[u] = stats ? sk.invstd[nc + u] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const int mb = m0 + wm * WM + 32 * i;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lrow] = acc[i][j][r];
-                    float4 yq[4], gq[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {             // all loads of the tile first
-                        const int mc = min(mb + (lane >> 3) + 8 * q, M - 1);
-                        yq[q] = need_y ? ldg4(sk.y + (size_t)mc * sk.ldy + nc) : f4zero();
-                        gq[q] = sk.accumulate ? ldg4(sk.g + (size_t)mc * sk.ldg + nc) : f4zero();
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = (lane >> 3) + 8 * q, m = mb + row;
-                        const float4 a4 = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
-                        float dz[4] = {a4.x + gq[q].x, a4.y + gq[q].y, a4.z + gq[q].z, a4.w + gq[q].w};
-                        const float yy[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w};
-                        if (need_y) {
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) dz[u] *= act_bwd(fmaf(ca[u], yy[u], cb[u]), sact);
-                            if (qmask) {
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const float qv = rintf(act_fwd(fmaf(ca[u], yy[u], cb[u]), sact) * qinv) + qzp;
-                                    dz[u] = (qv >= 0.f && qv <= 255.f) ? dz[u] : 0.f;
-                                }
-                            }
-                        }
-                        if (m < M && nok) {
-                            stg4(sk.g + (size_t)m * sk.ldg + nn, make_float4(dz[0], dz[1], dz[2], dz[3]));
-                            if (stats) {
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) { t1[u] += dz[u]; t2[u] = fmaf(dz[u], (yy[u] - cm[u]) * ci[u], t2[u]); }
-                            }
-                        }
-                    }
-                }
-                if (want_stats) {                             // fold the 8 row groups (lane bits 3..5), keep lanes 0..7
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                        for (int off = 8; off <= 32; off <<= 1) { t1[u] += __shfl_xor(t1[u], off); t2[u] += __shfl_xor(t2[u], off); }
-                        if (lane < 8) {
-                            red[(0 * 4 + wm) * 192 + wn * WN + 32 * j + c4 + u] = t1[u];
-                            red[(1 * 4 + wm) * 192 + wn * WN + 32 * j + c4 + u] = t2[u];
-                        }
-                    }
-                }
-            }
-        } else
+        if (p.sub <= 1) {
+            const SinkFlags sf = sink_flags(sk);
+            SinkCoef<TJ> sc;
+            sink_coefs<TJ>(sk, sf, eg, sc);
+            sink_epilogue<TI, TJ, 0>(acc, sk, sf, sc, eg, nullptr, nullptr, s1, s2);
+        } else          // strided 1x1 conv (RegNet projection shortcuts): output rows scatter to every sub-th pixel
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int n = n0 + wn * WN + 32 * j + lrow;
@@ -421,61 +359,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         }
     } else {
         want_stats = (EMODE == 1 || EMODE == 3) && (p.partial != nullptr || p.stat_acc != nullptr);
-        // Output tiles leave through LDS: a wave parks one 32x32 accumulator tile in its own 32x36 patch (lane = column, as the
-        // MFMA delivers it) and reads it back as rows, so the tile is written with 4 x 16-byte-per-lane stores (8 full 128-byte
-        // row segments each) instead of 16 dword stores.  Same-wave LDS traffic is ordered, no barrier inside the loop.
-        const bool vec_out = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
-        __syncthreads();                                            // every wave is done reading the operand tiles
-        float* patch = As2 + w * (32 * 36);
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int nb = n0 + wn * WN + 32 * j;
-            const int n = nb + lrow;
-            const bool nok = n < N;
-            const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int mb = m0 + wm * WM + 32 * i;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float v = acc[i][j][r] + bias;
-                    if (vec_out) patch[row * 36 + lrow] = v;
-                    else if (mb + row < M && nok) p.out[(size_t)(mb + row) * p.ldo + n] = v;
-                    if ((EMODE == 1 || EMODE == 3) && mb + row < M && nok) {
-                        s1[j] += v; s2[j] = fmaf(v, v, s2[j]);
-                        if (EMODE == 3) { mn[j] = fminf(mn[j], v); mx[j] = fmaxf(mx[j], v); }
-                    }
-                }
-                if (vec_out) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
-                        const int m = mb + row, nn = nb + c4;
-                        if (m < M && nn < N) {
-                            const float4 v4 = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
-                            float* dst = p.out + (size_t)m * p.ldo + nn;
-                            if (nn + 3 < N) stg4(dst, v4);
-                            else { const float e[4] = {v4.x, v4.y, v4.z, v4.w}; for (int u = 0; u < 4 && nn + u < N; ++u) dst[u] = e[u]; }
-                        }
-                    }
-                }
-            }
-        }
+        if (eg.full) epi_store<TI, TJ, EMODE, true>(acc, p.out, p.ldo, p.bias, eg, s1, s2, mn, mx);
+        else epi_store<TI, TJ, EMODE, false>(acc, p.out, p.ldo, p.bias, eg, s1, s2, mn, mx);
     }
 
     if (want_stats) {   // uniform across the block
         float* part = (EMODE == 2) ? p.sink.partial : p.partial;
         const int ldp = (EMODE == 2) ? p.sink.ldp : p.ldp;
-        if (!sums_in_red) {
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                s1[j] += __shfl_xor(s1[j], 32);
-                s2[j] += __shfl_xor(s2[j], 32);
-                if (lh == 0) {
-                    red[(0 * 4 + wm) * 192 + wn * WN + 32 * j + lrow] = s1[j];
-                    red[(1 * 4 + wm) * 192 + wn * WN + 32 * j + lrow] = s2[j];
-                }
+        for (int j = 0; j < TJ; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+            if (lh == 0) {
+                red[(0 * 4 + wm) * 192 + wn * WN + 32 * j + lrow] = s1[j];
+                red[(1 * 4 + wm) * 192 + wn * WN + 32 * j + lrow] = s2[j];
             }
         }
         if (EMODE == 3) {

@@ -19,8 +19,8 @@
 //   WAR  a stage is refilled only after the barrier that follows its last ds_read (whose data the MFMAs have consumed).
 //
 // mirrors: nn.Conv2d(k=1) forward / backward inside the conv blocks of the reference, model/parser.py:389-410.
-#include <type_traits>
 #include "common.h"
+#include "gemm_epi.h"
 #include "ldsdma.h"
 
 namespace pq {
@@ -73,7 +73,7 @@ struct G2P {
 // 176 / 240 / 528): the last k-tile is then half valid -- its upper four chunks of B come from g2_zero, those of A and of the
 // coefficient vectors repeat the lower four (finite values times zero), so the loop itself is unchanged.
 template <int BM, int BN, int AMODE, int EMODE, int S>
-__global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
+__global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two waves per SIMD: at most 256 registers
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
     constexpr int NA = AMODE == 2 ? 2 : 1;
     constexpr int A_FL = BM * 32, B_FL = BN * 32;
@@ -245,72 +245,29 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
     if (nk == 1) PQ_STAMP(1);
 #endif
 
-    // ---------------------------------------------------------------- epilogue
-    // The accumulators leave in their NATIVE layout: lane = output column (lrow), 16 rows per lane and 32 x 32 block,
-    // row(r) = (r & 3) + 8 * (r >> 2) + 4 * lh.  Every global access of a wave instruction is then two 128-byte row segments
-    // (full-rate dword stores / loads), there is no LDS transpose, the per-column coefficients and statistics are one value per
-    // lane, and a tile that lies inside the matrix takes a path without masks or branches (round 3's epilogue went through LDS
-    // patches and tested row / column / alignment flags per element: 6-15 k of a tile's 35-95 k cycles, scripts/gemm_stamps.py).
-    // EMODE 2, one or two blocks per wave: the gradient sink's operands (the layer input y for the activation derivative and the
-    // BatchNorm-backward sums, the running gradient of an accumulating sink) and its coefficients are requested HERE, in front of
-    // the last k-tile's MFMAs, so that their HBM round trip does not open the epilogue.
+    // ---------------------------------------------------------------- epilogue (gemm_epi.h: native accumulator layout, no LDS
+    // transpose, branch-free path for tiles inside the matrix).  EMODE 2, one or two blocks per wave: the gradient sink's operands
+    // (the layer input y for the activation derivative and the BatchNorm-backward sums, the running gradient of an accumulating
+    // sink) and its coefficients are requested HERE, in front of the last k-tile's MFMAs, so that their HBM round trip does not
+    // open the epilogue -- where every co-resident workgroup of a single-round grid would wait for the same burst at once.
     constexpr int NB = TI * TJ;
     constexpr bool HOIST = EMODE == 2 && NB <= 2;
+    EpiGeom eg;
+    eg.m0w = m0 + __builtin_amdgcn_readfirstlane(wm) * WM; eg.n0w = n0 + __builtin_amdgcn_readfirstlane(wn) * WN;
+    eg.lrow = lrow; eg.lh = lh; eg.M = M; eg.N = N;
+    eg.full = m0 + BM <= M && n0 + BN <= N;
     const pq_gsink& sk = p.sink;
-    const bool sk_affine = EMODE == 2 && sk.scale != nullptr;
-    const bool sk_stats = EMODE == 2 && sk.mean != nullptr && sk.partial != nullptr;
-    // QAT: the tensor is consumed as fake_quant(act(...)): straight-through mask of its activation observer (arithmetic of
-    // qat.hip / sink_apply4: the multiply sits inside rintf, nothing here can contract)
-    const bool qmask = EMODE == 2 && sk.finalize && sk.qstate != nullptr;
-    const bool need_y = EMODE == 2 && sk.finalize && (sk.act != PQ_ACT_LINEAR || sk_stats || qmask);
-    const bool sk_acc = EMODE == 2 && sk.accumulate;
-    const bool full = m0 + BM <= M && n0 + BN <= N;           // uniform
+    SinkFlags sf{};
+    SinkCoef<TJ> sc;
     float yv[HOIST ? NB : 1][16], gv[HOIST ? NB : 1][16];
-    float ca[TJ], cb[TJ], cm[TJ], ci[TJ];
-    auto sink_coefs = [&]() {
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int n = n0 + wn * WN + 32 * j + lrow;
-            const int nc = n < N ? n : 0;
-            ca[j] = sk_affine ? sk.scale[nc] : 1.f; cb[j] = sk_affine ? sk.shift[nc] : 0.f;
-            cm[j] = sk_stats ? sk.mean[nc] : 0.f; ci[j] = sk_stats ? sk.invstd[nc] : 0.f;
-        }
-    };
-    // Addressing of a 32 x 32 block: a wave-uniform pointer to (first row + rowc(r), first column) -- SGPR pair, SALU arithmetic --
-    // plus ONE 32-bit per-lane element offset (4 * lh rows down, lrow columns right) for all 16 accesses: no 64-bit VGPR address
-    // per row.  Tiles that stick out of the matrix clamp per lane instead (slow path, edge tiles only).
-    const int wmu = __builtin_amdgcn_readfirstlane(wm), wnu = __builtin_amdgcn_readfirstlane(wn);
-    auto urow = [&](const float* base, int ld, int i, int j, int rowc) -> const float* {
-        return base + (size_t)(m0 + wmu * WM + 32 * i + rowc) * (size_t)ld + (n0 + wnu * WN + 32 * j);
-    };
-    auto sink_block_loads = [&](auto full_c, int i, int j, float* yd, float* gd) {
-        if (decltype(full_c)::value) {
-            const unsigned oy = 4u * lh * (unsigned)sk.ldy + lrow, og = 4u * lh * (unsigned)sk.ldg + lrow;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowc = (r & 3) + 8 * (r >> 2);
-                yd[r] = need_y ? urow(sk.y, sk.ldy, i, j, rowc)[oy] : 0.f;
-                gd[r] = sk_acc ? urow(sk.g, sk.ldg, i, j, rowc)[og] : 0.f;
-            }
-        } else {
-            const int n = n0 + wn * WN + 32 * j + lrow;
-            const int nc = n < N ? n : 0;
-            const int mb = m0 + wm * WM + 32 * i + 4 * lh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mc = min(mb + (r & 3) + 8 * (r >> 2), M - 1);
-                yd[r] = need_y ? sk.y[(size_t)mc * sk.ldy + nc] : 0.f;
-                gd[r] = sk_acc ? sk.g[(size_t)mc * sk.ldg + nc] : 0.f;
-            }
-        }
-    };
     if (EMODE == 2) {
-        sink_coefs();
-        if (HOIST && full) {                       // (edge tiles load in the epilogue: their clamped per-lane addresses are not worth keeping)
+        sf = sink_flags(sk);
+        sink_coefs<TJ>(sk, sf, eg, sc);
+        if (HOIST && eg.full) {                    // (edge tiles load in the epilogue: their clamped per-lane addresses are not worth keeping)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int i = 0; i < TI; ++i) sink_block_loads(std::true_type{}, i, j, yv[HOIST ? j * TI + i : 0], gv[HOIST ? j * TI + i : 0]);
+                for (int i = 0; i < TI; ++i) sink_block_loads<true>(sk, sf, eg, i, j, yv[HOIST ? j * TI + i : 0], gv[HOIST ? j * TI + i : 0]);
         }
     }
     compute((nk - 1) % S, nk - 1);
@@ -319,83 +276,16 @@ __global__ __launch_bounds__(256) void gemm2_nt_kernel(G2P p) {
 
     float* red = lds;                              // [2][2][BN]
     bool want_stats = false;
-    float t1[TJ], t2[TJ];                          // per-column sums of this lane
+    float t1[TJ], t2[TJ], mn_[TJ], mx_[TJ];        // per-column sums of this lane
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) t1[j] = t2[j] = 0.f;
+    for (int j = 0; j < TJ; ++j) t1[j] = t2[j] = mn_[j] = mx_[j] = 0.f;
     if (EMODE == 2) {
-        const ActParam sact = act_param(sk.act);
-        const float qinv = qmask ? 1.f / sk.qstate[2] : 0.f, qzp = qmask ? sk.qstate[3] : 0.f;
-        want_stats = sk.finalize && sk_stats;
-        auto emit = [&](auto full_c, auto q_c) {
-            constexpr bool F = decltype(full_c)::value, Q = decltype(q_c)::value;
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int n = n0 + wn * WN + 32 * j + lrow;
-                const bool nok = F || n < N;
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const int mb = m0 + wm * WM + 32 * i + 4 * lh;
-                    float yl[16], gl[16];
-                    constexpr bool PRE = HOIST && F;           // this block's operands were requested in front of the last k-tile
-                    if (!PRE) sink_block_loads(full_c, i, j, yl, gl);
-                    const float* yy = PRE ? yv[PRE ? j * TI + i : 0] : yl;
-                    const float* gg = PRE ? gv[PRE ? j * TI + i : 0] : gl;
-                    float* dst = sk.g + (size_t)mb * sk.ldg + n;
-                    const unsigned og = 4u * lh * (unsigned)sk.ldg + lrow;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2);
-                        float dz = acc[i][j][r] + gg[r];
-                        const float uu = fmaf(ca[j], yy[r], cb[j]);
-                        dz *= need_y ? act_bwd(uu, sact) : 1.f;
-                        if (Q) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz = (qv >= 0.f && qv <= 255.f) ? dz : 0.f; }
-                        if (F) const_cast<float*>(urow(sk.g, sk.ldg, i, j, row))[og] = dz;
-                        else if (mb + row < M && nok) dst[(size_t)row * sk.ldg] = dz;
-                        if (F || (mb + row < M && nok)) {
-                            t1[j] += dz;
-                            t2[j] = fmaf(dz, (yy[r] - cm[j]) * ci[j], t2[j]);
-                        }
-                    }
-                    if (!PRE) __builtin_amdgcn_sched_barrier(0);        // one block's operands live at a time
-                }
-            }
-        };
-        if (qmask) { if (full) emit(std::true_type{}, std::true_type{}); else emit(std::false_type{}, std::true_type{}); }
-        else if (full) emit(std::true_type{}, std::false_type{});
-        else emit(std::false_type{}, std::false_type{});
+        want_stats = sk.finalize && sf.stats;
+        sink_epilogue<TI, TJ, HOIST ? NB : 0>(acc, sk, sf, sc, eg, yv, gv, t1, t2);
     } else {
         want_stats = (EMODE == 1) && (p.partial != nullptr || p.stat_acc != nullptr);
-        float bias[TJ];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int n = n0 + wn * WN + 32 * j + lrow;
-            bias[j] = (p.bias != nullptr && n < N) ? p.bias[n] : 0.f;
-        }
-        auto emit = [&](auto full_c) {
-            constexpr bool F = decltype(full_c)::value;
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int n = n0 + wn * WN + 32 * j + lrow;
-                const bool nok = F || n < N;
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const int mb = m0 + wm * WM + 32 * i + 4 * lh;
-                    float* dst = p.out + (size_t)mb * p.ldo + n;
-                    const unsigned oo = 4u * lh * (unsigned)p.ldo + lrow;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2);
-                        const float v = acc[i][j][r] + bias[j];
-                        if (F) const_cast<float*>(urow(p.out, p.ldo, i, j, row))[oo] = v;
-                        else if (mb + row < M && nok) dst[(size_t)row * p.ldo] = v;
-                        if (F || (mb + row < M && nok)) {
-                            if (EMODE == 1) { t1[j] += v; t2[j] = fmaf(v, v, t2[j]); }
-                        }
-                    }
-                }
-            }
-        };
-        if (full) emit(std::true_type{}); else emit(std::false_type{});
+        if (eg.full) epi_store<TI, TJ, EMODE, true>(acc, p.out, p.ldo, p.bias, eg, t1, t2, mn_, mx_);
+        else epi_store<TI, TJ, EMODE, false>(acc, p.out, p.ldo, p.bias, eg, t1, t2, mn_, mx_);
     }
     if (want_stats) {   // uniform across the block
 #pragma unroll
@@ -657,15 +547,16 @@ template <int AMODE, int EMODE>
 static int g2_dispatch_nt(const G2P& p, int bm, hipStream_t st, pq_gemm_plan* plan) {
     const int bn = g2_pick_bn(p.M, p.N, bm);
     // ring depth by LDS budget: two workgroups per CU (<= 80 KB each)
-    if (EMODE == 2) {
+    if constexpr (EMODE == 2) {
         // gradient sink: tiles of at most two 32 x 32 blocks per wave (the sink's operands of a whole tile are prefetched into
         // registers; a 128 x 128 sink tile would need 288 of them: one wave per SIMD)
         if (bm == 128) return g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
         if (AMODE == 2) return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
         return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
+    } else {
+        if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
+        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
     }
-    if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
-    return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
 }
 
 static bool act_clamp(int act, float& lo, float& hi) {
