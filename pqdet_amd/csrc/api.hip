@@ -174,7 +174,11 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
         }
         return PQ_OK;
     };
+    // place-holder slots the plan left behind (a fill of zero elements on the main stream: e.g. a BatchNorm finalize whose work a
+    // neighbouring kernel took over) are invisible: nothing is launched for them and the fork look-ahead reads through them
+    auto is_nop = [&](int k) { return ops[k].code == PQ_OP_FILL && ops[k].flags == 0 && ops[k].u.fill.n == 0; };
     for (int i = 0; i < n; ++i) {
+        if (is_nop(i)) continue;
         if (ops[i].flags & PQ_OPF_SIDE) {
             parked[nparked++] = i;
             side_dirty = true;
@@ -184,7 +188,9 @@ static int run_ops2_impl(const pq_op* ops, int32_t n, void* stream, void* side_s
         }
         if (ops[i].flags & PQ_OPF_JOIN) { const int rc = join(); if (rc != PQ_OK) return rc; }
         // the op after this one releases the parked group: offer the fork event to this op's kernel launch
-        const bool forks_next = bind && i + 1 < n && (ops[i + 1].flags & PQ_OPF_SIDE) && !(ops[i + 1].flags & (PQ_OPF_LAZY | PQ_OPF_NOFORK)) && nparked + 1 >= group;
+        int nx = i + 1;
+        while (nx < n && is_nop(nx)) ++nx;
+        const bool forks_next = bind && nx < n && (ops[nx].flags & PQ_OPF_SIDE) && !(ops[nx].flags & (PQ_OPF_LAZY | PQ_OPF_NOFORK)) && nparked + 1 >= group;
         bound = nullptr;
         if (forks_next) g_stop_event = ev[next];
         const int rc = run_one(ops[i], stream);

@@ -707,22 +707,22 @@ static void launch_nt(const GemmP& p, hipStream_t st, int bm, pq_gemm_plan* plan
     dim3 grid((p.N + t.bn - 1) / t.bn, (p.M + t.bm - 1) / t.bm);
     if (t.kind == 0) {
         switch (t.idx) {
-            case 0: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, AMODE, BKN, EMODE, true, 1>), grid, blk, 0, st, p); break;
-            case 1: hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 64, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
-            case 2: hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
-            default: hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
+            case 0: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 128, 64, 64, AMODE, BKN, EMODE, true, 1>), grid, blk, 0, st, p); break;
+            case 1: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 64, 64, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
+            case 2: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<64, 64, 32, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
+            default: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE, true, 2>), grid, blk, 0, st, p); break;
         }
     } else {
         switch (t.idx) {
-            case 1: hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
-            case 2: hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 32, 64, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
-            case 3: hipLaunchKernelGGL((gemm_nt_kernel<128, 96, 32, 96, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
-            case 4: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 32, 128, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
-            case 5: hipLaunchKernelGGL((gemm_nt_kernel<128, 160, 32, 160, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 1: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 32, 32, 32, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 2: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 64, 32, 64, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 3: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 96, 32, 96, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 4: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 128, 32, 128, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
+            case 5: PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 160, 32, 160, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p); break;
             default:
                 // (never reached with a gradient sink, see above: not instantiated either -- tests/test_codeobj.py asserts that no kernel
                 // of the library has a private segment)
-                if constexpr (EMODE != 2) hipLaunchKernelGGL((gemm_nt_kernel<128, 192, 32, 192, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p);
+                if constexpr (EMODE != 2) PQ_LAUNCH_BINDABLE((gemm_nt_kernel<128, 192, 32, 192, AMODE, BKN, EMODE, false>), grid, blk, 0, st, p);
                 break;
         }
     }

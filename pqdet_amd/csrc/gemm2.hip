@@ -529,7 +529,7 @@ static int g2_launch_nt(const G2P& p, hipStream_t st, pq_gemm_plan* plan) {
     const size_t ring = ring0 + (AMODE == 3 ? (size_t)2 * ((p.K + 31) / 32 * 32) * 4 : 0);
     const size_t bytes = ring > epi ? ring : epi;
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>), grid, dim3(256), bytes, st, p);
+    PQ_LAUNCH_BINDABLE((gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>), grid, dim3(256), bytes, st, p);
     return PQ_OK;
 }
 
