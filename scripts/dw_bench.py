@@ -29,10 +29,9 @@ for (B, H, W, Cc, s) in SHAPES:
     sc = torch.empty(max(l.pq_dw3x3_wgrad_scratch_bytes(B, OH, OW, Cc), l.pq_dw3x3_bwd_walk_blocks(B, H, W, Cc, s) * Cc * 9 * 4) // 4 + 16, device=dev)
     d = abi.DwDgrad(gs, w.data_ptr(), sink, B, H, W, OH, OW, Cc, s)
     wg = abi.DwWgrad(gs, src, dw.data_ptr(), sc.data_ptr(), B, H, W, OH, OW, Cc, s)
-    fb = abi.DwBwd(gs, src, w.data_ptr(), sink, dw.data_ptr(), sc.data_ptr(), B, H, W, OH, OW, Cc, s)
     t1 = timeit(lambda: abi.check(l.pq_dw3x3_dgrad(C.byref(d), st)))
     t2 = timeit(lambda: abi.check(l.pq_dw3x3_wgrad(C.byref(wg), st)))
-    t3 = timeit(lambda: abi.check(l.pq_dw3x3_bwd(C.byref(fb), st)))
+    t3 = 0.0
     nbw = l.pq_dw3x3_bwd_walk_blocks(B, H, W, Cc, s)
     partw = torch.empty(nbw * 2 * Cc, device=dev); scw = torch.empty(nbw * Cc * 9 + 16, device=dev)
     sinkw = abi.GSink(gin.data_ptr(), x.data_ptr(), a.data_ptr(), b2.data_ptr(), mn.data_ptr(), iv.data_ptr(), partw.data_ptr(), Cc, Cc, 2, 0, 1, Cc)
@@ -42,8 +41,8 @@ for (B, H, W, Cc, s) in SHAPES:
     t6 = timeit(lambda: abi.check(l.pq_dw3x3_bwd(C.byref(f6), st)))
     byt = 4.0 * (B * H * W * Cc * 2 + B * OH * OW * Cc * 2)     # minimal: g, y_out, y_in read + g_in written
     tot[0] += t1; tot[1] += t2; tot[2] += t3; tot[3] += t5; tot[4] += t6
-    print('B=%d %dx%d C=%d s=%d | dgrad %.3f wgrad %.3f sum %.3f | fused tiled %.3f ms | walking %.3f ms (%.0f GB/s of minimal traffic, %d workgroup rows) + reduce %.3f' % (
-        B, H, W, Cc, s, t1, t2, t1 + t2, t3, t5, byt / t5 / 1e6, nbw, t6), flush=True)
+    print('B=%d %dx%d C=%d s=%d | dgrad %.3f wgrad %.3f sum %.3f |%s walking %.3f ms (%.0f GB/s of minimal traffic, %d workgroup rows) + reduce %.3f' % (
+        B, H, W, Cc, s, t1, t2, t1 + t2, '', t5, byt / t5 / 1e6, nbw, t6), flush=True)
 print('sum dgrad %.3f wgrad %.3f fused tiled %.3f walking %.3f + reduce %.3f' % tuple(tot))
 if os.environ.get('BWD_ONLY'): sys.exit(0)
 
