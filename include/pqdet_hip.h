@@ -449,6 +449,11 @@ int32_t pq_bn_bstat_ok(int32_t code, const void* args, int32_t role);
 /* bytes of a pq_bn_stat.acc for C channels with pitch ldp and `slots` replicas, and the replica count to use for nblk row blocks */
 int64_t pq_bn_stat_bytes(int32_t ldp, int32_t slots);
 int32_t pq_bn_stat_slots(int32_t nblk);
+/* At most 4096 partials may be added into ONE slot of an accumulator (the low limb of the fixed-point image is read back as a
+ * signed 64-bit integer): every entry point that takes stat_acc / dx_stat_acc checks its own row-block count / slots against that
+ * and returns PQ_EUNSUPPORTED beyond it.  Test hook: values[i] is added as the partial of row block i (plane 0, channel 0) with
+ * exactly the producers' arithmetic; acc ([slots][2][ldp][2] int64) and *bad must be zero before. */
+int pq_bn_stat_selftest(const float* values, int32_t n, int32_t slots, int32_t ldp, int64_t* acc, uint32_t* bad, void* stream);
 int32_t pq_bn_finalize_tickets(int32_t C);
 
 /* ------------------------------------------------------------------ shortcut / route / upsample

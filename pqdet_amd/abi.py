@@ -322,6 +322,7 @@ SIGNATURES = {
     'pq_bn_finalize_scratch_bytes': (i64, [i32]),
     'pq_bn_finalize_tickets': (i32, [i32]),
     'pq_bn_stat_ok': (i32, [i32, C.c_void_p, i32]),
+    'pq_bn_stat_selftest': (C.c_int, [C.c_void_p, i32, i32, i32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pq_bn_bstat_ok': (i32, [i32, C.c_void_p, i32]),
     'pq_bn_stat_bytes': (i64, [i32, i32]),
     'pq_bn_stat_slots': (i32, [i32]),

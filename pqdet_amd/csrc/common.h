@@ -47,6 +47,11 @@ inline bool act_is_special(int act) { return act == PQ_ACT_LOGISTIC || act == PQ
 // fraction bits, high limb = floor(v)).  Integer addition is associative, so the accumulated value does not depend on the
 // arrival order; bits of v below 2^-50 are dropped (|error| < 1e-15 per partial, the same for every order).
 constexpr float PQ_STAT_MAX = 5.0e14f;         // |v| < 2^49: 8192 partials of that size still fit the high limb
+// The LOW limb takes up to 2^50 - 1 per partial and is read back as a signed 64-bit integer: at most PQ_STAT_MAX_ADDS partials may land
+// in one slot (4096 x 2^50 = 2^62).  Every entry point that accepts accumulators checks its own row-block count against it
+// (stat_adds_ok); the engine stays far below (<= 640 row blocks per layer).
+constexpr int PQ_STAT_MAX_ADDS = 4096;
+inline bool stat_adds_ok(long nblk, int slots) { return (nblk + (slots > 0 ? slots : 1) - 1) / (slots > 0 ? slots : 1) <= PQ_STAT_MAX_ADDS; }
 __device__ __forceinline__ void bn_stat_add(int64_t* acc, uint32_t* bad, int slots, int ldp, int blk, int plane, int c, float v) {
     if (!(fabsf(v) < PQ_STAT_MAX)) { atomicOr(bad, 1u); return; }          // NaN / Inf / absurd: poison the layer (NaN statistics)
     unsigned long long* d = reinterpret_cast<unsigned long long*>(acc + (((size_t)(blk % slots) * 2 + plane) * ldp + c) * 2);

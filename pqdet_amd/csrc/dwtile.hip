@@ -214,6 +214,7 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     if (act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     if (dw_fwd_use_walk(a->stride)) {
         PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->minmax == 0 && a->ldp >= a->C), "stat_acc needs stat_bad, no minmax");
+        PQ_CHECK_ARG(a->stat_acc == nullptr || stat_adds_ok(pq_dw3x3_fwd_blocks(a->B, a->OH, a->OW, a->C, a->stride), a->stat_slots), "too many row blocks per accumulator slot");
         const int rc = dw_fwd_walk_launch(a, stream);
         if (rc != PQ_OK) return rc;
         PQ_CHECK_LAUNCH();
@@ -228,6 +229,7 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.C = a->C; p.C4 = (a->C + 3) / 4;
     p.minmax = (a->partial && a->minmax) ? 1 : 0;
     PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->minmax == 0 && a->ldp >= a->C), "stat_acc needs stat_bad, no minmax");
+    PQ_CHECK_ARG(a->stat_acc == nullptr || stat_adds_ok(pq_dw3x3_fwd_blocks(a->B, a->OH, a->OW, a->C, a->stride), a->stat_slots), "too many row blocks per accumulator slot");
     p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
     fwd_tiles(a->OH, a->OW, a->stride, p.tilesH, p.tilesW);
     dim3 grid(a->B * p.tilesH * p.tilesW, (p.C4 + CBQ - 1) / CBQ), blk(256);

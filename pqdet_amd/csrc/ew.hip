@@ -558,6 +558,19 @@ extern "C" int pq_bn_eval_batch(const pq_bn_eval_args* a, void* stream) {
     return PQ_OK;
 }
 
+// test hook: thread i adds values[i] as the partial of row block i (plane 0, channel 0) -- the producers' bn_stat_add, nothing else
+__global__ void bn_stat_selftest_kernel(const float* v, int n, int64_t* acc, uint32_t* bad, int slots, int ldp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bn_stat_add(acc, bad, slots, ldp, i, 0, 0, v[i]);
+}
+extern "C" int pq_bn_stat_selftest(const float* values, int32_t n, int32_t slots, int32_t ldp, int64_t* acc, uint32_t* bad, void* stream) {
+    PQ_CHECK_ARG(values && acc && bad && n > 0 && slots >= 1 && slots <= 4 && ldp >= 1, "bad arguments");
+    if (!stat_adds_ok(n, slots)) { pq_set_error("pq_bn_stat_selftest: more than %d partials per accumulator slot", PQ_STAT_MAX_ADDS); return PQ_EUNSUPPORTED; }
+    hipLaunchKernelGGL(bn_stat_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, values, n, acc, bad, slots, ldp);
+    PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
 extern "C" int pq_bn_bwd_finalize(const pq_bn_bwd_finalize_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->partial && a->gamma && a->invstd && a->dgamma && a->dbeta && a->p && a->q && a->r, "null pointer");
     PQ_CHECK_ARG(a->C > 0 && a->nblk > 0 && a->count > 0.f, "empty");

@@ -652,6 +652,7 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
     PQ_CHECK_ARG((a->in.ld & 3) == 0, "input pitch must be a multiple of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_gconv3x3_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->ldp >= a->C), "stat_acc needs stat_bad");
+    PQ_CHECK_ARG(a->stat_acc == nullptr || stat_adds_ok(pq_gconv3x3_blocks(a->B, a->OH, a->OW), a->stat_slots), "too many row blocks per accumulator slot");
     PQ_CHECK_ARG(a->in.stat.acc == nullptr || !a->in.qstate, "the statistics hand-over has no QAT path");
     GcP p{};
     p.in = a->in; p.grad = 0; p.up = 0; p.w = a->w; p.wmode = 0; p.out = a->out; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;

@@ -743,6 +743,10 @@ static int conv1x1_fwd_impl(const pq_conv1x1_fwd_args* a, void* stream, pq_gemm_
     p.out = a->out; p.bias = a->bias; p.partial = a->partial; p.ldo = a->ldo; p.ldp = a->ldp;
     p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
     PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->minmax == 0 && a->ldp >= a->O), "stat_acc needs stat_bad, no minmax");
+    if (a->stat_acc && !stat_adds_ok(pq_conv1x1_blocks_k(a->M, a->O, a->I, 0), a->stat_slots)) {
+        pq_set_error("pq_conv1x1_fwd: more than %d row blocks per accumulator slot (use `partial` rows + pq_bn_fwd_finalize)", PQ_STAT_MAX_ADDS);
+        return PQ_EUNSUPPORTED;
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool xform = a->in.scale != nullptr || a->in.act != PQ_ACT_LINEAR || a->in.qstate != nullptr;
     const int bm = row_bm(a->M, a->O, a->I, 0);
@@ -806,6 +810,10 @@ static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_g
     if (a->dx_stat_acc) {     // the sink's BatchNorm-backward sums go to accumulators (pq_bn_bstat), not to rows
         PQ_CHECK_ARG(a->dx_stat_bad && a->sub <= 1 && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx_stat_slots <= 4,
                      "dx_stat_acc needs dx_stat_bad, sub == 1 and a finalising sink with statistics");
+        if (!stat_adds_ok(pq_conv1x1_blocks_k(a->M, a->I, a->O, 1), a->dx_stat_slots)) {
+            pq_set_error("pq_conv1x1_dgrad: more than %d row blocks per accumulator slot (use `partial` rows + pq_bn_bwd_finalize)", PQ_STAT_MAX_ADDS);
+            return PQ_EUNSUPPORTED;
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     const int bm = row_bm(a->M, a->I, a->O, 1);

@@ -427,6 +427,10 @@ extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
         PQ_CHECK_ARG(a->dx_stat_bad && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx_stat_slots <= 4,
                      "dx_stat_acc needs dx_stat_bad and a finalising sink with statistics");
         p.stat_acc = a->dx_stat_acc; p.stat_bad = a->dx_stat_bad; p.stat_slots = a->dx_stat_slots > 0 ? a->dx_stat_slots : 1;
+        if (!stat_adds_ok(pl.grid, p.stat_slots)) {
+            pq_set_error("pq_conv1x1_bwd: more than %d workgroups per accumulator slot", PQ_STAT_MAX_ADDS);
+            return PQ_EUNSUPPORTED;
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     const int i16 = (a->I + 15) / 16;

@@ -110,7 +110,13 @@ def main(argv=None) -> int:
     sys.path.insert(0, os.path.dirname(os.path.abspath(ns.script)))
     # a driver that raises (or exits non-zero) must NOT enter the closing barrier: its peers are inside other collectives and
     # would never match it; this rank exits non-zero instead and the parent ends the job (wait_ranks)
-    runpy.run_path(ns.script, run_name='__main__')
+    # (a driver that ends with sys.exit(0) / sys.exit(main()) returning 0 is a clean end: it falls through to the barrier like a
+    # script that simply runs off its last line)
+    try:
+        runpy.run_path(ns.script, run_name='__main__')
+    except SystemExit as e:
+        if e.code not in (None, 0):
+            raise
     if world > 1:
         import torch.distributed as dist
         if dist.is_initialized():

@@ -438,3 +438,53 @@ def test_dgrad_sink_to_walking_depthwise_backward_handover(B, H, W, Cc, O2, stri
     K.close(dw1, dw0, rt=1e-5, at=1e-6 * float(dw0.abs().max()), what='depthwise weight gradient')
     K.close(s1.view(nbw, 2, ldp)[:, :, :Cc].sum(0), s0.view(nbw, 2, ldp)[:, :, :Cc].sum(0), rt=1e-5,
             at=1e-5 * float(s0.view(nbw, 2, ldp)[:, :, :Cc].sum(0).abs().max()), what='statistic rows of the input gradient')
+
+
+# ---- the fixed-point image of the statistics accumulators at its limits (the low limb is read back signed)
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['max_magnitude_4096', 'tiny_negative', 'mixed', 'poison'])
+def test_stat_accumulator_image_at_the_limits(case):
+    import math
+    from fractions import Fraction
+    l = abi.lib()
+    g = torch.Generator().manual_seed(7)
+    slots, ldp = (1, 16)
+    if case == 'max_magnitude_4096':
+        v = torch.full((4096,), 4.9e14)                       # |v| < 2^49, the most one slot may take
+    elif case == 'tiny_negative':
+        v = -torch.rand(1000, generator=g) * 1e-18            # floor(v) = -1, fraction rounds to 2^50: image = 0 (error < 2^-50 each)
+    elif case == 'mixed':
+        slots = 4
+        v = (torch.rand(16384, generator=g) - 0.5) * torch.pow(10.0, torch.randint(-6, 12, (16384,), generator=g).float())
+    else:
+        v = torch.tensor([1.0, float('nan'), 2.0, float('inf'), 6.0e14])
+    vd = v.to(DEV)
+    acc = torch.zeros(slots * 2 * ldp * 2, dtype=torch.int64, device=DEV)
+    bad = torch.zeros(16, dtype=torch.int32, device=DEV)
+    abi.check(l.pq_bn_stat_selftest(vd.data_ptr(), v.numel(), slots, ldp, acc.data_ptr(), bad.data_ptr(), K.stream()))
+    torch.cuda.synchronize()
+    a = acc.view(slots, 2, ldp, 2)[:, 0, 0, :].cpu()          # plane 0, channel 0: (lo, hi) per slot
+    lo, hi = int(a[:, 0].sum()), int(a[:, 1].sum())
+    assert all(int(x) >= 0 for x in a[:, 0]), 'a low limb went negative (overflow)'
+    got = Fraction(hi) + Fraction(lo, 2 ** 50)
+    if case == 'poison':
+        assert int(bad[0]) == 1
+        assert got == Fraction(3)                              # the finite, in-range partials were still added
+        return
+    assert int(bad[0]) == 0
+    exact = sum(Fraction(float(x)) for x in v)
+    assert abs(got - exact) <= Fraction(v.numel(), 2 ** 50), (float(got), float(exact))
+    if case == 'max_magnitude_4096':
+        assert got == exact
+    # one partial more than a slot may take is refused
+    big = torch.zeros(4097, device=DEV)
+    assert l.pq_bn_stat_selftest(big.data_ptr(), 4097, 1, ldp, acc.data_ptr(), bad.data_ptr(), K.stream()) != 0
+    assert b'4096' in l.pq_last_error()
+    if case == 'max_magnitude_4096':
+        # ... and so is a producer whose launch would add more row blocks than that into one slot
+        M, I, O = 128 * 4097, 16, 16
+        x = torch.zeros(M, I, device=DEV); w = torch.zeros(O, I, device=DEV); y = torch.empty(M, O, device=DEV)
+        assert l.pq_conv1x1_blocks_k(M, O, I, 0) > 4096
+        a = abi.Conv1x1Fwd(abi.Src(x.data_ptr(), None, None, I, 0), w.data_ptr(), None, y.data_ptr(), None, M, I, O, O, 16, 1, 0, 0, 0, 0, 0,
+                           acc.data_ptr(), bad.data_ptr(), 1)
+        assert l.pq_conv1x1_fwd(C.byref(a), K.stream()) != 0 and b'row blocks per accumulator slot' in l.pq_last_error()

@@ -40,3 +40,30 @@ def test_wait_ranks_returns_first_failure_and_terminates_the_rest():
     assert sleeper.poll() is not None and time.monotonic() - t0 < 60
     ok = [subprocess.Popen([sys.executable, '-c', 'pass']) for _ in range(2)]
     assert wait_ranks(ok) == 0
+
+
+CLEAN_EXIT_DRIVER = '''
+import os, sys, time
+import torch.distributed as dist
+dist.barrier()
+if int(os.environ['RANK']) == 0:
+    sys.exit(0)              # one rank ends through SystemExit(0), the other runs off its last line a little later
+time.sleep(1.0)
+print('rank 1 done')
+'''
+
+
+def test_clean_sys_exit_still_reaches_the_closing_barrier(tmp_path):
+    """ADVICE r3: sys.exit(0) in the driver is a clean end -- the rank must still enter the closing barrier and destroy its
+    process group, or a peer that ends later waits for it until the rendezvous times out."""
+    script = tmp_path / 'driver.py'
+    script.write_text(CLEAN_EXIT_DRIVER)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    env['CUDA_VISIBLE_DEVICES'] = env['HIP_VISIBLE_DEVICES'] = ''
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, '-m', 'pqdet_amd.launch', '--nproc', '2', '--backend', 'gloo', str(script)], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert 'rank 1 done' in p.stdout
+    assert time.monotonic() - t0 < 120

@@ -520,3 +520,46 @@ def test_nan_trap_raises_once_and_recovers(monkeypatch, mapped):
         assert torch.isfinite(out['loss']).all()
     plan = list(net._plans.values())[0]
     assert (plan.nan_host is not None) == (mapped == '1')
+
+
+def _two_head_cfg():
+    """mobilenetv2-fpn without its stride-8 level: the cfg text up to (and including) the second [yolo] section."""
+    text = _cfg_text('mobilenetv2-fpn')
+    cut = [i for i in range(len(text)) if text.startswith('[yolo]', i)][1]
+    end = text.find('\n[', cut + 1)
+    return text[:end + 1] if end > 0 else text
+
+
+@pytest.mark.parametrize('heads', [3, 2])
+def test_one_launch_loss_gradients_equal_the_per_head_launches(heads, monkeypatch):
+    """pq_yolo_loss_args.also (PQ_LOSS_FUSE, default on): the gradients of all detection heads come out of the first head's
+    launch.  Same plan with one launch per head (PQ_LOSS_FUSE=0) on a second replica: bit-equal head gradients, hence bit-equal
+    parameter gradients."""
+    from pqdet_amd import abi
+    text = _cfg_text('mobilenetv2-fpn') if heads == 3 else _two_head_cfg()
+    x = seeded_images(2, 96, 128, 9)
+    tgt = _targets(2, 96, 128, 20, seed=5)
+    grads, head_grads = [], []
+    sd = None
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('PQ_LOSS_FUSE', fuse)
+        net = DetectionModel(io.StringIO(text)).to(DEV)
+        if sd is None:
+            seeded_fill(net, 11)
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+        else:
+            net.load_state_dict(sd)
+        net.train()
+        out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+        out['loss'].mean().backward()
+        plan = next(iter(net._plans.values()))
+        n_loss_ops = sum(1 for op in plan.bwd if op.code == abi.OP_LOSS_BWD)
+        assert n_loss_ops == (1 if fuse == '1' else heads), (fuse, n_loss_ops)
+        assert sum(1 for m in net.module_list if m._type == 'yolo') == heads
+        head_grads.append([plan.tensors[i].grad.clone() for i, m in enumerate(net.module_list) if m._type == 'yolo'])
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters()})
+        del net
+    for a, b in zip(*head_grads):
+        assert torch.equal(a, b)
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
