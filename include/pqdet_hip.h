@@ -629,6 +629,10 @@ typedef struct pq_nms_args {
     int32_t* img;        /* [cap] image index per kept row (B > 1), else NULL */
 } pq_nms_args;
 int pq_nms(const pq_nms_args* a, void* stream);
+/* which sort the calling thread's last pq_nms call took: 0 = one workgroup for the whole call (capacity <= 8192), 1 = one
+ * workgroup per image (batched call, capacity <= 8192 per image: the kept rows then come GROUPED BY IMAGE, descending score inside
+ * an image), 2 = the library radix sorts (rows of a batch in descending score order across images) */
+int32_t pq_nms_last_path(void);
 int64_t pq_nms_scratch_bytes(int32_t N, int32_t C);
 int64_t pq_nms_batch_scratch_bytes(int32_t B, int32_t N, int32_t C);
 

@@ -351,6 +351,7 @@ SIGNATURES = {
     'pq_fill': (C.c_int, [c_fp, f32, i64, C.c_void_p]),
     'pq_recover': (C.c_int, [C.POINTER(Recover), C.c_void_p]),
     'pq_create_label': (C.c_int, [C.POINTER(CreateLabel), C.c_void_p]),
+    'pq_nms_last_path': (i32, []),
     'pq_nms': (C.c_int, [C.POINTER(Nms), C.c_void_p]),
     'pq_nms_scratch_bytes': (i64, [i32, i32]),
     'pq_nms_batch_scratch_bytes': (i64, [i32, i32, i32]),

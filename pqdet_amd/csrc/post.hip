@@ -342,6 +342,61 @@ __global__ __launch_bounds__(1024) void nms_sort_small_kernel(const float* keys0
     }
 }
 
+// The same for a BATCHED call whose images have at most NMS_SMALL_MAX candidates each: one workgroup per image sorts that image's
+// segment of the (image-major) candidate list in its own LDS -- the suppression is per image anyway.  Positions stay global
+// (rk1 holds indices into keys1 / vals1 of the whole call), so every later stage is unchanged; the kept rows then come grouped by
+// image, in descending score order inside an image.  An image with more candidates than that poisons the call (count = -1, the
+// caller's overflow path), its segment is passed through unsorted so that every index stays in range.
+__global__ __launch_bounds__(1024) void nms_sort_seg_kernel(const float* keys0, const unsigned* vals0, int S, int C, int NC, int nimg,
+                                                             NmsMeta* meta, float* keys1, unsigned* vals1, unsigned* rk1, unsigned* offs) {
+    extern __shared__ unsigned long long sk[];
+    __shared__ int s_lo, s_hi;
+    const int t = threadIdx.x, nt = blockDim.x, b = blockIdx.x, B = gridDim.x;
+    const int K = (int)meta->count;
+    if (t < 2) {                                     // this image's candidates: pair indices in [b, b + 1) * nimg * C (vals0 ascending)
+        const unsigned long long want = (unsigned long long)(b + t) * (unsigned long long)nimg * (unsigned long long)C;
+        int lo = 0, hi = K;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((unsigned long long)vals0[mid] < want) lo = mid + 1; else hi = mid; }
+        if (t == 0) s_lo = lo; else s_hi = lo;
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi, n = hi - lo;
+    if (b == 0)
+        for (int i = K + t; i < S; i += nt) { keys1[i] = keys0[i]; vals1[i] = vals0[i]; rk1[i] = (unsigned)i; }     // fill, already in place
+    if (n > NMS_SMALL_MAX) {                         // uniform
+        if (t == 0) atomicOr(&meta->pad, 1u);
+        for (int i = lo + t; i < hi; i += nt) { keys1[i] = keys0[i]; vals1[i] = vals0[i]; rk1[i] = (unsigned)i; }
+        for (int c = t; c < C; c += nt) offs[b * C + c] = (unsigned)lo;
+        if (b == B - 1 && t == 0) offs[NC] = (unsigned)K;
+        return;
+    }
+    int Q = 64;
+    while (Q < n) Q <<= 1;
+    for (int i = t; i < Q; i += nt)
+        sk[i] = i < n ? ((unsigned long long)(~f2ord(keys0[lo + i])) << 32) | (unsigned long long)vals0[lo + i] : ~0ull;
+    bitonic_sort_lds(sk, Q, t, nt);
+    for (int i = t; i < Q; i += nt) {
+        const unsigned long long v = sk[i];
+        unsigned long long k2 = ~0ull;
+        if (i < n) {
+            const unsigned e = (unsigned)v;
+            keys1[lo + i] = ord2f(~(unsigned)(v >> 32));
+            vals1[lo + i] = e;
+            k2 = ((unsigned long long)(e % (unsigned)C) << 32) | (unsigned long long)(unsigned)i;       // (class, score rank in the image)
+        }
+        sk[i] = k2;
+    }
+    bitonic_sort_lds(sk, Q, t, nt);
+    for (int i = t; i < n; i += nt) rk1[lo + i] = (unsigned)lo + (unsigned)sk[i];
+    for (int c = t; c < C; c += nt) {                // first position of class c of this image (global)
+        const unsigned long long want = (unsigned long long)(unsigned)c << 32;
+        int l2 = 0, h2 = n;
+        while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (sk[mid] < want) l2 = mid + 1; else h2 = mid; }
+        offs[b * C + c] = (unsigned)(lo + l2);
+    }
+    if (b == B - 1 && t == 0) offs[NC] = (unsigned)K;
+}
+
 __device__ __forceinline__ bool nms_overlap(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2,
                                             float by2, float barea, float thr) {
     const float w = fmaxf(0.f, fminf(ax2, bx2) - fmaxf(ax1, bx1));
@@ -358,7 +413,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* bboxes, in
     __shared__ unsigned s_nk;
     const int c = blockIdx.x;
     const unsigned beg = offs[c], end = offs[c + 1];
-    if (beg == end || meta->greedy == 0u) return;                           // the bit-mask path below handles this call
+    if (beg == end || meta->greedy != 1u) return;                           // 0: the bit-mask path below handles this call; 2: nothing does
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float off = (float)(c % C) * (ord2f(maxb[c / C]) + 1.f);          // blockIdx = image * C + class
     float* kept = keptbuf + (size_t)beg * 5;
@@ -433,6 +488,11 @@ struct NmsMaskPlan { unsigned* tp; unsigned long long* wp; unsigned long long* m
 
 __global__ void nms_mask_plan_kernel(const unsigned* offs, int NC, NmsMaskPlan pl, NmsMeta* meta) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (meta->pad) {                                        // candidate capacity exceeded: the result is discarded (count = -1), and the
+        for (int c = 0; c <= NC; ++c) { pl.tp[c] = 0u; pl.wp[c] = 0ull; }      // segments may be unsorted pass-through: no suppression
+        meta->greedy = 2u;                                  // stage touches them
+        return;
+    }
     unsigned long long words = 0;
     unsigned tiles = 0;
     bool fits = true;
@@ -651,6 +711,11 @@ extern "C" int64_t pq_nms_batch_scratch_bytes(int32_t B, int32_t N, int32_t C) {
     return (int64_t)(L.total + (size_t)E * 24 + (8u << 20));
 }
 
+static thread_local int g_nms_path = -1;
+// which sort the calling thread's last pq_nms took: 0 = one workgroup for the whole call, 1 = one workgroup per image (batch),
+// 2 = the library radix sorts (tests assert the path they mean to cover)
+extern "C" int32_t pq_nms_last_path(void) { return g_nms_path; }
+
 extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->bboxes && a->dets && a->count && a->scratch, "null pointer");
     PQ_CHECK_ARG(a->N > 0 && a->C > 0 && a->C < 65535 && a->cap > 0, "bad shape");
@@ -698,8 +763,19 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
         PQ_CHECK_LAUNCH();
     }
     static const char* lib_env = getenv("PQ_NMS_LIBSORT");            // "1": the library radix sorts at every size (A/B timing, tests)
-    const bool small = S <= NMS_SMALL_MAX && !(lib_env && lib_env[0] == '1');
-    if (small) {
+    const bool libsort = lib_env && lib_env[0] == '1';
+    const bool small = S <= NMS_SMALL_MAX && !libsort;
+    // a batch whose candidate capacity is NMS_SMALL_MAX per image: one workgroup per image sorts its own segment
+    const bool seg = !small && !libsort && B > 1 && S < E && S <= (long)B * NMS_SMALL_MAX;
+    g_nms_path = small ? 0 : (seg ? 1 : 2);
+    if (seg) {
+        static bool raised2 = hipFuncSetAttribute((const void*)nms_sort_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  NMS_SMALL_MAX * 8) == hipSuccess;
+        if (!raised2) { pq_set_error("pq_nms: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
+        hipLaunchKernelGGL(nms_sort_seg_kernel, dim3(B), dim3(1024), (size_t)NMS_SMALL_MAX * 8, st, (const float*)keys0, (const unsigned*)vals0, (int)S,
+                           a->C, NC, a->N, meta, keys1, vals1, rk1, offs);
+        PQ_CHECK_LAUNCH();
+    } else if (small) {
         int P = 1024;                                                    // power of two >= S, >= the block size (uniform loops)
         while (P < S) P <<= 1;
         static bool raised = hipFuncSetAttribute((const void*)nms_sort_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

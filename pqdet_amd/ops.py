@@ -216,8 +216,10 @@ def nms(bboxes: torch.Tensor, score_thr: float, iou_thr: float, cap: Optional[in
 def nms_batch(bboxes: torch.Tensor, score_thr: float, iou_thr: float, cap: Optional[int] = None, cand_cap: Optional[int] = None):
     """Whole batch in ONE ``pq_nms`` call: ``bboxes`` (B, N, 4+C) -> (dets[cap,6], img int32[cap], count int32[1]) on device.
     Every image is suppressed on its own exactly like one ``nms`` call per image (classes and the coordinate offset are per
-    image); the kept rows of all images come in descending score order, ``img`` holds their image -- a stable sort by ``img``
-    gives the per-image lists.  ``count == -1``: ``cand_cap`` (for the whole batch) was too small."""
+    image).  ``img`` holds the image of every kept row; the rows come grouped by image with descending scores inside an image
+    (capacity <= 8192 candidates per image: one workgroup per image sorts in LDS) or in descending score order across the
+    batch (larger capacities: library radix sorts) -- a stable sort by ``img`` gives the per-image lists either way.
+    ``count == -1``: ``cand_cap`` (for the whole batch; 8192 per image on the first path) was too small."""
     _need_cuda(bboxes)
     bboxes = bboxes.contiguous().float()
     b, n, w = bboxes.shape
