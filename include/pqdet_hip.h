@@ -131,6 +131,14 @@ typedef struct pq_gsink {
     int32_t ldp;
     const float* qstate; /* QAT: T is consumed as fake_quant(act(...)) with this observer state {min,max,scale,zp}: finalize also
                             applies the straight-through mask (0 where the value falls outside [0,255] steps).  NULL otherwise */
+    int64_t* stat_acc;   /* != NULL (only with finalize && mean && partial): the two BatchNorm-backward sums per channel are ADDED to
+                            this accumulator (pq_bn_bstat.acc, pitch ldp) instead of written as rows of `partial` (which stays
+                            non-NULL: it is what marks a sink with statistics) -- no pq_bn_bwd_finalize launch follows, the kernels
+                            that read the tensor's gradient operand derive p / q / r themselves (pq_bn_bstat in their gsrc's *_stat).
+                            Honoured by the calls pq_bn_bstat_ok(code, args, 0) accepts */
+    uint32_t* stat_bad;
+    int32_t stat_slots;
+    int32_t pad_;
 } pq_gsink;
 
 /* ------------------------------------------------------------------ 1x1 convolution = fp32 MFMA GEMM
@@ -175,11 +183,9 @@ typedef struct pq_conv1x1_dgrad_args {
                                       sink must then be accumulate-only (finalize==0) -- untouched pixels keep their value */
     const float* wt;     /* optional transposed copy of w, [I][ceil4(O)] with zero pad columns (pq_transpose_batch writes that
                             layout): K-contiguous B operand, faster LDS path */
-    int64_t* dx_stat_acc;  /* != NULL: the sink's BatchNorm-backward sums are ADDED to this accumulator (pq_bn_bstat.acc, pitch
-                            * dx.ldp) instead of written as rows of dx.partial (not written then, but still non-NULL: it is what
-                            * marks a sink with statistics).  sub == 1 only */
-    uint32_t* dx_stat_bad;
-    int32_t dx_stat_slots;
+    pq_bn_bstat dy_stat; /* dy_stat.acc != NULL: the coefficients of dy are DERIVED from these sums in the kernel's prologue (no
+                            pq_bn_bwd_finalize launch in front of this call; dy.p / dy.q / dy.r are ignored, dy.mu is still read).
+                            Ring kernels only: pq_bn_bstat_ok(PQ_OP_CONV1X1_DGRAD, args, 1) */
 } pq_conv1x1_dgrad_args;
 int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream);
 
@@ -191,6 +197,7 @@ typedef struct pq_conv1x1_wgrad_args {
     float* scratch;      /* >= pq_conv1x1_wgrad_scratch_bytes(M,I,O) */
     int32_t M, I, O;
     int32_t sub, OH, OW, IH, IW;   /* sub>1: in' rows are gathered at (b,oy*sub,ox*sub) as in the forward */
+    pq_bn_bstat dy_stat; /* as in the data-gradient arguments above; every kernel of this entry derives per lane */
 } pq_conv1x1_wgrad_args;
 int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream);
 
@@ -208,9 +215,7 @@ typedef struct pq_conv1x1_bwd_args {
     float* dw;           /* [O][I] */
     float* scratch;      /* >= pq_conv1x1_bwd_scratch_bytes(M,I,O) */
     int32_t M, I, O;
-    int64_t* dx_stat_acc;  /* as in pq_conv1x1_dgrad_args */
-    uint32_t* dx_stat_bad;
-    int32_t dx_stat_slots;
+    pq_bn_bstat dy_stat; /* as in the data-gradient arguments above */
 } pq_conv1x1_bwd_args;
 int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream);
 int32_t pq_conv1x1_bwd_blocks(int32_t M, int32_t I, int32_t O);
@@ -443,8 +448,11 @@ int64_t pq_bn_finalize_scratch_bytes(int32_t C);
  * has the atomic epilogue), role 1: as the first CONSUMER of its input operand (in.stat / a.stat derived in the prologue).
  * Pure host function. */
 int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role);
-/* the same question for the backward sums (pq_bn_bstat): role 0 = this call's sink can add into accumulators
- * (PQ_OP_CONV1X1_DGRAD, PQ_OP_CONV1X1_BWD), role 1 = this call can derive its gradient operand's coefficients (PQ_OP_DW_BWD) */
+/* the same question for the backward sums (pq_bn_bstat): role 0 = this call's sink honours pq_gsink.stat_acc (PQ_OP_CONV1X1_DGRAD on the
+ * ring kernels, PQ_OP_CONV1X1_BWD, PQ_OP_DW_BWD part 5, PQ_OP_ROUTE_BWD), role 1 = this call can derive its gradient operand's
+ * coefficients from its dy_stat (PQ_OP_CONV1X1_DGRAD on the ring kernels, PQ_OP_CONV1X1_WGRAD, PQ_OP_CONV1X1_BWD, PQ_OP_DW_BWD part 5).
+ * Exactly the kernels of role 1 that have a gradient sink of their own store the derived vectors / dgamma / dbeta (the weight-gradient
+ * entry never does): hand over only when one of the readers is such a call. */
 int32_t pq_bn_bstat_ok(int32_t code, const void* args, int32_t role);
 /* bytes of a pq_bn_stat.acc for C channels with pitch ldp and `slots` replicas, and the replica count to use for nblk row blocks */
 int64_t pq_bn_stat_bytes(int32_t ldp, int32_t slots);

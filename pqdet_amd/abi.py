@@ -43,7 +43,7 @@ class GSrc(C.Structure):
 class GSink(C.Structure):
     _fields_ = [('g', c_fp), ('y', c_fp), ('scale', c_fp), ('shift', c_fp), ('mean', c_fp), ('invstd', c_fp),
                 ('partial', c_fp), ('ldg', i32), ('ldy', i32), ('act', i32), ('accumulate', i32), ('finalize', i32),
-                ('ldp', i32), ('qstate', c_fp)]
+                ('ldp', i32), ('qstate', c_fp), ('stat_acc', c_fp), ('stat_bad', c_fp), ('stat_slots', i32), ('pad_', i32)]
 
 
 class Conv1x1Fwd(C.Structure):
@@ -55,19 +55,18 @@ class Conv1x1Fwd(C.Structure):
 
 class Conv1x1Dgrad(C.Structure):
     _fields_ = [('dy', GSrc), ('w', c_fp), ('dx', GSink), ('M', i32), ('I', i32), ('O', i32),
-                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('wt', c_fp),
-                ('dx_stat_acc', c_fp), ('dx_stat_bad', c_fp), ('dx_stat_slots', i32)]
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('wt', c_fp), ('dy_stat', BnBstat)]
 
 
 class Conv1x1Wgrad(C.Structure):
     _fields_ = [('dy', GSrc), ('inp', Src), ('dw', c_fp), ('dbias', c_fp), ('scratch', c_fp),
                 ('M', i32), ('I', i32), ('O', i32),
-                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32)]
+                ('sub', i32), ('OH', i32), ('OW', i32), ('IH', i32), ('IW', i32), ('dy_stat', BnBstat)]
 
 
 class Conv1x1Bwd(C.Structure):
     _fields_ = [('dy', GSrc), ('w', c_fp), ('inp', Src), ('dx', GSink), ('dw', c_fp), ('scratch', c_fp),
-                ('M', i32), ('I', i32), ('O', i32), ('dx_stat_acc', c_fp), ('dx_stat_bad', c_fp), ('dx_stat_slots', i32)]
+                ('M', i32), ('I', i32), ('O', i32), ('dy_stat', BnBstat)]
 
 
 class GemmPlan(C.Structure):

@@ -308,16 +308,32 @@ extern "C" int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role) {
         default: return 0;
     }
 }
-// ---- the same for the backward sums (pq_bn_bstat): role 0 = the sink adds into the accumulators, 1 = the operand is derived
-int conv1x1_dgrad_bstat_ok(const pq_conv1x1_dgrad_args* a);       // gemm.hip
+// ---- the same for the backward sums (pq_bn_bstat): role 0 = the call's sink can add into accumulators (pq_gsink.stat_acc),
+// role 1 = the call derives its gradient operand's coefficients from them (its dy_stat)
+int conv1x1_dgrad_bstat_ok(const pq_conv1x1_dgrad_args* a, int role);       // gemm.hip
 int conv1x1_bwd_bstat_ok(const pq_conv1x1_bwd_args* a);           // pwbwd.hip
 int dw_bwd_bstat_ok(const pq_dw3x3_bwd_args* a);                  // dwwalk.hip
+static bool sink_has_stats(const pq_gsink& s) { return s.g && s.finalize && s.mean && s.partial && !s.qstate; }
 extern "C" int32_t pq_bn_bstat_ok(int32_t code, const void* args, int32_t role) {
     if (!args || (role != 0 && role != 1)) return 0;
     switch (code) {
-        case PQ_OP_CONV1X1_DGRAD: return role == 0 && conv1x1_dgrad_bstat_ok((const pq_conv1x1_dgrad_args*)args);
-        case PQ_OP_CONV1X1_BWD: return role == 0 && conv1x1_bwd_bstat_ok((const pq_conv1x1_bwd_args*)args);
-        case PQ_OP_DW_BWD: return role == 1 && dw_bwd_bstat_ok((const pq_dw3x3_bwd_args*)args);
+        case PQ_OP_CONV1X1_DGRAD: return conv1x1_dgrad_bstat_ok((const pq_conv1x1_dgrad_args*)args, role);
+        case PQ_OP_CONV1X1_WGRAD: {       // consumer only: every kernel of the entry derives per lane (bias gradients, strided and QAT included)
+            const pq_conv1x1_wgrad_args* a = (const pq_conv1x1_wgrad_args*)args;
+            return role == 1 && a->dy.y != nullptr && a->dy.mu != nullptr;
+        }
+        case PQ_OP_CONV1X1_BWD: {
+            const pq_conv1x1_bwd_args* a = (const pq_conv1x1_bwd_args*)args;
+            return role == 0 ? conv1x1_bwd_bstat_ok(a) : (a->dy.y != nullptr && a->dy.mu != nullptr);
+        }
+        case PQ_OP_DW_BWD: {
+            const pq_dw3x3_bwd_args* a = (const pq_dw3x3_bwd_args*)args;
+            return role == 0 ? (a->part == 5 && sink_has_stats(a->dx)) : dw_bwd_bstat_ok(a);
+        }
+        case PQ_OP_ROUTE_BWD: {           // producer only; either sink (the caller sets stat_acc on the one(s) it means)
+            const pq_route_bwd_args* a = (const pq_route_bwd_args*)args;
+            return role == 0 && (sink_has_stats(a->dx) || sink_has_stats(a->dx2));
+        }
         default: return 0;
     }
 }

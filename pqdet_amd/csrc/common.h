@@ -265,6 +265,54 @@ __device__ __forceinline__ GsrcCoef1 gsrc_coef1_bstat(const pq_gsrc& s, const pq
     if (writer) { st.dbeta[c] = (float)t1; st.dgamma[c] = (float)t2; st.p[c] = k.p; st.q[c] = k.q; st.r[c] = k.r; }
     return k;
 }
+// U channels c0, c0 + stride, ... of one thread with ALL their accumulator loads in flight before the first use (one memory round trip
+// in the consumer's prologue); out(c, coef1) receives the results
+template <int U, class F>
+__device__ __forceinline__ void bn_bstat_coefs(const pq_bn_bstat& st, const float* mu, int c0, int stride, int C, bool writer, F out) {
+    BnSums u[U];
+    float ga[U], iv[U], m[U];
+    const unsigned bad = *st.bad;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int c = min(c0 + i * stride, C - 1);
+        u[i] = bn_acc_load(st.acc, st.slots, st.ldp, c);
+        ga[i] = st.gamma[c]; iv[i] = st.invstd[c]; m[i] = mu[c];
+    }
+    const double invn = 1.0 / (double)st.count;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int c = c0 + i * stride;
+        if (c < C) {
+            double t1 = (double)u[i].hi1 + (double)u[i].lo1 * 0x1p-50, t2 = (double)u[i].hi2 + (double)u[i].lo2 * 0x1p-50;
+            if (bad) t1 = t2 = __builtin_nan("");
+            GsrcCoef1 k;
+            k.mu = m[i];
+            k.p = ga[i] * iv[i];
+            k.q = st.train ? (float)(-(double)k.p * (double)iv[i] * t2 * invn) : 0.f;
+            k.r = st.train ? (float)(-(double)k.p * t1 * invn) : 0.f;
+            if (writer) { st.dbeta[c] = (float)t1; st.dgamma[c] = (float)t2; st.p[c] = k.p; st.q[c] = k.q; st.r[c] = k.r; }
+            out(c, k);
+        }
+    }
+}
+// the same for 4 consecutive channels (kernels whose threads own a channel quad); writer: store the vectors too
+__device__ __forceinline__ GsrcCoef4 gsrc_coef4_bstat(const pq_gsrc& s, const pq_bn_bstat& st, int c0, int C, bool writer) {
+    GsrcCoef4 k;
+    k.two = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        GsrcCoef1 k1{1.f, 0.f, 0.f, 0.f};
+        if (c0 + j < C) k1 = gsrc_coef1_bstat(s, st, c0 + j, writer);
+        k.p[j] = k1.p; k.q[j] = k1.q; k.mu[j] = k1.mu; k.r[j] = k1.r;
+    }
+    return k;
+}
+// a sink's statistics accumulators (pq_gsink.stat_acc) as block_reduce_store_stats / the GEMM epilogues take them
+struct SinkAcc { int64_t* acc; uint32_t* bad; int slots; };
+__device__ __forceinline__ SinkAcc sink_acc(const pq_gsink& s) {
+    return SinkAcc{(s.finalize && s.mean != nullptr && s.partial != nullptr) ? s.stat_acc : nullptr, s.stat_bad, s.stat_slots > 0 ? s.stat_slots : 1};
+}
+
 __device__ __forceinline__ float4 gsrc_apply4(float4 g, float4 y, const GsrcCoef4& k) {
     if (!k.two) return g;
     float gg[4] = {g.x, g.y, g.z, g.w}, yy[4] = {y.x, y.y, y.z, y.w};
@@ -392,9 +440,11 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by) {
 // Reduce two float4 accumulators over threadIdx.y and store to partial[bx][0|1][ldp] (bx = logical row-block).
 // planes = 2 (sum, sum of squares) or 4 (+ per-channel min, max of the stored values: QAT observers, written by
 // block_reduce_store_minmax): the row pitch of `partial` is planes * ldp.
+// sa.acc != nullptr (pq_gsink.stat_acc): the two sums are ADDED into the sink's exact accumulators instead (bn_stat_add).
 template <int MAXT>
 __device__ __forceinline__ void block_reduce_store_stats(float4 s1, float4 s2, float* partial, int ldp, int c0, int C,
-                                                         float* lds /* >= MAXT*8 floats */, int bx, int planes = 2) {
+                                                         float* lds /* >= MAXT*8 floats */, int bx, int planes = 2,
+                                                         SinkAcc sa = SinkAcc{nullptr, nullptr, 1}) {
     const int tx = threadIdx.x, ty = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
     float* slot = lds + (size_t)(ty * nx + tx) * 8;
     slot[0] = s1.x; slot[1] = s1.y; slot[2] = s1.z; slot[3] = s1.w;
@@ -408,6 +458,15 @@ __device__ __forceinline__ void block_reduce_store_stats(float4 s1, float4 s2, f
             const float* o = lds + (size_t)(y * nx + tx) * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += o[j];
+        }
+        if (sa.acc != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < C) {
+                    bn_stat_add(sa.acc, sa.bad, sa.slots, ldp, bx, 0, c0 + j, acc[j]);
+                    bn_stat_add(sa.acc, sa.bad, sa.slots, ldp, bx, 1, c0 + j, acc[4 + j]);
+                }
+            return;
         }
         float* dst = partial + (size_t)bx * planes * ldp;
 #pragma unroll

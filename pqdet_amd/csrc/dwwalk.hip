@@ -302,7 +302,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s2_kernel(DwWP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
             const int c = (cq0 + qq) * 4 + (comp & 3);
-            if (c < p.C) p.sink.partial[(size_t)tIdx * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
+            if (c < p.C) {
+                const SinkAcc sa = sink_acc(p.sink);
+                if (sa.acc) bn_stat_add(sa.acc, sa.bad, sa.slots, p.sink.ldp, tIdx, comp >> 2, c, a);       // no finalize launch follows
+                else p.sink.partial[(size_t)tIdx * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
+            }
         }
     }
 }
@@ -547,7 +551,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s1_kernel(DwWP p) {
 #pragma unroll
             for (int l = 0; l < 32; ++l) a += red[(l * 8 + qq) * 8 + comp];
             const int c = (cq0 + qq) * 4 + (comp & 3);
-            if (c < p.C) p.sink.partial[(size_t)tIdx * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
+            if (c < p.C) {
+                const SinkAcc sa = sink_acc(p.sink);
+                if (sa.acc) bn_stat_add(sa.acc, sa.bad, sa.slots, p.sink.ldp, tIdx, comp >> 2, c, a);       // no finalize launch follows
+                else p.sink.partial[(size_t)tIdx * 2 * p.sink.ldp + (comp >> 2) * p.sink.ldp + c] = a;
+            }
         }
     }
 }

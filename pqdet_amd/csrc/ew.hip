@@ -350,9 +350,9 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
         }
         float* part1 = (a.dx.finalize && a.dx.mean) ? a.dx.partial : nullptr;
         float* part2 = (a.dx2.finalize && a.dx2.mean) ? a.dx2.partial : nullptr;
-        if (part1) block_reduce_store_stats<256>(s1, s2, part1, a.dx.ldp, c0, a.C, lds, bx);
+        if (part1) block_reduce_store_stats<256>(s1, s2, part1, a.dx.ldp, c0, a.C, lds, bx, 2, sink_acc(a.dx));
         if (part1 && part2) __syncthreads();
-        if (part2) block_reduce_store_stats<256>(t1, t2, part2, a.dx2.ldp, c0, a.C, lds, bx);
+        if (part2) block_reduce_store_stats<256>(t1, t2, part2, a.dx2.ldp, c0, a.C, lds, bx, 2, sink_acc(a.dx2));
         return;
     }
     if (!a.bcast && a.up == 1 && !a.gate && !p.unal) {
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
         sink_emit4(a.dx, sk, (size_t)r, c0, dz, s1, s2);
     }
     float* part = (a.dx.finalize && a.dx.mean) ? a.dx.partial : nullptr;
-    if (part) block_reduce_store_stats<256>(s1, s2, part, a.dx.ldp, c0, a.C, lds, bx);
+    if (part) block_reduce_store_stats<256>(s1, s2, part, a.dx.ldp, c0, a.C, lds, bx, 2, sink_acc(a.dx));
 }
 
 // ------------------------------------------------------------------------------------------------ pooled reductions

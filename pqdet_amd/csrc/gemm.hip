@@ -419,6 +419,7 @@ struct GemmTP {
     int M, O, I, rows_per_split, want_bias;
     size_t slab_stride;
     int sub, OH, OW, IH, IW;     // strided 1x1 conv: x rows are gathered at (b, oy*sub, ox*sub)
+    pq_bn_bstat dys;             // acc != NULL: dy's p / q / r derived per thread from the sink kernel's accumulators (never the writer)
 };
 
 template <int BO, int BIc>
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTP p) {
 
     const int yc4 = t % OQ, yr0 = t / OQ, xc4 = t % IQ, xr0 = t / IQ;
     const int oc = o0 + 4 * yc4, ic = i0 + 4 * xc4;
-    const GsrcCoef4 gk = gsrc_coef4(p.dy, oc, p.O);
+    const GsrcCoef4 gk = p.dys.acc != nullptr ? gsrc_coef4_bstat(p.dy, p.dys, oc, p.O, false) : gsrc_coef4(p.dy, oc, p.O);
     const SrcCoef4 xk = src_coef4(p.x, ic, p.I);
     const bool do_bias = p.want_bias && ti == 0;
     // unconditional loads at clamped coordinates (pitches are multiples of 4, so a whole quad is always readable);
@@ -807,10 +808,15 @@ static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_g
     p.sub = a->sub > 1 ? a->sub : 1; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->I; p.K = a->O;
     p.sink = a->dx;
-    if (a->dx_stat_acc) {     // the sink's BatchNorm-backward sums go to accumulators (pq_bn_bstat), not to rows
-        PQ_CHECK_ARG(a->dx_stat_bad && a->sub <= 1 && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx_stat_slots <= 4,
-                     "dx_stat_acc needs dx_stat_bad, sub == 1 and a finalising sink with statistics");
-        if (!stat_adds_ok(pq_conv1x1_blocks_k(a->M, a->I, a->O, 1), a->dx_stat_slots)) {
+    if (a->dy_stat.acc && !plan) {
+        PQ_CHECK_ARG(a->dy.y && a->dy.mu && a->dy_stat.bad && a->dy_stat.gamma && a->dy_stat.invstd && a->dy_stat.dgamma && a->dy_stat.dbeta &&
+                     a->dy_stat.p && a->dy_stat.q && a->dy_stat.r && a->dy_stat.count > 0.f && a->dy_stat.ldp >= a->O && a->dy_stat.slots <= 4,
+                     "dy_stat: incomplete");
+    }
+    if (a->dx.stat_acc) {     // the sink's BatchNorm-backward sums go to accumulators (pq_bn_bstat), not to rows
+        PQ_CHECK_ARG(a->dx.stat_bad && a->sub <= 1 && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx.stat_slots <= 4,
+                     "dx.stat_acc needs stat_bad, sub == 1 and a finalising sink with statistics");
+        if (!stat_adds_ok(pq_conv1x1_blocks_k(a->M, a->I, a->O, 1), a->dx.stat_slots)) {
             pq_set_error("pq_conv1x1_dgrad: more than %d row blocks per accumulator slot (use `partial` rows + pq_bn_bwd_finalize)", PQ_STAT_MAX_ADDS);
             return PQ_EUNSUPPORTED;
         }
@@ -824,7 +830,10 @@ static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_g
     }
     // only the ring kernels (gemm2.hip) have the atomic sink epilogue: in the register-staged family the extra path made the
     // 128 x 192 sink instantiations spill to scratch (the only scratch users of the library)
-    if (a->dx_stat_acc && !plan) { pq_set_error("pq_conv1x1_dgrad: dx_stat_acc is not supported for this shape (pq_bn_bstat_ok)"); return PQ_EUNSUPPORTED; }
+    if ((a->dx.stat_acc || a->dy_stat.acc) && !plan) {
+        pq_set_error("pq_conv1x1_dgrad: dx.stat_acc / dy_stat are not supported for this shape (pq_bn_bstat_ok)");
+        return PQ_EUNSUPPORTED;
+    }
     if (a->wt) {        // transposed weights [I][ceil4(O)] (pad columns zero): B rows are K-contiguous like the forward operand
         p.b = a->wt; p.ldb = (a->O + 3) & ~3;
         if (a->dy.y) launch_nt<2, false, 2>(p, st, bm, plan); else launch_nt<0, false, 2>(p, st, bm, plan);
@@ -841,11 +850,20 @@ extern "C" int pq_conv1x1_dgrad_plan(const pq_conv1x1_dgrad_args* a, pq_gemm_pla
     return conv1x1_dgrad_impl(a, nullptr, out);
 }
 
-// pq_bn_bstat_ok for PQ_OP_CONV1X1_DGRAD (producer role): the shapes that dispatch to the ring kernels (family 2)
-int conv1x1_dgrad_bstat_ok(const pq_conv1x1_dgrad_args* a) {
-    if (!(a->sub <= 1 && a->dx.finalize && a->dx.mean != nullptr && a->dx.partial != nullptr && !a->dx.qstate)) return 0;
+// pq_bn_bstat_ok for PQ_OP_CONV1X1_DGRAD: producer (role 0: the sink adds) and consumer (role 1: dy's coefficients derived) roles both
+// need the shape to dispatch to the ring kernels (family 2)
+int conv1x1_dgrad_bstat_ok(const pq_conv1x1_dgrad_args* a, int role) {
+    if (a->sub > 1) return 0;
+    pq_conv1x1_dgrad_args b = *a;
+    if (role == 0) {
+        if (!(a->dx.finalize && a->dx.mean != nullptr && a->dx.partial != nullptr && !a->dx.qstate)) return 0;
+    } else {
+        if (!a->dy.y || !a->dy.mu) return 0;
+        b.dy_stat.acc = reinterpret_cast<int64_t*>(uintptr_t(256));     // ask the dispatch as if the hand-over were on
+    }
     pq_gemm_plan pl{};
-    return conv1x1_dgrad_impl(a, nullptr, &pl) == PQ_OK && pl.family == 2;
+    if (conv1x1_dgrad_impl(&b, nullptr, &pl) != PQ_OK || pl.family != 2) return 0;
+    return role == 0 || pl.amode == 4;
 }
 
 static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, int& rows) {
@@ -877,6 +895,10 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->in.ld & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "pitches must be multiples of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_conv1x1_wgrad: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
+    if (a->dy_stat.acc && !plan) {
+        PQ_CHECK_ARG(a->dy.y && a->dy.mu && a->dy_stat.bad && a->dy_stat.gamma && a->dy_stat.invstd && a->dy_stat.count > 0.f &&
+                     a->dy_stat.ldp >= a->O && a->dy_stat.slots <= 4, "dy_stat: incomplete");
+    }
     bool big; int tiles, splits, rows;
     hipStream_t st = (hipStream_t)stream;
     {
@@ -902,6 +924,8 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
     }
     GemmTP p{};
     p.dy = a->dy; p.x = a->in; p.slab = a->scratch; p.M = a->M; p.O = a->O; p.I = a->I;
+    p.dys = a->dy_stat;
+    if (p.dys.slots < 1) p.dys.slots = 1;
     p.rows_per_split = rows; p.want_bias = a->dbias != nullptr;
     p.sub = a->sub > 1 ? a->sub : 1; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
     if (a->sub > 1) {

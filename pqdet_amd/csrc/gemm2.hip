@@ -64,18 +64,22 @@ struct G2P {
     int64_t* stat_acc; uint32_t* stat_bad; int stat_slots;                // EMODE 1: statistics into pq_bn_stat accumulators
     pq_gsink sink;                                                        // EMODE 2
     pq_bn_stat stat;                                                      // AMODE 3: the operand's BatchNorm, derived in the prologue
+    pq_bn_bstat bstat;                                                    // AMODE 4: the gradient operand's BatchNorm backward, derived in the prologue
 };
 
 // AMODE 0: A as stored; 1: clamp(c0*a + c1, lo, hi); 2: c0*g + c1*(y - c2) + c3; 3: as 1, but (c0, c1) = BatchNorm scale / shift
 // DERIVED in the prologue from the producer's statistic accumulators (pq_bn_stat: no finalize launch in between) into an LDS table
 // behind the ring -- nothing rides in the ring for them.   EMODE 0: store(+bias); 1: + statistics;
+// AMODE 4: as 2, but (c0, c1, c3) = p, q, r of the BatchNorm backward DERIVED in the prologue from the sink kernel's accumulators
+// (pq_bn_bstat: no finalize launch in between) into a [4][Kp] LDS table behind the ring together with c2 = mu.
 // 2: gradient sink (16-byte rows only: the host checks alignment).   K % 32 == 0, or K % 32 == 16 (RegNetX widths 48 / 80 /
 // 176 / 240 / 528): the last k-tile is then half valid -- its upper four chunks of B come from g2_zero, those of A and of the
 // coefficient vectors repeat the lower four (finite values times zero), so the loop itself is unchanged.
 template <int BM, int BN, int AMODE, int EMODE, int S>
 __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two waves per SIMD: at most 256 registers
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
-    constexpr int NA = AMODE == 2 ? 2 : 1;
+    constexpr bool PAIR = AMODE == 2 || AMODE == 4;                      // two-tensor gradient operand (g, y)
+    constexpr int NA = PAIR ? 2 : 1;
     constexpr int A_FL = BM * 32, B_FL = BN * 32;
     constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);        // coefficient floats per wave per stage
     constexpr int NC = AMODE == 2 ? 2 : (AMODE == 1 ? 1 : 0);
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
             if (c >= 4) hiA |= 1u << q;
             const size_t row = (size_t)min(m0 + r, M - 1);
             pa[0][q] = p.a0 + row * (size_t)p.lda0 + 4 * c;
-            if (AMODE == 2) pa[NA - 1][q] = p.a1 + row * (size_t)p.lda1 + 4 * c;
+            if (PAIR) pa[NA - 1][q] = p.a1 + row * (size_t)p.lda1 + 4 * c;
         }
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
     const int swz = (lrow >> 1) & 7;
     const float lo = p.lo, hi = p.hi;
     const int Kp = nk * 32;
-    float* ctab = lds + S * STAGE;                 // AMODE 3: [2][Kp] scale, shift
+    float* ctab = lds + S * STAGE;                 // AMODE 3: [2][Kp] scale, shift; AMODE 4: [4][Kp] p, q, mu, r
     auto compute = [&](int s, int kt) {
         const float* As = lds + s * STAGE;
         const float* Bs = As + NA * A_FL;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + 32 * i + lrow) * 32 + ch]);
-                if (AMODE == 2) yf[i] = *reinterpret_cast<const float4*>(&As[A_FL + (wm * WM + 32 * i + lrow) * 32 + ch]);
+                if (PAIR) yf[i] = *reinterpret_cast<const float4*>(&As[A_FL + (wm * WM + 32 * i + lrow) * 32 + ch]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + 32 * j + lrow) * 32 + ch]);
@@ -190,11 +194,12 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) ak[i][q] = __builtin_amdgcn_fmed3f(fmaf(s4[q], ak[i][q], h4[q]), lo, hi);
-            } else if (AMODE == 2) {
-                const float4 c0 = *reinterpret_cast<const float4*>(&Cs[ks * 8 + 4 * lh]);
-                const float4 c1 = *reinterpret_cast<const float4*>(&Cs[32 + ks * 8 + 4 * lh]);
-                const float4 c2 = *reinterpret_cast<const float4*>(&Cs[64 + ks * 8 + 4 * lh]);
-                const float4 c3 = *reinterpret_cast<const float4*>(&Cs[96 + ks * 8 + 4 * lh]);
+            } else if (PAIR) {
+                const float* T4 = &ctab[kt * 32 + ks * 8 + 4 * lh];
+                const float4 c0 = *reinterpret_cast<const float4*>(AMODE == 2 ? &Cs[ks * 8 + 4 * lh] : T4);
+                const float4 c1 = *reinterpret_cast<const float4*>(AMODE == 2 ? &Cs[32 + ks * 8 + 4 * lh] : T4 + Kp);
+                const float4 c2 = *reinterpret_cast<const float4*>(AMODE == 2 ? &Cs[64 + ks * 8 + 4 * lh] : T4 + 2 * Kp);
+                const float4 c3 = *reinterpret_cast<const float4*>(AMODE == 2 ? &Cs[96 + ks * 8 + 4 * lh] : T4 + 3 * Kp);
                 const float p4[4] = {c0.x, c0.y, c0.z, c0.w}, q4[4] = {c1.x, c1.y, c1.z, c1.w};
                 const float m4[4] = {c2.x, c2.y, c2.z, c2.w}, r4[4] = {c3.x, c3.y, c3.z, c3.w};
 #pragma unroll
@@ -226,6 +231,16 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
         // all of a thread's accumulator loads in flight at once: one memory round trip for K <= 1280 (one slot) / 512 (four)
         if (p.stat.slots == 1) bn_stat_coefs<5>(p.stat, t, 256, K, writer, put);
         else for (int k0 = t; k0 < K; k0 += 512) bn_stat_coefs<2>(p.stat, k0, 256, K, writer, put);
+        __syncthreads();
+    }
+    if (AMODE == 4) {
+        // the same for the BatchNorm BACKWARD of the gradient operand (pq_bn_bstat): the sums the sink kernel added -> p, q, r per
+        // contraction channel; logical workgroup (0, 0) also stores them with dgamma / dbeta
+        const bool writer = bmy == 0 && bnx == 0;
+        for (int k = K + t; k < Kp; k += 256) { ctab[k] = 0.f; ctab[Kp + k] = 0.f; ctab[2 * Kp + k] = 0.f; ctab[3 * Kp + k] = 0.f; }
+        auto put = [&](int c, const GsrcCoef1& k1) { ctab[c] = k1.p; ctab[Kp + c] = k1.q; ctab[2 * Kp + c] = k1.mu; ctab[3 * Kp + c] = k1.r; };
+        if (p.bstat.slots == 1) bn_bstat_coefs<5>(p.bstat, p.c2, t, 256, K, writer, put);
+        else for (int k0 = t; k0 < K; k0 += 512) bn_bstat_coefs<2>(p.bstat, p.c2, k0, 256, K, writer, put);
         __syncthreads();
     }
     // ---- main loop; the last k-tile is peeled so that the loads of the epilogue can be requested under its MFMAs
@@ -337,6 +352,7 @@ struct G2TP {
     const float* x; const float* scale; const float* shift; int ldx; float lo, hi;
     float* slab; size_t slab_stride;
     int M, O, I, rows_per_split;
+    pq_bn_bstat bstat;                                    // acc != NULL: p / q / r derived per lane from the sink kernel's accumulators
 };
 
 // TWO: dy' = p*g + q*(y-mu) + r (else dy' = g).  XA: x' = clamp(scale*x + shift, lo, hi) (else x' = x).
@@ -403,6 +419,13 @@ __global__ __launch_bounds__(NW * 64) void gemm2_tn_kernel(G2TP p) {
     for (int d = 0; d < D; ++d)
         if (d < nk) issue(d);
     float cp[2], cq[2], cm[2], cr[2], xs[4], xh[4];
+    if (TWO && p.bstat.acc != nullptr) {                  // uniform: no finalize launch in front -- both channels of the lane in one round trip
+        const int oa = min(o0 + og * 64 + 2 * lrow, p.O - 1);
+        // (never the writer of the vectors: the data-gradient kernel of the layer is -- the engine hands over only with one)
+        bn_bstat_coefs<2>(p.bstat, p.mu, oa, 1, p.O, false,
+                          [&](int c, const GsrcCoef1& k1) { const int a = c - oa; cp[a] = k1.p; cq[a] = k1.q; cm[a] = k1.mu; cr[a] = k1.r; });
+        if (oa + 1 >= p.O) { cp[1] = cp[0]; cq[1] = cq[0]; cm[1] = cm[0]; cr[1] = cr[0]; }          // (clamped duplicate: its rows are never stored)
+    } else
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int o = min(o0 + og * 64 + 2 * lrow + a, p.O - 1);
@@ -516,17 +539,17 @@ static bool g2_raise_lds(const void* fn, size_t bytes) {
 template <int BM, int BN, int AMODE, int EMODE, int S>
 static int g2_launch_nt(const G2P& p, hipStream_t st, pq_gemm_plan* plan) {
     if (plan) { *plan = pq_gemm_plan{2, BM, BN, S, AMODE, EMODE, 0, 0}; return PQ_OK; }      // query only (pq_conv1x1_*_plan)
-    constexpr int NA = AMODE == 2 ? 2 : 1;
+    constexpr int NA = (AMODE == 2 || AMODE == 4) ? 2 : 1;
     constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);
     constexpr int STAGE = NA * BM * 32 + BN * 32 + 4 * CW;
     constexpr size_t ring0 = (size_t)S * STAGE * 4, epi = (size_t)(4 * BN) * 4;
-    constexpr size_t ring_max = ring0 + (AMODE == 3 ? (size_t)2 * G2_STAT_KMAX * 4 : 0);
+    constexpr size_t ring_max = ring0 + (AMODE == 3 ? (size_t)2 * G2_STAT_KMAX * 4 : (AMODE == 4 ? (size_t)4 * G2_STAT_KMAX * 4 : 0));
     constexpr size_t bytes_max = ring_max > epi ? ring_max : epi;
     static bool ok = g2_raise_lds((const void*)gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>, bytes_max);
     if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
     // AMODE 3: the coefficient table behind the ring is sized by THIS contraction (a fixed 10 KB pushed the 128 x 64 x 3-stage ring
     // over 80 KB, i.e. down to one workgroup per CU: +13 us on the K = 512 layers)
-    const size_t ring = ring0 + (AMODE == 3 ? (size_t)2 * ((p.K + 31) / 32 * 32) * 4 : 0);
+    const size_t ring = ring0 + (AMODE == 3 ? (size_t)2 * ((p.K + 31) / 32 * 32) * 4 : (AMODE == 4 ? (size_t)4 * ((p.K + 31) / 32 * 32) * 4 : 0));
     const size_t bytes = ring > epi ? ring : epi;
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
     PQ_LAUNCH_BINDABLE((gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>), grid, dim3(256), bytes, st, p);
@@ -551,7 +574,7 @@ static int g2_dispatch_nt(const G2P& p, int bm, hipStream_t st, pq_gemm_plan* pl
         // gradient sink: tiles of at most two 32 x 32 blocks per wave (the sink's operands of a whole tile are prefetched into
         // registers; a 128 x 128 sink tile would need 288 of them: one wave per SIMD)
         if (bm == 128) return g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
-        if (AMODE == 2) return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
+        if (AMODE == 2 || AMODE == 4) return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
         return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
     } else {
         if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
@@ -603,8 +626,13 @@ int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st, pq_
     p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
     p.b = a->wt; p.ldb = a->O; p.M = a->M; p.N = a->I; p.K = a->O;      // O % 16 == 0: the transposed rows have no pad
     p.sink = a->dx;
-    p.stat_acc = a->dx_stat_acc; p.stat_bad = a->dx_stat_bad; p.stat_slots = a->dx_stat_slots > 0 ? a->dx_stat_slots : 1;   // (checked by the caller)
-    const int rc = a->dy.y ? g2_dispatch_nt<2, 2>(p, bm, st, plan) : g2_dispatch_nt<0, 2>(p, bm, st, plan);
+    p.stat_acc = a->dx.stat_acc; p.stat_bad = a->dx.stat_bad; p.stat_slots = a->dx.stat_slots > 0 ? a->dx.stat_slots : 1;   // (checked by the caller)
+    const bool from_bstat = a->dy_stat.acc != nullptr;       // (the caller checked the record)
+    if (from_bstat && (!a->dy.y || a->O > G2_STAT_KMAX)) return 0;
+    p.bstat = a->dy_stat;
+    if (p.bstat.slots < 1) p.bstat.slots = 1;
+    const int rc = from_bstat ? g2_dispatch_nt<4, 2>(p, bm, st, plan)
+                              : (a->dy.y ? g2_dispatch_nt<2, 2>(p, bm, st, plan) : g2_dispatch_nt<0, 2>(p, bm, st, plan));
     return rc == PQ_OK ? 1 : rc;
 }
 
@@ -662,6 +690,8 @@ int g2_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, int* splits_out, size_t* st
     p.x = a->in.x; p.scale = a->in.scale; p.shift = a->in.shift; p.ldx = a->in.ld;
     p.slab = a->scratch; p.slab_stride = (size_t)a->O * a->I + a->O;
     p.M = a->M; p.O = a->O; p.I = a->I; p.rows_per_split = pl.rows;
+    p.bstat = a->dy_stat;
+    if (p.bstat.slots < 1) p.bstat.slots = 1;
     int rc;
     if (a->dy.y) rc = xa ? g2_launch_tn<true, true>(p, pl, st, plan) : g2_launch_tn<true, false>(p, pl, st, plan);
     else rc = xa ? g2_launch_tn<false, true>(p, pl, st, plan) : g2_launch_tn<false, false>(p, pl, st, plan);

@@ -21,6 +21,7 @@ struct PwP {
     const float* w;      // [O][I]
     float* slab;         // [gridDim.x][O*I]
     int64_t* stat_acc; uint32_t* stat_bad; int stat_slots;      // the sink's BatchNorm-backward sums into pq_bn_bstat accumulators
+    pq_bn_bstat dys;                                            // dy's BatchNorm-backward sums (hand-over: no finalize launch in front)
     int M, I, O, LDZ, LDX, tiles;
 };
 
@@ -49,6 +50,12 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
     float* cs = cx + 2 * I;                       // [4][I]  scale, shift, mean, invstd of the sink
     const bool two = p.dy.y != nullptr, xaff = p.x.scale != nullptr, saff = p.dx.scale != nullptr;
     const bool sstats = p.dx.mean != nullptr && p.dx.partial != nullptr;
+    if (p.dys.acc != nullptr) {                  // uniform: dy's coefficients from the sink kernel's accumulators (no finalize launch)
+        for (int c = t; c < O; c += 256) {
+            const GsrcCoef1 k1 = gsrc_coef1_bstat(p.dy, p.dys, c, blockIdx.x == 0);
+            cg[c] = k1.p; cg[O + c] = k1.q; cg[2 * O + c] = k1.mu; cg[3 * O + c] = k1.r;
+        }
+    } else
     for (int c = t; c < O; c += 256) {
         cg[c] = two ? p.dy.p[c] : 1.f; cg[O + c] = two ? p.dy.q[c] : 0.f;
         cg[2 * O + c] = two ? p.dy.mu[c] : 0.f; cg[3 * O + c] = two ? p.dy.r[c] : 0.f;
@@ -423,10 +430,17 @@ extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
     PwP p{};
     p.dy = a->dy; p.x = a->in; p.dx = a->dx; p.w = a->w; p.slab = a->scratch;
     p.M = a->M; p.I = a->I; p.O = a->O; p.LDZ = pl.ldz; p.LDX = pl.ldx; p.tiles = pl.tiles;
-    if (a->dx_stat_acc) {
-        PQ_CHECK_ARG(a->dx_stat_bad && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx_stat_slots <= 4,
-                     "dx_stat_acc needs dx_stat_bad and a finalising sink with statistics");
-        p.stat_acc = a->dx_stat_acc; p.stat_bad = a->dx_stat_bad; p.stat_slots = a->dx_stat_slots > 0 ? a->dx_stat_slots : 1;
+    p.dys = a->dy_stat;
+    if (p.dys.slots < 1) p.dys.slots = 1;
+    if (a->dy_stat.acc) {
+        PQ_CHECK_ARG(a->dy.y && a->dy.mu && a->dy_stat.bad && a->dy_stat.gamma && a->dy_stat.invstd && a->dy_stat.dgamma && a->dy_stat.dbeta &&
+                     a->dy_stat.p && a->dy_stat.q && a->dy_stat.r && a->dy_stat.count > 0.f && a->dy_stat.ldp >= a->O && a->dy_stat.slots <= 4,
+                     "dy_stat: incomplete");
+    }
+    if (a->dx.stat_acc) {
+        PQ_CHECK_ARG(a->dx.stat_bad && a->dx.finalize && a->dx.mean && a->dx.partial && a->dx.ldp >= a->I && a->dx.stat_slots <= 4,
+                     "dx.stat_acc needs stat_bad and a finalising sink with statistics");
+        p.stat_acc = a->dx.stat_acc; p.stat_bad = a->dx.stat_bad; p.stat_slots = a->dx.stat_slots > 0 ? a->dx.stat_slots : 1;
         if (!stat_adds_ok(pl.grid, p.stat_slots)) {
             pq_set_error("pq_conv1x1_bwd: more than %d workgroups per accumulator slot", PQ_STAT_MAX_ADDS);
             return PQ_EUNSUPPORTED;

@@ -1204,58 +1204,95 @@ class Plan:
         self._handover_bn_bwd()
 
     def _handover_bn_bwd(self):
-        """Backward twin of _handover_bn_stats for the depthwise layers: drop the pq_bn_bwd_finalize launch between the kernel whose
-        sink finalises a depthwise conv's output gradient (the 1x1 projection's data gradient, plain or fused with its weight
-        gradient) and the walking depthwise backward, the ONE reader of that gradient operand.  The sink adds its BatchNorm-backward
-        sums into exact fixed-point accumulators (pq_bn_bstat), the walking kernel derives p / q / r in its prologue and its first
-        workgroup per channel chunk stores dgamma / dbeta.  These finalizes carry no fork (the depthwise weight gradient is part of
-        the same kernel), but they sit on the critical chain right where the previous layer's weight-gradient GEMM owns the CUs:
-        5-20 us each in the step's kernel trace.  The accumulators are cleared by a side-stream op at the end of the forward
-        (two-stream forward), else by the first op of the backward."""
+        """Backward twin of _handover_bn_stats: drop the pq_bn_bwd_finalize launch between the kernel whose sink finalises a
+        BatchNorm output's gradient (the PRODUCER: data gradient of the next 1x1 conv, plain or fused; walking depthwise backward;
+        shortcut / route / upsample backward) and the kernels that read that gradient operand (the CONSUMERS: the layer's own data
+        and weight gradient -- 1x1 on the ring kernels, fused narrow 1x1, walking depthwise).  The producer adds its sums into exact
+        fixed-point accumulators (pq_gsink.stat_acc), every consumer derives p / q / r in its prologue (its dy_stat) and the ones
+        with a gradient sink of their own store dgamma / dbeta and the vectors.  A finalize launch costs its own 4-9 us on the
+        critical chain plus a kernel boundary; the weight gradient's fork then hangs off the producer.  The accumulators are
+        cleared by a side-stream op at the end of the forward (two-stream forward), else by the first op of the backward."""
         self.bn_bwd_handover = 0
         self.bn_bwd_handover_producers = set()          # op codes of the kernels that add (tests)
-        if not self.bn_train or self.qat or os.environ.get('PQ_BN_BWD_ATOMIC', '1') == '0':
+        self.bn_bwd_handover_consumers = set()
+        # Scope (PQ_BN_BWD_ATOMIC): 'dw' (default) = the layers whose only reader is the walking depthwise backward, one workgroup
+        # column per channel chunk; 'all' = every layer whose producer and readers support it (61 of 81 on mobilenetv2-fpn);
+        # '0' = none.  MEASURED (round 4, mobilenetv2-fpn 512 x 512 batch 16, same box): none 9.81-9.84 ms, 'dw' 9.76-9.78,
+        # 'all' 10.06-10.08, 'all' with at most 16 / 32 / 64 / 128 / 256 row blocks 9.76 / 9.81 / 9.81 / 9.85 / 9.86: a GEMM reader
+        # re-derives the whole contraction's coefficients in EVERY workgroup (K x 32 B x slots from L2 per workgroup, thousands of
+        # workgroups) and the producers' same-address atomics serialise, which costs more than the 6.5 us launch it replaces.
+        scope = os.environ.get('PQ_BN_BWD_ATOMIC', 'dw')
+        if not self.bn_train or self.qat or scope == '0':
             return
         l = lib()
-        maxblk = 640         # as in the forward; with every depthwise layer handed over (1024-row lists): 10.09-10.11 ms against 10.06-10.11
+        maxblk = int(os.environ.get('PQ_BN_BWD_MAXBLK', '640'))     # row blocks adding to one channel (same-address atomics serialise)
+        only_dw = scope not in ('all', '1')
+        sink_fields = {abi.OP_CONV1X1_DGRAD: ('dx',), abi.OP_CONV1X1_BWD: ('dx',), abi.OP_DW_BWD: ('dx',), abi.OP_ROUTE_BWD: ('dx', 'dx2')}
+        dy_ops = (abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_WGRAD, abi.OP_CONV1X1_BWD, abi.OP_DW_BWD, abi.OP_GCONV_DGRAD, abi.OP_GCONV_WGRAD,
+                  abi.OP_DW_DGRAD, abi.OP_DW_WGRAD, abi.OP_STEM_WGRAD)
+        writers = (abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_BWD, abi.OP_DW_BWD)
         picks, total = [], 0
         for k in range(1, len(self.bwd) - 1):
             op = self.bwd[k]
             if op.code != abi.OP_BN_BWD_FIN or op.flags:
                 continue
             f = op.u.bnb
-            cons = self.bwd[k + 1]
-            if not f.train or f.nblk > maxblk or cons.code != abi.OP_DW_BWD or cons.flags:
+            if not f.train or f.nblk > maxblk or not f.partial:
                 continue
-            ca = cons.u.dwb
-            if ca.part != 5 or ca.dy.p != f.p or ca.dy_stat.acc or not l.pq_bn_bstat_ok(cons.code, C.byref(ca), 1):
+            # ---- the producer: the op whose sink finalises this tensor's gradient
+            prod = None
+            for j in range(k - 1, -1, -1):
+                pj = self.bwd[j]
+                if pj.code not in sink_fields:
+                    continue
+                pa = getattr(pj.u, abi.OP_FIELD[pj.code])
+                for name in sink_fields[pj.code]:
+                    sk = getattr(pa, name)
+                    if sk.g and sk.partial == f.partial and sk.finalize:
+                        prod = (pj, pa, sk)
+                if prod:
+                    break
+            if not prod:
                 continue
-            i = k - 1
-            while i >= 0 and (self.bwd[i].flags & abi.OPF_SIDE):
-                i -= 1
-            if i < 0 or self.bwd[i].flags or self.bwd[i].code not in (abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_BWD):
+            pj, pa, sk = prod
+            if pj.flags or sk.stat_acc or sk.ldp != f.ldp or not l.pq_bn_bstat_ok(pj.code, C.byref(pa), 0):
                 continue
-            pa = getattr(self.bwd[i].u, abi.OP_FIELD[self.bwd[i].code])
-            if pa.dx.partial != f.partial or not pa.dx.finalize or pa.dx.ldp != f.ldp or pa.dx_stat_acc \
-                    or not l.pq_bn_bstat_ok(self.bwd[i].code, C.byref(pa), 0):
+            # ---- the consumers: every op that reads the gradient operand through these p / q / r vectors
+            cons, ok = [], True
+            for j in range(k + 1, len(self.bwd)):
+                cj = self.bwd[j]
+                if cj.code not in dy_ops:
+                    continue
+                ca = getattr(cj.u, abi.OP_FIELD[cj.code])
+                if not ca.dy.p or ca.dy.p != f.p:
+                    continue
+                if not hasattr(ca, 'dy_stat') or ca.dy_stat.acc or not l.pq_bn_bstat_ok(cj.code, C.byref(ca), 1):
+                    ok = False
+                    break
+                cons.append((cj, ca))
+            if not ok or not any(cj.code in writers and not cj.flags for cj, _ in cons):
+                continue
+            if only_dw and not all(cj.code == abi.OP_DW_BWD for cj, _ in cons):
                 continue
             slots = l.pq_bn_stat_slots(f.nblk)
             nbytes = _round_up(l.pq_bn_stat_bytes(f.ldp, slots), 64)
-            picks.append((k, pa, ca, f, slots, total, total + nbytes))
+            picks.append((k, sk, cons, f, slots, total, total + nbytes))
             total += nbytes + 64
-            self.bn_bwd_handover_producers.add(self.bwd[i].code)
+            self.bn_bwd_handover_producers.add(pj.code)
+            self.bn_bwd_handover_consumers.update(cj.code for cj, _ in cons)
         if not picks:
             return
         arena = torch.zeros(total // 8, device=self.device, dtype=torch.int64)
         self.keep.append(arena)
         base = arena.data_ptr()
-        for k, pa, ca, f, slots, off_acc, off_bad in picks:
-            pa.dx_stat_acc, pa.dx_stat_bad, pa.dx_stat_slots = base + off_acc, base + off_bad, slots
-            ca.dy_stat = abi.BnBstat(base + off_acc, base + off_bad, f.gamma, f.invstd, f.dgamma, f.dbeta, f.p, f.q, f.r,
-                                     slots, f.ldp, f.count, 1)
-            nop = abi.Op()
-            nop.code = abi.OP_FILL
-            nop.u.fill = abi.Fill(base, 0.0, 0)
+        nop = abi.Op()
+        nop.code = abi.OP_FILL
+        nop.u.fill = abi.Fill(base, 0.0, 0)
+        for k, sk, cons, f, slots, off_acc, off_bad in picks:
+            sk.stat_acc, sk.stat_bad, sk.stat_slots = base + off_acc, base + off_bad, slots
+            for _, ca in cons:
+                ca.dy_stat = abi.BnBstat(base + off_acc, base + off_bad, f.gamma, f.invstd, f.dgamma, f.dbeta, f.p, f.q, f.r,
+                                         slots, f.ldp, f.count, 1)
             self.bwd[k] = nop
         fill = abi.Fill(base, 0.0, total // 4)
         if self.fwd_side_slots_ok:
