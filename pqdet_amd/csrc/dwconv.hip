@@ -795,8 +795,8 @@ int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream) {
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     size_t sh = (size_t)g.cx * g.py * 8 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (a->stride == 1) hipLaunchKernelGGL((dw_fwd_kernel<1, 4, false>), grid, blk, sh, st, p);
-    else hipLaunchKernelGGL((dw_fwd_kernel<2, 2, false>), grid, blk, sh, st, p);
+    if (a->stride == 1) { pq_set_error("pq_dw3x3_fwd: internal -- stride 1 runs on the walking kernel"); return PQ_EINVAL; }
+    hipLaunchKernelGGL((dw_fwd_kernel<2, 2, false>), grid, blk, sh, st, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -10,7 +10,6 @@
 // Forward only since round 4: the LDS-tiled backward kernels (round 2) were superseded by the walking kernels of dwwalk.hip
 // (pq_dw3x3_bwd parts 5 / 6) on every shape and have been removed; planes the walking backward does not take (stride 2 with an odd
 // input size) use pq_dw3x3_dgrad + pq_dw3x3_wgrad (dwconv.hip).
-#include <cstdlib>
 #include "common.h"
 
 namespace pq {
@@ -179,28 +178,12 @@ int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream);
 int dw_fwd_walk_blocks(int B, int H, int W, int C);
 int dw_fwd_walk_launch(const pq_dw3x3_fwd_args* a, void* stream);
 
-// Which forward / backward variant pays: the LDS-tiled kernels win while the planes are small (<= 64x64 at batch 16:
-// few, fat workgroups per image), the streaming register-window kernels win on the big early planes (measured with
-// scripts/dw_bench.py).  PQ_DW_MODE=tiled|stream overrides (benchmarking only).
-static int dw_mode_override() {
-    static int mode = -2;
-    if (mode == -2) {
-        const char* e = getenv("PQ_DW_MODE");
-        mode = !e ? -1 : (e[0] == 't' ? 1 : 0);
-    }
-    return mode;
-}
-// stride-1 forward: the walking kernel (dwwalk.hip) at every plane size; PQ_DW_FWD_WALK=0 restores the tiled / streaming pair (A/B)
-static bool dw_fwd_use_walk(int stride) {
-    static const char* e = getenv("PQ_DW_FWD_WALK");
-    return stride == 1 && !(e && e[0] == '0') && dw_mode_override() < 0;
-}
-static bool dw_fwd_use_tiled(int OH, int OW, int stride) {
-    const int o = dw_mode_override();
-    if (o >= 0) return o == 1;
-    (void)stride;
-    return (long)OH * OW <= 64 * 64;
-}
+// Forward dispatch: stride 1 = the walking kernel (dwwalk.hip) at every plane size; stride 2 = the LDS-tiled kernel below while the
+// planes are small (<= 64x64 outputs at batch 16: few, fat workgroups per image), the streaming register-window kernel of
+// dwconv.hip on the big early planes (measured with scripts/dw_bench.py).
+static bool dw_fwd_use_walk(int stride) { return stride == 1; }
+static bool dw_fwd_use_tiled(int OH, int OW, int stride) { (void)stride; return (long)OH * OW <= 64 * 64; }
+
 extern "C" int32_t pq_dw3x3_fwd_blocks(int32_t B, int32_t OH, int32_t OW, int32_t C, int32_t stride) {
     if (dw_fwd_use_walk(stride)) return dw_fwd_walk_blocks(B, OH, OW, C);
     if (!dw_fwd_use_tiled(OH, OW, stride)) return ew_geom((long)B * OH * OW, C).gx;
@@ -234,8 +217,7 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     fwd_tiles(a->OH, a->OW, a->stride, p.tilesH, p.tilesW);
     dim3 grid(a->B * p.tilesH * p.tilesW, (p.C4 + CBQ - 1) / CBQ), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (a->stride == 1) hipLaunchKernelGGL((dwt_fwd_kernel<1>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((dwt_fwd_kernel<2>), grid, blk, 0, st, p);
+    hipLaunchKernelGGL((dwt_fwd_kernel<2>), grid, blk, 0, st, p);          // (stride 1 never gets here: walking kernel)
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

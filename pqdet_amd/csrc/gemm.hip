@@ -662,11 +662,8 @@ int g2_wgrad_splits(int M, int I, int O);
 // tiled for the LDS-DMA kernels: the largest tile that still gives every CU two workgroups; the data gradient stages two
 // tensors per row, so its row block is 64 wherever that keeps two workgroups per CU in LDS.  PQ_G2_BM=64|128 forces (A/B).
 static int row_bm(int M, int N, int K, int kind) {
-    static const char* g2off = getenv("PQ_G2");
-    const bool g2 = !(g2off && g2off[0] == '0') && K >= (kind == 0 ? 128 : 64) && (K & 15) == 0 && N >= 64;
+    const bool g2 = K >= (kind == 0 ? 128 : 64) && (K & 15) == 0 && N >= 64;
     if (!g2) return pick_tile(M, N).bm;
-    static const char* force = getenv("PQ_G2_BM");
-    if (force) return atoi(force) >= 128 ? 128 : 64;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
     if (kind == 0) return (t128 >= 400 || t12864 >= 400) ? 128 : 64;
     // data gradient: 128-row tiles stage two tensors per row (126-150 KB of LDS: one workgroup per CU) -- only where 64-row tiles would
@@ -866,12 +863,11 @@ int conv1x1_dgrad_bstat_ok(const pq_conv1x1_dgrad_args* a, int role) {
     return role == 0 || pl.amode == 4;
 }
 
-static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, int& rows) {
+static void wgrad_plan(int M, int I, int O, int& tiles, int& splits, int& rows) {
     // 64x64 output tiles everywhere: four times more tiles than 128x128 means four times fewer row splits for the same
     // number of workgroups, i.e. longer contraction loops per workgroup and a quarter of the slab traffic; measured equal
     // or faster on every layer shape of the nets
-    big = false;
-    const int b = big ? 128 : 64;
+    const int b = 64;
     tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
     const int target = 512;
     int want = (target + tiles - 1) / tiles;
@@ -883,8 +879,8 @@ static void wgrad_plan(int M, int I, int O, bool& big, int& tiles, int& splits, 
 }
 
 extern "C" int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t O) {
-    bool big; int tiles, splits, rows;
-    wgrad_plan(M, I, O, big, tiles, splits, rows);
+    int tiles, splits, rows;
+    wgrad_plan(M, I, O, tiles, splits, rows);
     const int s2 = g2_wgrad_splits(M, I, O);
     if (s2 > splits) splits = s2;
     return (int64_t)splits * ((int64_t)O * I + O) * 4;
@@ -899,7 +895,7 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
         PQ_CHECK_ARG(a->dy.y && a->dy.mu && a->dy_stat.bad && a->dy_stat.gamma && a->dy_stat.invstd && a->dy_stat.count > 0.f &&
                      a->dy_stat.ldp >= a->O && a->dy_stat.slots <= 4, "dy_stat: incomplete");
     }
-    bool big; int tiles, splits, rows;
+    int tiles, splits, rows;
     hipStream_t st = (hipStream_t)stream;
     {
         int s2 = 0; size_t stride2 = 0;
@@ -917,9 +913,9 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
             return PQ_OK;
         }
     }
-    wgrad_plan(a->M, a->I, a->O, big, tiles, splits, rows);
+    wgrad_plan(a->M, a->I, a->O, tiles, splits, rows);
     if (plan) {
-        *plan = pq_gemm_plan{1, big ? 128 : 64, big ? 128 : 64, 1, (a->dy.y ? 1 : 0) | ((a->in.scale || a->in.act != PQ_ACT_LINEAR) ? 2 : 0), 0, splits, 0};
+        *plan = pq_gemm_plan{1, 64, 64, 1, (a->dy.y ? 1 : 0) | ((a->in.scale || a->in.act != PQ_ACT_LINEAR) ? 2 : 0), 0, splits, 0};
         return PQ_OK;
     }
     GemmTP p{};
@@ -934,8 +930,7 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
     }
     p.slab_stride = (size_t)a->O * a->I + a->O;
     dim3 grid(tiles, splits), blk(256);
-    if (big) hipLaunchKernelGGL((gemm_tn_kernel<128, 128>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
     const int n0 = a->O * a->I, n1 = a->dbias ? a->O : 0;
     if (splits <= 64) {

@@ -528,10 +528,7 @@ extern "C" int pq_debug_set_stamps(void* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(pq::pq_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
-static bool g2_enabled() {
-    static const char* e = getenv("PQ_G2");
-    return !(e && e[0] == '0');
-}
+static bool g2_enabled() { return true; }
 static bool g2_raise_lds(const void* fn, size_t bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
@@ -559,8 +556,6 @@ static int g2_launch_nt(const G2P& p, hipStream_t st, pq_gemm_plan* plan) {
 // Column-tile width for a row-block height the caller has fixed (pq_conv1x1_blocks decides BM from (M, N) alone because the
 // statistics rows are sized from it): 128-wide tiles while they still give every CU two workgroups.
 static int g2_pick_bn(int M, int N, int bm) {
-    static const char* force = getenv("PQ_G2_BN");
-    if (force) return atoi(force) >= 128 ? 128 : 64;
     if (N <= 64) return 64;
     const long tiles128 = (long)((M + bm - 1) / bm) * ((N + 127) / 128);
     return tiles128 >= 512 ? 128 : 64;

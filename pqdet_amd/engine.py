@@ -1073,7 +1073,7 @@ class Plan:
                                                    B, src.H, src.W, out.H, out.W, out.C, gw, s)
                                 self._op(self.bwd, abi.OP_GCONV_DGRAD, d)
                         else:
-                            walk = os.environ.get('PQ_DW_WALK', '1') != '0' and src.needs_grad and \
+                            walk = src.needs_grad and \
                                 (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0))
                             if walk:
                                 nblk = l.pq_dw3x3_bwd_walk_blocks(B, src.H, src.W, out.C, s)
@@ -1085,8 +1085,8 @@ class Plan:
                                 # the WALKING backward (dwwalk.hip): both gradients from one pass over (g, y_out, y_in) on the main
                                 # stream -- 4 tensor passes instead of the 7 of a data- and a weight-gradient kernel -- with one
                                 # statistics / weight-gradient row per workgroup; only the reduction of those few rows goes to the
-                                # weight-gradient stream.  (PQ_DW_WALK=0: separate data / weight gradient kernels, the fallback for
-                                # odd stride-2 planes -- A/B and tests.)
+                                # weight-gradient stream.  (Separate data / weight gradient kernels remain for stride-2 planes of odd size
+                                # and for a conv whose input needs no gradient.)
                                 buf = self._new(nblk * out.C * 9 + 16)
                                 a = abi.DwBwd(dy, sin, wsrc, sink, None, ptr(buf), B, src.H, src.W, out.H, out.W, out.C, s, 5)
                                 self._op(self.bwd, abi.OP_DW_BWD, a)
@@ -1094,7 +1094,7 @@ class Plan:
                                               out.W, out.C, s, 6)
                                 idx = self._op(self.bwd, abi.OP_DW_BWD, a)
                                 # the reduction of a few rows is not urgent: it rides with the next weight gradient's fork
-                                self.bwd[idx].flags = abi.OPF_SIDE | (abi.OPF_LAZY if os.environ.get('PQ_LAZY_REDUCE', '1') != '0' else 0)
+                                self.bwd[idx].flags = abi.OPF_SIDE | abi.OPF_LAZY
                             else:
                                 need = l.pq_dw3x3_wgrad_scratch_bytes(B, out.H, out.W, out.C)
                                 a = abi.DwWgrad(dy, src.src(), wdst, None, B, src.H, src.W, out.H, out.W,
@@ -1182,8 +1182,7 @@ class Plan:
         # NOFORK is only safe behind a side op of THIS forward that did fork (the head-branch layers): the side stream is then
         # past the previous step's optimiser update / backward, which a fork-less op at its head would not be.
         self.fwd_side_slots_ok = getattr(self, 'fwd_two_streams', False) and bool(getattr(self, 'fwd_side_layers', []))
-        self.tr_in_forward = bool(tr_items) and self.fwd_side_slots_ok and not self.qat \
-            and os.environ.get('PQ_TR_FWD', '1') != '0'
+        self.tr_in_forward = bool(tr_items) and self.fwd_side_slots_ok and not self.qat
         if self.tr_in_forward:
             op = abi.Op()
             op.code = abi.OP_TRANSPOSE
@@ -1225,7 +1224,7 @@ class Plan:
         if not self.bn_train or self.qat or scope == '0':
             return
         l = lib()
-        maxblk = int(os.environ.get('PQ_BN_BWD_MAXBLK', '640'))     # row blocks adding to one channel (same-address atomics serialise)
+        maxblk = 640                                                 # row blocks adding to one channel (same-address atomics serialise)
         only_dw = scope not in ('all', '1')
         sink_fields = {abi.OP_CONV1X1_DGRAD: ('dx',), abi.OP_CONV1X1_BWD: ('dx',), abi.OP_DW_BWD: ('dx',), abi.OP_ROUTE_BWD: ('dx', 'dx2')}
         dy_ops = (abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_WGRAD, abi.OP_CONV1X1_BWD, abi.OP_DW_BWD, abi.OP_GCONV_DGRAD, abi.OP_GCONV_WGRAD,

@@ -46,8 +46,8 @@ for (B, H, W, Cc, s) in SHAPES:
 print('sum dgrad %.3f wgrad %.3f fused tiled %.3f walking %.3f + reduce %.3f' % tuple(tot))
 if os.environ.get('BWD_ONLY'): sys.exit(0)
 
-# ---- forward: PQ_DW_MODE decides tiled vs streaming (run the script twice)
-print('forward, mode', os.environ.get('PQ_DW_MODE', 'auto'))
+# ---- forward
+print('forward')
 totf = 0
 for (B, H, W, Cc, s) in SHAPES:
     OH, OW = (H - 1) // s + 1, (W - 1) // s + 1

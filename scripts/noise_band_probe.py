@@ -17,7 +17,7 @@ ref.train(), ref64.train()
 ref(x, tgt)['loss'].mean().backward()
 ref64(x.double(), tuple(t.double() for t in tgt))['loss'].mean().backward()
 for env in ({}, {'PQ_BN_ATOMIC': '0'}):
-    for k in ('PQ_BN_ATOMIC', 'PQ_FWD_SIDE', 'PQ_DW_WALK', 'PQ_TR_FWD'):
+    for k in ('PQ_BN_ATOMIC', 'PQ_FWD_SIDE'):
         os.environ.pop(k, None)
     os.environ.update(env)
     net, _ = _pair(seed=3, name=name)

@@ -136,18 +136,18 @@ def _id(case):
 
 @pytest.mark.parametrize('case', FWD, ids=_id)
 def test_conv1x1_fwd_at_benchmark_shapes(case):
-    K.test_conv1x1_fwd(*case[:7], expect=case[7])
+    K.check_conv1x1_fwd(*case[:7], expect=case[7])
 
 
 @pytest.mark.parametrize('case', DGRAD, ids=_id)
 def test_conv1x1_dgrad_at_benchmark_shapes(case):
-    K.test_conv1x1_dgrad(*case[:7], expect_wt=case[7])
+    K.check_conv1x1_dgrad(*case[:7], expect_wt=case[7])
 
 
 @pytest.mark.parametrize('case', WGRAD, ids=_id)
 def test_conv1x1_wgrad_at_benchmark_shapes(case):
     M, I, O, two, xa, expect, splits = case
-    K.test_conv1x1_wgrad(M, I, O, two, False, xa=xa, expect=expect)
+    K.check_conv1x1_wgrad(M, I, O, two, False, xa=xa, expect=expect)
     a = abi.Conv1x1Wgrad()            # the row-split count is part of what the case was written for
     a.dy.g = a.inp.x = a.dw = 256
     a.dy.y = 256 if two else None
@@ -162,17 +162,17 @@ def test_conv1x1_wgrad_at_benchmark_shapes(case):
 @pytest.mark.parametrize('case', WGRAD_BIAS, ids=_id)
 def test_conv1x1_wgrad_with_bias_at_benchmark_shapes(case):
     M, I, O, two, expect = case
-    K.test_conv1x1_wgrad(M, I, O, two, True, expect=expect)
+    K.check_conv1x1_wgrad(M, I, O, two, True, expect=expect)
 
 
 @pytest.mark.parametrize('case', FWD_STRIDED, ids=lambda c: '%dx%dx%dx%d' % c[:4])
 def test_conv1x1_fwd_strided_at_benchmark_shapes(case):
-    K.test_conv1x1_fwd_strided_rows(*case[:5], act=1, stats=True, expect=case[5])
+    K.check_conv1x1_fwd_strided_rows(*case[:5], act=1, stats=True, expect=case[5])
 
 
 @pytest.mark.parametrize('case', BWD_STRIDED, ids=lambda c: '%dx%dx%dx%d' % c[:4])
 def test_conv1x1_strided_backward_at_benchmark_shapes(case):
-    K.test_conv1x1_strided_backward(*case[:5], True, expect=case[5], expect_w=case[6])
+    K.check_conv1x1_strided_backward(*case[:5], True, expect=case[5], expect_w=case[6])
 
 
 @pytest.mark.parametrize('case', HANDOVER, ids=lambda c: '%dx%dx%dx%d' % c[:4])

@@ -92,7 +92,11 @@ def reduce_partial(partial, nblk, ldp, C_):
     (1000, 240, 240, 1, True, True, True),
     (515, 176, 80, 0, False, False, True),        # ... with the raw operand (no transform to hide behind)
 ])
-def test_conv1x1_fwd(M, I, O, act, affine, bias, stats, expect=None):
+def test_conv1x1_fwd(M, I, O, act, affine, bias, stats):
+    check_conv1x1_fwd(M, I, O, act, affine, bias, stats)
+
+
+def check_conv1x1_fwd(M, I, O, act, affine, bias, stats, expect=None):
     g = torch.Generator().manual_seed(M + I + O)
     x = rnd(M, I, g=g)
     w = rnd(O, I, g=g, scale=1 / math.sqrt(I))
@@ -131,7 +135,11 @@ def test_conv1x1_fwd(M, I, O, act, affine, bias, stats, expect=None):
 
 
 @pytest.mark.parametrize('B,IH,IW,I,O', [(2, 6, 10, 16, 24)])
-def test_conv1x1_fwd_strided_rows(B, IH, IW, I, O, act=0, stats=False, expect=None):
+def test_conv1x1_fwd_strided_rows(B, IH, IW, I, O):
+    check_conv1x1_fwd_strided_rows(B, IH, IW, I, O)
+
+
+def check_conv1x1_fwd_strided_rows(B, IH, IW, I, O, act=0, stats=False, expect=None):
     g = torch.Generator().manual_seed(5 + I + O)
     x = rnd(B, IH, IW, I, g=g)
     w = rnd(O, I, g=g, scale=1 / math.sqrt(I))
@@ -184,7 +192,11 @@ def _bn_bwd_coeffs(g_, y, gamma, eps=1e-5):
     (1000, 240, 80, True, 0, True, True),
     (515, 176, 240, False, 1, False, True),       # ... one-tensor gradient operand
 ])
-def test_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=None):
+def test_conv1x1_dgrad(M, I, O, two, act, accum, stats):
+    check_conv1x1_dgrad(M, I, O, two, act, accum, stats)
+
+
+def check_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=None):
     g = torch.Generator().manual_seed(M + I + O + 1)
     gy = rnd(M, O, g=g)
     yout = rnd(M, O, g=g) + 0.3
@@ -282,7 +294,11 @@ def test_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=N
                                             (4096, 256, 512, True, False), (1024, 224, 120, True, False),
                                             (2048, 128, 96, False, False), (160, 96, 576, True, False),
                                             (16384, 352, 256, True, False)])
-def test_conv1x1_wgrad(M, I, O, two, bias, xa=True, expect=None):
+def test_conv1x1_wgrad(M, I, O, two, bias):
+    check_conv1x1_wgrad(M, I, O, two, bias)
+
+
+def check_conv1x1_wgrad(M, I, O, two, bias, xa=True, expect=None):
     g = torch.Generator().manual_seed(M + I + O + 2)
     gy = rnd(M, O, g=g)
     yout = rnd(M, O, g=g) + 0.3
@@ -668,7 +684,11 @@ def test_gconv3x3_fwd_bwd(B, H, W, Cc, gw, stride):
 
 
 @pytest.mark.parametrize('B,H,W,I,O,two', [(2, 10, 14, 32, 48, False), (2, 10, 14, 32, 48, True)])
-def test_conv1x1_strided_backward(B, H, W, I, O, two, expect=None, expect_w=None):
+def test_conv1x1_strided_backward(B, H, W, I, O, two):
+    check_conv1x1_strided_backward(B, H, W, I, O, two)
+
+
+def check_conv1x1_strided_backward(B, H, W, I, O, two, expect=None, expect_w=None):
     """Backward of a stride-2 1x1 conv: dz scatters (accumulating) onto every second pixel, the weight gradient gathers them."""
     g = torch.Generator().manual_seed(77 + I + O)
     l = abi.lib()
