@@ -187,19 +187,27 @@ PMC_PATTERN = {
     'conv1x1_fwd (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], |gemm2_nt_kernel<\d+, \d+, \d, [01], ', None),
     'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<|gemm2_tn_kernel<', r'pq::slab_reduce'),
     'conv1x1_bwd narrow layers (fused dgrad+wgrad, one pass over dy)': (r'pw_bwd_kernel<', r'pw_slab_reduce_kernel'),
+    'gconv3x3_fwd (implicit GEMM, fp32 MFMA)': (r'gconv_kernel<[01], ', None),
+    'gconv3x3_dgrad (implicit GEMM, fp32 MFMA)': (r'gconv_kernel<2, |gconv_dgrad_s2_kernel', None),
+    'gconv3x3_wgrad (implicit GEMM, fp32 MFMA)': (r'gconv_wgrad_kernel<', r'gconv_wgrad_reduce|gconv_slab'),
 }
-PMC_FILE = 'r3_pmc_summary.csv'
+# per (model, QAT plan): the PMC summary collected with scripts/profile_round.sh for exactly that plan (MODEL / BENCH_ARGS)
+PMC_FILES = {('mobilenetv2-fpn', False): 'r4_pmc_summary.csv', ('regnetx-600m-fpn', False): 'r4_pmc_summary_regnetx-600m-fpn.csv',
+             ('regnetx-600m-pan', False): 'r4_pmc_summary_regnetx-600m-pan.csv', ('mobilenetv2-fpn', True): 'r4_pmc_summary_qat.csv'}
 
 
-def measured_traffic(kernel_class, model_name):
+def measured_traffic(kernel_class, model_name, qat=False):
     """HBM bytes per launch of a kernel class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs of this command, gfx950 read correction applied -- scripts/pmc_summary.py), averaged over the launches of
     the class's kernels (both kernel generations) with the helper launches of the same op added in.  None if unavailable."""
     import csv
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', PMC_FILE)
+    fname = PMC_FILES.get((model_name, bool(qat)))
     main, extra = PMC_PATTERN.get(kernel_class, (None, None))
-    if model_name != 'mobilenetv2-fpn' or main is None or not os.path.exists(path):
+    if fname is None or main is None:
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', fname)
+    if not os.path.exists(path):
         return None
     calls = tot = 0.0
     for r in csv.DictReader(open(path)):
@@ -335,8 +343,8 @@ def main(args, world, rank, local):
             achieved, peak, unit = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9, PEAK_HBM_GBS, 'GB/s'
         total_ms = sum(v['ms'] for v in prof.values())
         roofline = {'bound': dom['bound'], 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
-                    'frac': round(achieved / peak, 4), 'traffic': measured_traffic(dom_name, args.model),
-                    'traffic_unit': 'HBM bytes per launch (profiles/%s)' % PMC_FILE,
+                    'frac': round(achieved / peak, 4), 'traffic': measured_traffic(dom_name, args.model, getattr(args, 'qat', False)),
+                    'traffic_unit': 'HBM bytes per launch (profiles/%s)' % PMC_FILES.get((args.model, bool(getattr(args, 'qat', False))), 'none'),
                     'algorithmic_per_launch': round((dom['flops'] if dom['bound'] == 'mfma' else dom['bytes']) / dom['launches']),
                     'algorithmic_bytes_per_launch': round(dom['bytes'] / dom['launches']), 'kernel': dom_name,
                     'kernel_avg_us': round(dom['ms'] * 1e3 / dom['launches'], 2),

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     EpiGeom eg;
     eg.m0w = m0 + __builtin_amdgcn_readfirstlane(wm) * WM; eg.n0w = n0 + __builtin_amdgcn_readfirstlane(wn) * WN;
     eg.lrow = lrow; eg.lh = lh; eg.M = M; eg.N = N;
-    eg.full = m0 + BM <= M && n0 + BN <= N;
+    eg.full = m0 + BM <= M;
 
     if (EMODE == 2) {
         const pq_gsink& sk = p.sink;

@@ -19,7 +19,7 @@ struct EpiGeom {
     int m0w, n0w;        // first row / column of the WAVE's tile (wave-uniform: built from readfirstlane'd wave coordinates)
     int lrow, lh;        // lane & 31, lane >> 5
     int M, N;
-    bool full;           // the whole WORKGROUP tile lies inside the matrix (uniform)
+    bool full;           // every ROW of the workgroup tile lies inside the matrix (uniform); columns past N are masked per lane
 };
 __device__ __forceinline__ int epi_rowc(int r) { return (r & 3) + 8 * (r >> 2); }
 
@@ -28,11 +28,11 @@ __device__ __forceinline__ int epi_rowc(int r) { return (r & 3) + 8 * (r >> 2); 
 template <int TI, int TJ, int EMODE, bool F>
 __device__ __forceinline__ void epi_store(const f32x16 (&acc)[TI][TJ], float* out, int ldo, const float* bias, const EpiGeom& g,
                                           float (&t1)[TJ], float (&t2)[TJ], float (&mn)[TJ], float (&mx)[TJ]) {
-    const unsigned oo = 4u * g.lh * (unsigned)ldo + g.lrow;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int n = g.n0w + 32 * j + g.lrow;
-        const bool nok = F || n < g.N;
+        const bool nok = n < g.N;                                       // (widths that are not multiples of the tile: the last column tile)
+        const unsigned oo = 4u * g.lh * (unsigned)ldo + (nok ? g.lrow : 0);
         const float bj = (bias != nullptr && nok) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
@@ -41,8 +41,8 @@ __device__ __forceinline__ void epi_store(const f32x16 (&acc)[TI][TJ], float* ou
             for (int r = 0; r < 16; ++r) {
                 const int row = epi_rowc(r);
                 const float v = acc[i][j][r] + bj;
-                const bool ok = F || (mb + 4 * g.lh + row < g.M && nok);
-                if (F) (out + (size_t)(mb + row) * (size_t)ldo + (g.n0w + 32 * j))[oo] = v;
+                const bool ok = nok && (F || mb + 4 * g.lh + row < g.M);
+                if (F) { if (nok) (out + (size_t)(mb + row) * (size_t)ldo + (g.n0w + 32 * j))[oo] = v; }
                 else if (ok) out[(size_t)(mb + 4 * g.lh + row) * ldo + n] = v;
                 if (EMODE != 0 && ok) {
                     t1[j] += v; t2[j] = fmaf(v, v, t2[j]);
@@ -81,10 +81,15 @@ __device__ __forceinline__ void sink_coefs(const pq_gsink& sk, const SinkFlags& 
 template <bool F>
 __device__ __forceinline__ void sink_block_loads(const pq_gsink& sk, const SinkFlags& f, const EpiGeom& g, int i, int j, float* yd, float* gd) {
     if (F) {
-        const unsigned oy = 4u * g.lh * (unsigned)sk.ldy + g.lrow, og = 4u * g.lh * (unsigned)sk.ldg + g.lrow;
+        // columns past N (widths that are not multiples of the tile): the block's base column is clamped to the last block that still
+        // has a valid column and the lane to the last valid column -- never an address past the row's end (the last rows of the
+        // tensor would otherwise read past the allocation); the values are discarded by the column mask of the store
+        const int nb = min(g.n0w + 32 * j, (g.N - 1) & ~31);                           // uniform
+        const unsigned lc = (unsigned)min(g.lrow, g.N - 1 - nb);
+        const unsigned oy = 4u * g.lh * (unsigned)sk.ldy + lc, og = 4u * g.lh * (unsigned)sk.ldg + lc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = g.m0w + 32 * i + epi_rowc(r), n = g.n0w + 32 * j;          // uniform
+            const int m = g.m0w + 32 * i + epi_rowc(r), n = nb;                       // uniform
             yd[r] = f.need_y ? (sk.y + (size_t)m * (size_t)sk.ldy + n)[oy] : 0.f;
             gd[r] = f.acc ? (sk.g + (size_t)m * (size_t)sk.ldg + n)[og] : 0.f;
         }
@@ -117,7 +122,7 @@ __device__ __forceinline__ void sink_emit(const f32x16 (&acc)[TI][TJ], const pq_
         const int j = b / TI, i = b % TI;
         if (!PRE && b + 1 < NBLK) sink_block_loads<F>(sk, f, g, (b + 1) % TI, (b + 1) / TI, yl[(b + 1) & 1], gl[(b + 1) & 1]);
         const int n = g.n0w + 32 * j + g.lrow;
-        const bool nok = F || n < g.N;
+        const bool nok = n < g.N;
         const int mb = g.m0w + 32 * i;
         const float* yy = PRE ? pre_y[PRE ? b : 0] : yl[b & 1];
         const float* gg = PRE ? pre_g[PRE ? b : 0] : gl[b & 1];
@@ -128,8 +133,8 @@ __device__ __forceinline__ void sink_emit(const f32x16 (&acc)[TI][TJ], const pq_
             const float uu = fmaf(c.a[j], yy[r], c.b[j]);
             dz *= f.need_y ? act_bwd(uu, sact) : 1.f;
             if (Q) { const float qv = rintf(act_fwd(uu, sact) * qinv) + qzp; dz = (qv >= 0.f && qv <= 255.f) ? dz : 0.f; }
-            const bool ok = F || (mb + 4 * g.lh + row < g.M && nok);
-            if (F) (sk.g + (size_t)(mb + row) * (size_t)sk.ldg + (g.n0w + 32 * j))[og] = dz;
+            const bool ok = nok && (F || mb + 4 * g.lh + row < g.M);
+            if (F) { if (nok) (sk.g + (size_t)(mb + row) * (size_t)sk.ldg + (g.n0w + 32 * j))[og] = dz; }
             else if (ok) sk.g[(size_t)(mb + 4 * g.lh + row) * sk.ldg + n] = dz;
             if (ok) {
                 t1[j] += dz;

@@ -4,23 +4,25 @@
 # usage (from the repo root on the GPU box): bash scripts/profile_round.sh
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r3}
+TAG=${TAG:-r4}
+# BENCH_ARGS: e.g. "--model regnetx-600m-fpn" or "--qat --batch 12"; SUFFIX names the summary (r4_pmc_summary$SUFFIX.csv)
+SUFFIX=${SUFFIX:-}
 OUT=$ROOT/gpurun_out/prof
-rm -rf $OUT && mkdir -p $OUT
+mkdir -p $OUT && rm -rf $OUT/stats $OUT/fetch $OUT/write
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
-python3 $ROOT/scripts/trace_timeline.py $(find $OUT/stats -name "$TAG*kernel_trace.csv" | head -1) > $OUT/${TAG}_step_timeline.txt 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline $BENCH_ARGS > $OUT/bench_under_rocprof$SUFFIX.json 2> $OUT/stats.log
+python3 $ROOT/scripts/trace_timeline.py $(find $OUT/stats -name "$TAG*kernel_trace.csv" | head -1) > $OUT/${TAG}_step_timeline$SUFFIX.txt 2>&1 || true
 echo "stats pass done"
 if [ -n "$STATS_ONLY" ]; then cp $(find $OUT/stats -name "$TAG*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv; rm -rf $OUT/stats; exit 0; fi
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/fetch.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline $BENCH_ARGS --steps 4 --warmup 2 > /dev/null 2> $OUT/fetch.log
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/write.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline $BENCH_ARGS --steps 4 --warmup 2 > /dev/null 2> $OUT/write.log
 echo "write pass done"
 cd $ROOT
 S=$(dirname $(find $OUT/stats -name "$TAG*kernel_stats.csv" | head -1))
 F=$(dirname $(find $OUT/fetch -name "$TAG*counter_collection.csv" | head -1))
 W=$(dirname $(find $OUT/write -name "$TAG*counter_collection.csv" | head -1))
-python3 scripts/pmc_summary.py $S $F $W $TAG > $OUT/${TAG}_pmc_summary.csv
-cp $(find $OUT/stats -name "$TAG*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
+python3 scripts/pmc_summary.py $S $F $W $TAG > $OUT/${TAG}_pmc_summary$SUFFIX.csv
+cp $(find $OUT/stats -name "$TAG*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats$SUFFIX.csv
 rm -rf $OUT/fetch $OUT/write $OUT/stats
 echo "summary done"

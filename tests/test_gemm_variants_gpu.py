@@ -81,6 +81,8 @@ DGRAD = [
     (4096, 512, 1024, True, 2, False, True, (2, 64, 64, 3, 2, 2, 0)),
     (131072, 64, 128, True, 2, False, True, (2, 64, 64, 3, 2, 2, 0)),
     (65500, 252, 128, True, 1, True, True, (2, 64, 128, 2, 2, 2, 0)),        # ragged M, N
+    (4096, 160, 960, True, 2, False, True, (2, 64, 64, 3, 2, 2, 0)),         # 160 = 2.5 column tiles: a wave's whole block lies past N (its
+                                                                             # prefetched sink operands are clamped into the row, round 4)
     (65536, 240, 240, True, 1, False, True, (2, 64, 128, 2, 2, 2, 0)),       # contraction (O) 16 modulo 32
     (16384, 528, 528, True, 1, False, True, (2, 64, 128, 2, 2, 2, 0)),
     (65536, 128, 256, False, 2, False, True, (2, 64, 128, 3, 0, 2, 0)),      # one-tensor gradient operand (conv without BatchNorm)
