@@ -660,7 +660,7 @@ int g2_wgrad_splits(int M, int I, int O);
 // Row-block height of the GEMM (M rows, N output columns, contraction K; kind 0 forward, 1 data gradient).  The BatchNorm
 // statistics rows are sized from it at plan time, so it is a pure function of the shape.  K % 16 == 0 (K >= 64) shapes are
 // tiled for the LDS-DMA kernels: the largest tile that still gives every CU two workgroups; the data gradient stages two
-// tensors per row, so its row block is 64 wherever that keeps two workgroups per CU in LDS.  PQ_G2_BM=64|128 forces (A/B).
+// tensors per row, so its row block is 64 wherever that keeps two workgroups per CU in LDS.
 static int row_bm(int M, int N, int K, int kind) {
     const bool g2 = K >= (kind == 0 ? 128 : 64) && (K & 15) == 0 && N >= 64;
     if (!g2) return pick_tile(M, N).bm;
