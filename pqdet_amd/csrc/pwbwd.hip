@@ -27,8 +27,22 @@ struct PwP {
 
 constexpr int PW_BM = 64;     // rows per tile
 
-// TD: 16-wide column tiles of the input gradient per wave, ceil(I/16) <= TD
-template <int TD, int PW_NB, int OCC>   // PW_NB: rows a thread keeps in flight while staging; OCC: workgroups per CU the register budget allows
+// Diagnostic build only (-DPQ_STAMPS, scripts/pw_stamps.py): cycles a workgroup spends in the phases of a tile (first barrier, stage
+// the operands, the two contractions, the sink), summed over its tiles, + the real time of its first and last instruction
+#ifdef PQ_STAMPS
+__device__ unsigned long long* pw_stamp_buf = nullptr;
+#define PW_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define PW_T(v)
+#endif
+
+// TD: 16-wide column tiles of the input gradient per wave, ceil(I/16) <= TD (tiles past I are computed on whatever LDS holds there and
+// never stored: no run-time tile count inside the MFMA loops, whose branches made the compiler drain lgkmcnt in front of every MFMA pair)
+// NZ / NX: rows of the gradient pair / of the layer input ONE thread stages per tile (a thread owns one channel quad and every
+// (256 / quads)-th row).  All of a tile's loads are issued as ONE batch: in the in-kernel stamps (scripts/pw_stamps.py) the staging
+// phase of round 3's kernel -- batches of 2..6 rows, each a full memory round trip, then the input's -- was 50-60 % of a tile's time.
+// OCC: workgroups per CU the register budget allows
+template <int TD, int NZ, int NX, int OCC>
 __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
     constexpr bool OWIDE = TD <= 2;               // which side of the weight gradient is dealt to the waves in 16-wide tiles
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -105,9 +119,8 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
 
     // The sink's y is normally the layer input itself (dx.y == in.x in every engine plan): the RAW input values a thread stages
     // stay in registers across the MFMA phase and serve the sink, instead of a second (L2-hit, but exposed) load per tile.
-    constexpr int NIT = TD <= 2 ? 1 : (TD <= 6 ? 2 : 4);      // staging rounds of PW_NB rows a thread needs at most (64 rows)
     constexpr bool KEEP = TD <= 6;                             // the 12-tile flavour (I up to 192) has no registers to spare
-    float4 xraw[KEEP ? NIT * PW_NB : 1];
+    float4 xraw[KEEP ? NX : 1];
     const bool same_y = KEEP && need_y && p.dx.y == p.x.x && p.dx.ldy == p.x.ld;
 
     f32x4 aw[3][2];      // [tile of the wide side: w, w+4, w+8][tile of the narrow side: 0, 1]
@@ -117,22 +130,43 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
         for (int b = 0; b < 2; ++b) aw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 s1 = f4zero(), s2 = f4zero();
 
+#ifdef PQ_STAMPS
+    unsigned long long tL = 0, tC = 0, tS = 0, tW = 0, nT = 0;
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime(), c_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
         const int m0 = tile * PW_BM;
+        PW_T(s0);
         __syncthreads();                          // previous tile's epilogue has read xs; Ws is written (first pass)
-        if (zact) {
-            const GsrcCoef4 gk = gcoef();
-            for (int r0 = zy; r0 < PW_BM; r0 += PW_NB * PYz) {
-                float4 g[PW_NB], y[PW_NB];
+        PW_T(s1_);
+        {
+            // every load of the tile first (rows past the tile are not requested, rows past the matrix re-read its last row) ...
+            // (a one-tensor operand reads g twice: `two ? load(y) : g` made the compiler WAIT for every g before it branched
+            // around the y load -- 2 x NZ serialised round trips per tile, in round 3's kernel as well)
+            float4 g[NZ], y[NZ], xv[NX];
+            const float* yp = two ? p.dy.y : p.dy.g;
+            const size_t yld = two ? (size_t)p.dy.ldy : (size_t)p.dy.ldg;
 #pragma unroll
-                for (int u = 0; u < PW_NB; ++u) {
-                    const int m = min(m0 + min(r0 + u * PYz, PW_BM - 1), p.M - 1);   // past the tile: re-read its last row (cache hit)
-                    g[u] = ldg4(p.dy.g + (size_t)m * p.dy.ldg + 4 * zx);
-                    y[u] = gk.two ? ldg4(p.dy.y + (size_t)m * p.dy.ldy + 4 * zx) : g[u];
+            for (int u = 0; u < NZ; ++u) {
+                g[u] = f4zero(); y[u] = f4zero();
+                if (zact && zy + u * PYz < PW_BM) {
+                    const size_t m = (size_t)min(m0 + zy + u * PYz, p.M - 1);
+                    g[u] = ldg4(p.dy.g + m * p.dy.ldg + 4 * zx);
+                    y[u] = ldg4(yp + m * yld + 4 * zx);
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < PW_NB; ++u) {
-                    const int r = r0 + u * PYz;
+            for (int u = 0; u < NX; ++u) {
+                xv[u] = f4zero();
+                if (iact && iy + u * PYi < PW_BM) xv[u] = ldg4(p.x.x + (size_t)min(m0 + iy + u * PYi, p.M - 1) * p.x.ld + 4 * ix);
+                if (KEEP) xraw[u] = xv[u];
+            }
+            // ... then transform and store
+            if (zact) {
+                const GsrcCoef4 gk = gcoef();
+#pragma unroll
+                for (int u = 0; u < NZ; ++u) {
+                    const int r = zy + u * PYz;
                     if (r < PW_BM) {
                         float4 v = gsrc_apply4(g[u], y[u], gk);
                         if (m0 + r >= p.M) v = f4zero();
@@ -140,33 +174,21 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
                     }
                 }
             }
-        }
-        if (iact) {
-            const SrcCoef4 xk = xcoef();
+            if (iact) {
+                const SrcCoef4 xk = xcoef();
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int r0 = iy + it * PW_NB * PYi;
-                if (r0 < PW_BM) {
-                    float4 xv[PW_NB];
-#pragma unroll
-                    for (int u = 0; u < PW_NB; ++u) {
-                        const int m = min(m0 + min(r0 + u * PYi, PW_BM - 1), p.M - 1);
-                        xv[u] = ldg4(p.x.x + (size_t)m * p.x.ld + 4 * ix);
-                        if (KEEP) xraw[it * PW_NB + u] = xv[u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < PW_NB; ++u) {
-                        const int r = r0 + u * PYi;
-                        if (r < PW_BM) {
-                            float4 v = src_apply4(xv[u], xk);
-                            if (m0 + r >= p.M) v = f4zero();
-                            *reinterpret_cast<float4*>(&xs[r * LDX + 4 * ix]) = v;
-                        }
+                for (int u = 0; u < NX; ++u) {
+                    const int r = iy + u * PYi;
+                    if (r < PW_BM) {
+                        float4 v = src_apply4(xv[u], xk);
+                        if (m0 + r >= p.M) v = f4zero();
+                        *reinterpret_cast<float4*>(&xs[r * LDX + 4 * ix]) = v;
                     }
                 }
             }
         }
         __syncthreads();
+        PW_T(s2_);
 
         // input gradient: wave w owns rows 16w..16w+15 and all column tiles; contraction over the O output channels,
         // two k-steps per iteration (operands fetched from LDS before the MFMAs; KS interleaved accumulator sets keep
@@ -181,21 +203,37 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
             const float* arow = dzs + (16 * w + l16) * LDZ + lq;
             const float* brow = Ws + lq * LDX + l16;
             int k0 = 0;
-            for (; k0 + 8 <= O; k0 += 8) {
-                const float a0 = arow[k0], a1 = arow[k0 + 4];
-                float b0[TD], b1[TD];
+            const int kend = O & ~7;
+            constexpr bool PRE = TD <= 2;          // operands of the next step leave LDS before this step's MFMAs (registers: narrow flavours only)
+            float a0 = 0.f, a1 = 0.f, b0[TD], b1[TD];
+            auto fetch = [&](int k, float& fa0, float& fa1, float (&fb0)[TD], float (&fb1)[TD]) {
+                fa0 = arow[k]; fa1 = arow[k + 4];
 #pragma unroll
-                for (int c = 0; c < TD; ++c)
-                    if (c < I16) { b0[c] = brow[k0 * LDX + 16 * c]; b1[c] = brow[(k0 + 4) * LDX + 16 * c]; }
+                for (int c = 0; c < TD; ++c) { fb0[c] = brow[k * LDX + 16 * c]; fb1[c] = brow[(k + 4) * LDX + 16 * c]; }
+            };
+            if (PRE && kend > 0) fetch(0, a0, a1, b0, b1);
+            for (; k0 < kend; k0 += 8) {
+                if (PRE) {
+                    float na0 = 0.f, na1 = 0.f, nb0[TD], nb1[TD];
+                    const int kn = k0 + 8 < kend ? k0 + 8 : k0;        // (last step: re-reads its own operands, unused)
+                    fetch(kn, na0, na1, nb0, nb1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < TD; ++c)
-                    if (c < I16) { ad[0][c] = mfma16(a0, b0[c], ad[0][c]); ad[KS - 1][c] = mfma16(a1, b1[c], ad[KS - 1][c]); }
+                    for (int c = 0; c < TD; ++c) { ad[0][c] = mfma16(a0, b0[c], ad[0][c]); ad[KS - 1][c] = mfma16(a1, b1[c], ad[KS - 1][c]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    a0 = na0; a1 = na1;
+#pragma unroll
+                    for (int c = 0; c < TD; ++c) { b0[c] = nb0[c]; b1[c] = nb1[c]; }
+                } else {
+                    fetch(k0, a0, a1, b0, b1);
+#pragma unroll
+                    for (int c = 0; c < TD; ++c) { ad[0][c] = mfma16(a0, b0[c], ad[0][c]); ad[KS - 1][c] = mfma16(a1, b1[c], ad[KS - 1][c]); }
+                }
             }
             for (; k0 < O; k0 += 4) {
-                const float a0 = arow[k0];
+                const float ta = arow[k0];
 #pragma unroll
-                for (int c = 0; c < TD; ++c)
-                    if (c < I16) ad[0][c] = mfma16(a0, brow[k0 * LDX + 16 * c], ad[0][c]);
+                for (int c = 0; c < TD; ++c) ad[0][c] = mfma16(ta, brow[k0 * LDX + 16 * c], ad[0][c]);
             }
             if (KS == 2) {
 #pragma unroll
@@ -230,10 +268,11 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
             else { if (na == 3) run(i3{}, i1{}); else if (na == 2) run(i2{}, i1{}); else if (na == 1) run(i1{}, i1{}); }
         }
         __syncthreads();                          // all waves are done with xs (and dzs)
+        PW_T(s3_);
 #pragma unroll
         for (int c = 0; c < TD; ++c) {
             const int col = 16 * c + l16;
-            if (c < I16 && col < I) {
+            if (col < I) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xs[(16 * w + 4 * lq + j) * LDX + col] = ad[0][c][j];
             }
@@ -241,29 +280,50 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
         __syncthreads();
         if (iact) {
             const SinkCoef4 sk = scoef();
+            constexpr int SC = TD >= 12 ? 7 : NX;     // the sink's own loads (running gradient; y where it is not kept): one batch as well (widest flavour: two)
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int r0 = iy + it * PW_NB * PYi;
-                if (r0 < PW_BM) {
-                    float4 go[PW_NB], yv[PW_NB];
+            for (int u0 = 0; u0 < NX; u0 += SC) {
+                // three straight-line passes: every load (rows past the tile / the matrix: a clamped, valid row), every value, then the
+                // stores.  With the loads and stores inside per-row `if`s the compiler could not count what was outstanding and put
+                // s_waitcnt vmcnt(0) in front of every row: each row then waited for the previous row's STORE (stamps: 14-20 k cycles).
+                float4 go[SC], yv[SC];
 #pragma unroll
-                    for (int u = 0; u < PW_NB; ++u) {
-                        const int m = min(m0 + min(r0 + u * PYi, PW_BM - 1), p.M - 1);
-                        go[u] = p.dx.accumulate ? ldg4(p.dx.g + (size_t)m * p.dx.ldg + 4 * ix) : f4zero();
-                        yv[u] = same_y ? xraw[KEEP ? it * PW_NB + u : 0] : (need_y ? ldg4(p.dx.y + (size_t)m * p.dx.ldy + 4 * ix) : f4zero());
-                    }
+                for (int v = 0; v < SC; ++v) {
+                    const int u = min(u0 + v, NX - 1), r = min(iy + u * PYi, PW_BM - 1);
+                    const size_t m = (size_t)min(m0 + r, p.M - 1);
+                    go[v] = f4zero(); yv[v] = f4zero();
+                    if (p.dx.accumulate) go[v] = ldg4(p.dx.g + m * p.dx.ldg + 4 * ix);
+                    if (same_y) yv[v] = xraw[KEEP ? u : 0];
+                    else if (need_y) yv[v] = ldg4(p.dx.y + m * p.dx.ldy + 4 * ix);
+                }
 #pragma unroll
-                    for (int u = 0; u < PW_NB; ++u) {
-                        const int r = r0 + u * PYi, m = m0 + r;
-                        if (r < PW_BM && m < p.M) {
-                            float4 dz = f4add(*reinterpret_cast<const float4*>(&xs[r * LDX + 4 * ix]), go[u]);
-                            stg4(p.dx.g + (size_t)m * p.dx.ldg + 4 * ix, sink_apply4(p.dx, sk, dz, yv[u], s1, s2));
-                        }
-                    }
+                for (int v = 0; v < SC; ++v) {
+                    const int u = u0 + v, r = iy + u * PYi;
+                    const bool ok = u < NX && r < PW_BM && m0 + r < p.M;
+                    const float4 dz = f4add(*reinterpret_cast<const float4*>(&xs[min(r, PW_BM - 1) * LDX + 4 * ix]), go[v]);
+                    float4 a1 = s1, a2 = s2;
+                    go[v] = sink_apply4(p.dx, sk, dz, yv[v], a1, a2);
+                    s1.x = ok ? a1.x : s1.x; s1.y = ok ? a1.y : s1.y; s1.z = ok ? a1.z : s1.z; s1.w = ok ? a1.w : s1.w;
+                    s2.x = ok ? a2.x : s2.x; s2.y = ok ? a2.y : s2.y; s2.z = ok ? a2.z : s2.z; s2.w = ok ? a2.w : s2.w;
+                }
+#pragma unroll
+                for (int v = 0; v < SC; ++v) {
+                    const int u = u0 + v, r = iy + u * PYi, m = m0 + r;
+                    if (u < NX && r < PW_BM && m < p.M) stg4(p.dx.g + (size_t)m * p.dx.ldg + 4 * ix, go[v]);
                 }
             }
         }
+#ifdef PQ_STAMPS
+        { PW_T(s4_); tW += s1_ - s0; tL += s2_ - s1_; tC += s3_ - s2_; tS += s4_ - s3_; ++nT; }
+#endif
     }
+#ifdef PQ_STAMPS
+    if (t == 0 && pw_stamp_buf) {
+        unsigned long long* o = pw_stamp_buf + (size_t)blockIdx.x * 8;
+        o[0] = tW; o[1] = tL; o[2] = tC; o[3] = tS; o[4] = r_begin; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = nT;
+        o[7] = __builtin_amdgcn_s_memtime() - c_begin;
+    }
+#endif
 
     // weight-gradient slab of this workgroup
     float* dst = p.slab + (size_t)blockIdx.x * O * I;
@@ -347,7 +407,7 @@ static int pw_pitch(int x) {
     return v;
 }
 
-struct PwPlan { bool ok, deep; int ldz, ldx, tiles, grid; size_t lds_bytes; };
+struct PwPlan { bool ok; int nz, nx, occ; int ldz, ldx, tiles, grid; size_t lds_bytes; };
 static PwPlan pw_plan(int M, int I, int O) {
     PwPlan pl{};
     const int lo = I < O ? I : O, hi = I < O ? O : I;
@@ -361,12 +421,14 @@ static PwPlan pw_plan(int M, int I, int O) {
     pl.lds_bytes = fl * 4;
     pl.tiles = (M + PW_BM - 1) / PW_BM;
     int occ = (int)((160 * 1024) / pl.lds_bytes);
-    // narrow-I flavour: 3 workgroups per CU with 2 rows in flight per thread while LDS allows it; wide O (LDS for 2 at most):
-    // 6 rows in flight instead
-    pl.deep = (I + 15) / 16 <= 2 && occ < 3;
-    const int reg_occ = ((I + 15) / 16 <= 2 && !pl.deep) ? 3 : 2;
+    // rows one thread stages per tile: the 256 threads cover 256 / quads rows per pass
+    pl.nz = (PW_BM + 256 / (O / 4) - 1) / (256 / (O / 4));
+    pl.nx = (PW_BM + 256 / (I / 4) - 1) / (256 / (I / 4));
+    // register budget: three workgroups per CU while a thread holds at most 2 rows of the gradient pair (O <= 32), else two
+    const int reg_occ = ((I + 15) / 16 <= 2 && pl.nz <= 2) ? 3 : 2;
     if (occ > reg_occ) occ = reg_occ;
     if (occ < 1) occ = 1;
+    pl.occ = occ;
     int grid = 256 * occ;
     const int half = pl.tiles / 2 > 256 ? pl.tiles / 2 : 256;     // at least two tiles per workgroup once the chip is covered
     if (grid > half) grid = half;
@@ -395,17 +457,22 @@ extern "C" int64_t pq_conv1x1_bwd_scratch_bytes(int32_t M, int32_t I, int32_t O)
     return pl.ok ? (int64_t)pl.grid * O * I * 4 : 0;
 }
 
-template <int TD, int NB, int OCC>
+#ifdef PQ_STAMPS
+extern "C" int pq_debug_set_stamps_pw(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(pq::pw_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+template <int TD, int NZ, int NX, int OCC>
 static int pw_launch(const PwP& p, const PwPlan& pl, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)pw_bwd_kernel<TD, NB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)pw_bwd_kernel<TD, NZ, NX, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             pq_set_error("pq_conv1x1_bwd: cannot raise the dynamic LDS limit");
             return PQ_ELAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((pw_bwd_kernel<TD, NB, OCC>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, p);
+    hipLaunchKernelGGL((pw_bwd_kernel<TD, NZ, NX, OCC>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, p);
     return PQ_OK;
 }
 
@@ -449,9 +516,20 @@ extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int i16 = (a->I + 15) / 16;
     int rc;
-    if (i16 <= 2) rc = pl.deep ? pw_launch<2, 6, 2>(p, pl, st) : pw_launch<2, 2, 3>(p, pl, st);
-    else if (i16 <= 6) rc = pw_launch<6, 4, 2>(p, pl, st);
-    else rc = pw_launch<12, 4, 2>(p, pl, st);
+    // flavours: <input-gradient column tiles, rows of the gradient pair per thread, rows of the input per thread, workgroups per CU>
+    if (i16 <= 1) {              // I <= 16: one row of the input per thread; O up to 192
+        if (pl.nz <= 2) rc = pw_launch<1, 2, 1, 3>(p, pl, st);
+        else if (pl.nz <= 7) rc = pw_launch<1, 7, 1, 2>(p, pl, st);
+        else if (pl.nz <= 10) rc = pw_launch<1, 10, 1, 2>(p, pl, st);
+        else rc = pw_launch<1, 13, 1, 2>(p, pl, st);
+    } else if (i16 <= 2) {       // I <= 32
+        if (pl.nz <= 2) rc = pw_launch<2, 2, 2, 3>(p, pl, st);
+        else if (pl.nz <= 7) rc = pw_launch<2, 7, 2, 2>(p, pl, st);
+        else if (pl.nz <= 10) rc = pw_launch<2, 10, 2, 2>(p, pl, st);
+        else rc = pw_launch<2, 13, 2, 2>(p, pl, st);
+    } else if (i16 <= 6) rc = pw_launch<6, 2, 7, 2>(p, pl, st);        // I <= 96, O <= 32
+    else if (i16 <= 9) rc = pw_launch<9, 2, 10, 2>(p, pl, st);         // I <= 144
+    else rc = pw_launch<12, 2, 13, 2>(p, pl, st);                      // I <= 192
     if (rc != PQ_OK) return rc;
     PQ_CHECK_LAUNCH();
     const int n = a->O * a->I;

@@ -1,1 +1,7 @@
-for v in 1 0 1 0; do echo "PQ_BN_ATOMIC=$v"; PQ_BN_ATOMIC=$v timeout -k 10 200 python bench.py --no-cpu-baseline 2>/dev/null | cut -c100-200; done
+#!/bin/bash
+# temporary A/B driver: start stagger of the fused narrow backward
+mkdir -p gpurun_out/r4l
+for pct in 0 50 100 150; do
+  echo "== PQ_PW_STAGGER=$pct"
+  PQ_PW_STAGGER=$pct PQDET_HIP_LIB=pqdet_amd/lib/libpqdet_hip_stamps.so timeout -k 10 300 python scripts/pw_stamps.py 2>&1 | grep "^M=" | cut -c1-330
+done
