@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s2_kernel(DwWP p) {
         float* ct = reinterpret_cast<float*>(&ctab[t >> 2][0]) + (t & 3);
         ct[0] = k1.p; ct[4] = k1.q; ct[8] = k1.mu; ct[12] = k1.r;
     }
-    if (pl == 0) {
+    if (pl == 8) {             // (wave 1: beside the hand-over derivation above, which runs in wave 0)
         const SinkCoef4 k0 = sink_coef4(p.sink, cc, p.C);
         if (!dy_stat) {
             const GsrcCoef4 g0 = gsrc_coef4(p.dy, cc, p.C);
@@ -85,12 +85,23 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s2_kernel(DwWP p) {
         }
         ctab[q][4] = make_float4(k0.mean[0], k0.mean[1], k0.mean[2], k0.mean[3]);
         ctab[q][5] = make_float4(k0.inv[0], k0.inv[1], k0.inv[2], k0.inv[3]);
+        {
+            // all 36 taps of the quad requested before the first one is used (unconditional loads at clamped channels: with the loads
+            // inside per-element conditions the compiler waited for every tap's four loads before it issued the next four -- nine
+            // serialised round trips at the head of every workgroup)
+            float e[9][4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            float e[4];
+            for (int j = 0; j < 4; ++j) {
+                const float* wp = p.w + (size_t)min(cc + j, p.C - 1) * 9;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = (cok && c0 + j < p.C) ? p.w[(size_t)(c0 + j) * 9 + k] : 0.f;
-            wtab[q][k] = make_float4(e[0], e[1], e[2], e[3]);
+                for (int k = 0; k < 9; ++k) e[k][j] = wp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[k][j] = (cok && c0 + j < p.C) ? e[k][j] : 0.f;
+                wtab[q][k] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
+            }
         }
     }
     __syncthreads();
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s1_kernel(DwWP p) {
         float* ct = reinterpret_cast<float*>(&ctab[t >> 2][0]) + (t & 3);
         ct[0] = k1.p; ct[4] = k1.q; ct[8] = k1.mu; ct[12] = k1.r;
     }
-    if (pl == 0) {
+    if (pl == 8) {             // (wave 1: beside the hand-over derivation above, which runs in wave 0)
         const SinkCoef4 k0 = sink_coef4(p.sink, cc, p.C);
         if (!dy_stat) {
             const GsrcCoef4 g0 = gsrc_coef4(p.dy, cc, p.C);
@@ -362,12 +373,23 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s1_kernel(DwWP p) {
         }
         ctab[q][4] = make_float4(k0.mean[0], k0.mean[1], k0.mean[2], k0.mean[3]);
         ctab[q][5] = make_float4(k0.inv[0], k0.inv[1], k0.inv[2], k0.inv[3]);
+        {
+            // all 36 taps of the quad requested before the first one is used (unconditional loads at clamped channels: with the loads
+            // inside per-element conditions the compiler waited for every tap's four loads before it issued the next four -- nine
+            // serialised round trips at the head of every workgroup)
+            float e[9][4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            float e[4];
+            for (int j = 0; j < 4; ++j) {
+                const float* wp = p.w + (size_t)min(cc + j, p.C - 1) * 9;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = (cok && c0 + j < p.C) ? p.w[(size_t)(c0 + j) * 9 + k] : 0.f;
-            wtab[q][k] = make_float4(e[0], e[1], e[2], e[3]);
+                for (int k = 0; k < 9; ++k) e[k][j] = wp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[k][j] = (cok && c0 + j < p.C) ? e[k][j] : 0.f;
+                wtab[q][k] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
+            }
         }
     }
     auto ring = [&](int slot) { return slot >= R ? slot - R : slot; };
@@ -596,12 +618,23 @@ __global__ __launch_bounds__(256, 3) void dw_fwd_walk_s1_kernel(DwFWP p) {
     const SrcCoef4 xk = p.in.stat.acc ? src_coef4_chunk32(p.in, cq0 * 4, q, p.C, tIdx == 0, reinterpret_cast<float*>(xtr))
                                       : src_coef4(p.in, cc, p.C);
     if (pl == 0) {
+        {
+            // all 36 taps of the quad requested before the first one is used (unconditional loads at clamped channels: with the loads
+            // inside per-element conditions the compiler waited for every tap's four loads before it issued the next four -- nine
+            // serialised round trips at the head of every workgroup)
+            float e[9][4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            float e[4];
+            for (int j = 0; j < 4; ++j) {
+                const float* wp = p.w + (size_t)min(cc + j, p.C - 1) * 9;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = (cok && c0 + j < p.C) ? p.w[(size_t)(c0 + j) * 9 + k] : 0.f;
-            wtab[q][k] = make_float4(e[0], e[1], e[2], e[3]);
+                for (int k = 0; k < 9; ++k) e[k][j] = wp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[k][j] = (cok && c0 + j < p.C) ? e[k][j] : 0.f;
+                wtab[q][k] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
+            }
         }
     }
     auto ring = [&](int slot) { return slot >= R ? slot - R : slot; };
