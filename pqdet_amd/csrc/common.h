@@ -89,7 +89,9 @@ __device__ __forceinline__ BnSums bn_acc_load(const int64_t* acc, int slots, int
     return r;
 }
 __device__ __forceinline__ BnSums bn_stat_load(const pq_bn_stat& st, int c) { return bn_acc_load(st.acc, st.slots, st.ldp, c); }
-__device__ __forceinline__ BnCoef bn_stat_finish(const pq_bn_stat& st, int c, const BnSums& u, bool bad, bool writer) {
+// gamma / beta: the channel's affine parameters, loaded by the caller TOGETHER with the accumulators (loaded here, after the fp64
+// chain, they were a second exposed round trip in every consumer's prologue)
+__device__ __forceinline__ BnCoef bn_stat_finish(const pq_bn_stat& st, int c, const BnSums& u, bool bad, bool writer, float gamma, float beta) {
     double t1 = (double)u.hi1 + (double)u.lo1 * 0x1p-50, t2 = (double)u.hi2 + (double)u.lo2 * 0x1p-50;
     if (bad) t1 = t2 = __builtin_nan("");
     const double invn = (double)st.inv_count;
@@ -99,8 +101,8 @@ __device__ __forceinline__ BnCoef bn_stat_finish(const pq_bn_stat& st, int c, co
     BnCoef k;
     k.inv = 1.0f / sqrtf((float)var + st.eps);
     k.mean = (float)mean;
-    k.scale = st.gamma[c] * k.inv;
-    k.shift = st.beta[c] - k.mean * k.scale;
+    k.scale = gamma * k.inv;
+    k.shift = beta - k.mean * k.scale;
     if (writer) {
         st.mean[c] = k.mean; st.invstd[c] = k.inv; st.scale[c] = k.scale; st.shift[c] = k.shift;
         if (st.running_mean) {
@@ -123,14 +125,13 @@ __device__ __forceinline__ void bn_stat_coefs(const pq_bn_stat& st, int c0, int 
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int c = min(c0 + i * stride, C - 1);
-        u[i] = bn_stat_load(st, c);
         g[i] = st.gamma[c]; b[i] = st.beta[c];
+        u[i] = bn_stat_load(st, c);
     }
-    (void)g; (void)b;
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int c = c0 + i * stride;
-        if (c < C) out(c, bn_stat_finish(st, c, u[i], bad != 0, writer));
+        if (c < C) out(c, bn_stat_finish(st, c, u[i], bad != 0, writer, g[i], b[i]));
     }
 }
 
@@ -196,6 +197,7 @@ __device__ __forceinline__ SrcCoef4 src_coef4_chunk32(const pq_src& s, int chunk
     if ((part >> 1) < st.slots)
         stage[part * 32 + ch] = *reinterpret_cast<const longlong2*>(st.acc + (((size_t)(part >> 1) * 2 + (part & 1)) * st.ldp + c) * 2);
     const unsigned bad = *st.bad;
+    const float ga = st.gamma[c], be = st.beta[c];                         // (same round trip as the accumulators)
     __syncthreads();
     if (t < 32) {
         BnSums u{0, 0, 0, 0};
@@ -204,7 +206,7 @@ __device__ __forceinline__ SrcCoef4 src_coef4_chunk32(const pq_src& s, int chunk
             u.lo1 += a.x; u.hi1 += a.y; u.lo2 += b.x; u.hi2 += b.y;
         }
         float sc = 1.f, sh = 0.f;
-        if (chunk0 + ch < C) { const BnCoef bc = bn_stat_finish(st, chunk0 + ch, u, bad != 0, writer); sc = bc.scale; sh = bc.shift; }
+        if (chunk0 + ch < C) { const BnCoef bc = bn_stat_finish(st, chunk0 + ch, u, bad != 0, writer, ga, be); sc = bc.scale; sh = bc.shift; }
         coef[ch] = sc; coef[32 + ch] = sh;
     }
     __syncthreads();
@@ -252,10 +254,10 @@ __device__ __forceinline__ GsrcCoef4 gsrc_coef4(const pq_gsrc& s, int c0, int C)
 struct GsrcCoef1 { float p, q, mu, r; };
 __device__ __forceinline__ GsrcCoef1 gsrc_coef1_bstat(const pq_gsrc& s, const pq_bn_bstat& st, int c, bool writer) {
     const unsigned bad = *st.bad;
+    const float ga = st.gamma[c], iv = st.invstd[c];         // (in front of the accumulator loads and their uniform branch on the slot
+    GsrcCoef1 k;                                             //  count: behind it the compiler issued them after the accumulators'
+    k.mu = s.mu[c];                                          //  wait -- a second exposed round trip)
     const BnSums u = bn_acc_load(st.acc, st.slots, st.ldp, c);
-    const float ga = st.gamma[c], iv = st.invstd[c];
-    GsrcCoef1 k;
-    k.mu = s.mu[c];
     double t1 = (double)u.hi1 + (double)u.lo1 * 0x1p-50, t2 = (double)u.hi2 + (double)u.lo2 * 0x1p-50;
     if (bad) t1 = t2 = __builtin_nan("");
     const double invn = 1.0 / (double)st.count;

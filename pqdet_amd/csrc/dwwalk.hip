@@ -615,26 +615,25 @@ __global__ __launch_bounds__(256, 3) void dw_fwd_walk_s1_kernel(DwFWP p) {
     const int cc = cok ? c0 : 0;
     // (with p.in.stat: the workgroup derives its 32 channels' coefficients from the producer's accumulators; workgroup 0 of the
     // channel chunk also stores the vectors for every later consumer)
+    // the 36 taps of the quad are requested BEFORE the derivation (unconditional loads at clamped channels, all in flight at once; they
+    // share the round trip of the accumulator loads: the derivation's first barrier drains both) and written to LDS after it
+    float e[9][4];
+    if (pl == 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* wp = p.w + (size_t)min(cc + j, p.C - 1) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k][j] = wp[k];
+        }
+    }
     const SrcCoef4 xk = p.in.stat.acc ? src_coef4_chunk32(p.in, cq0 * 4, q, p.C, tIdx == 0, reinterpret_cast<float*>(xtr))
                                       : src_coef4(p.in, cc, p.C);
-    if (pl == 0) {
-        {
-            // all 36 taps of the quad requested before the first one is used (unconditional loads at clamped channels: with the loads
-            // inside per-element conditions the compiler waited for every tap's four loads before it issued the next four -- nine
-            // serialised round trips at the head of every workgroup)
-            float e[9][4];
+    if (pl == 8) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float* wp = p.w + (size_t)min(cc + j, p.C - 1) * 9;
+        for (int k = 0; k < 9; ++k) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) e[k][j] = wp[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[k][j] = (cok && c0 + j < p.C) ? e[k][j] : 0.f;
-                wtab[q][k] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
-            }
+            for (int j = 0; j < 4; ++j) e[k][j] = (cok && c0 + j < p.C) ? e[k][j] : 0.f;
+            wtab[q][k] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
         }
     }
     auto ring = [&](int slot) { return slot >= R ? slot - R : slot; };

@@ -161,11 +161,16 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
     // arithmetic follows the weight staging below (the round trip hides behind it; every workgroup of the grid pays this
     // prologue); the workgroup of logical tile 0 of every group also stores the vectors / running statistics
     BnSums su[4];
+    float sga[4] = {1.f, 1.f, 1.f, 1.f}, sbe[4] = {0.f, 0.f, 0.f, 0.f};
     unsigned sbad = 0;
     if (from_stat && t < gq) {
         sbad = *p.in.stat.bad;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) su[i] = bn_stat_load(p.in.stat, min(cbase + 4 * t + i, p.C - 1));
+        for (int i = 0; i < 4; ++i) {
+            const int c = min(cbase + 4 * t + i, p.C - 1);
+            su[i] = bn_stat_load(p.in.stat, c);
+            sga[i] = p.in.stat.gamma[c]; sbe[i] = p.in.stat.beta[c];
+        }
     }
     // ---- stage B (this group's weights, k = tap*gw + i): row n = t/8, eight lanes walk k; four loads in flight
     {
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = cbase + 4 * t + i;
-                if (c < p.C) { const BnCoef bc = bn_stat_finish(p.in.stat, c, su[i], sbad != 0, writer); lco[4 * t + i] = bc.scale; lco[32 + 4 * t + i] = bc.shift; }
+                if (c < p.C) { const BnCoef bc = bn_stat_finish(p.in.stat, c, su[i], sbad != 0, writer, sga[i], sbe[i]); lco[4 * t + i] = bc.scale; lco[32 + 4 * t + i] = bc.shift; }
             }
         }
         __syncthreads();               // the coefficient table
