@@ -348,6 +348,14 @@ def check_conv1x1_wgrad(M, I, O, two, bias, xa=True, expect=None):
     (32768, 24, 144, True, 0, False, False),     # linear sink without statistics
     (35000, 192, 32, False, 1, True, True),      # dy' = g (no BatchNorm after the conv), 12 column tiles
     (34000, 96, 24, True, 3, False, True),       # leaky
+    # round 4: one instantiation per (column tiles, rows of dy per thread, rows of x per thread) -- the remaining ones
+    (33000, 16, 32, True, 2, False, True),       # <1, 2, 1>
+    (33000, 16, 144, True, 2, True, True),       # <1, 10, 1>
+    (33000, 16, 192, False, 0, False, False),    # <1, 13, 1>, one-tensor operand
+    (33000, 32, 96, True, 2, False, True),       # <2, 7, 2>
+    (33000, 32, 192, True, 1, True, True),       # <2, 13, 2>
+    (33000, 48, 24, True, 2, False, True),       # <6, 2, 7> with three of its six column tiles in use
+    (33000, 176, 24, True, 2, True, True),       # <12, 2, 13> with eleven of twelve, two sink batches
 ])
 def test_conv1x1_bwd_fused_matches_the_two_kernel_backward(M, I, O, two, act, accum, stats):
     """pq_conv1x1_bwd (one pass) against the fp64 statement AND against pq_conv1x1_dgrad + pq_conv1x1_wgrad."""
