@@ -28,12 +28,24 @@ __device__ __forceinline__ int epi_rowc(int r) { return (r & 3) + 8 * (r >> 2); 
 template <int TI, int TJ, int EMODE, bool F>
 __device__ __forceinline__ void epi_store(const f32x16 (&acc)[TI][TJ], float* out, int ldo, const float* bias, const EpiGeom& g,
                                           float (&t1)[TJ], float (&t2)[TJ], float (&mn)[TJ], float (&mx)[TJ]) {
+    // every column block's bias first: loaded inside the block loop, the (conditional) load's wait sat in front of each block's first
+    // store as s_waitcnt vmcnt(0) -- with or without a bias it drained the PREVIOUS block's 16 stores, TJ - 1 store round trips per tile
+    float bjv[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int n = g.n0w + 32 * j + g.lrow;
+        bjv[j] = (bias != nullptr && n < g.N) ? bias[n] : 0.f;
+    }
+    // (an opaque use in straight-line code: the compiler waits for the conditional loads HERE, once; without it every later
+    // lane-masked store block re-waited for them with vmcnt(0), which also drains the stores issued since)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) asm volatile("" : "+v"(bjv[j]));
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int n = g.n0w + 32 * j + g.lrow;
         const bool nok = n < g.N;                                       // (widths that are not multiples of the tile: the last column tile)
         const unsigned oo = 4u * g.lh * (unsigned)ldo + (nok ? g.lrow : 0);
-        const float bj = (bias != nullptr && nok) ? bias[n] : 0.f;
+        const float bj = bjv[j];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int mb = g.m0w + 32 * i;
