@@ -45,3 +45,9 @@ for x in g:
 for k in range(len(h)): print('  [%g, %g) us: %d gaps, %.3f ms' % (edges[k], edges[k + 1], h[k], hs[k] / 1e3))
 print('largest gaps:')
 for x in g[-12:]: print('  %.1f us after %s -> before %s (at %.2f ms)' % x)
+# the tail of the step: what still runs after the main queue's last kernel in front of the optimiser (the join of the two streams)
+adam_s = step[-1][0]
+tail = [(s, e, n, q) for s, e, n, q in step[:-1] if e > adam_s - 400000]
+print('last 400 us in front of adam_kernel (start us before adam, duration us, queue, kernel):')
+for s, e, n, q in sorted(tail)[-28:]:
+    print('  -%7.1f  %6.1f  q%s  %s' % ((adam_s - s) / 1e3, (e - s) / 1e3, 'M' if q == mainq else 'S', n[:90]))
