@@ -153,7 +153,8 @@ typedef struct pq_conv1x1_fwd_args {
     pq_src in;
     const float* w;      /* [O][I] */
     const float* bias;   /* [O] or NULL */
-    float* out;          /* [M][ldo] raw */
+    float* out;          /* [M][ldo] raw; NULL: statistics ONLY (partial / stat_acc required, no bias, no minmax): nothing is stored --
+                          * the pass in front of pq_xdw_fwd, which recomputes the values */
     float* partial;      /* [pq_conv1x1_blocks_k(M, O, I, 0)][2][ldp] or NULL ([..][4][ldp] with minmax) */
     int32_t M, I, O, ldo, ldp;
     int32_t sub, OH, OW, IH, IW;   /* sub==1: plain; else strided gather of input rows */
@@ -298,6 +299,60 @@ typedef struct pq_dw3x3_bwd_args {
 int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream);
 /* workgroups of the walking kernel = rows of the sink's statistics = rows [C][9] of `scratch` */
 int32_t pq_dw3x3_bwd_walk_blocks(int32_t B, int32_t IH, int32_t IW, int32_t C, int32_t stride);
+
+/* ------------------------------------------------------------------ fused inverted-residual block (MobileNetV2)
+ * replaces the conv(1x1, I -> E) -> BatchNorm -> act -> conv(3x3, groups = E, stride 1|2, pad 1) chain of an inverted-residual block
+ * (model/parser.py:389-410 as mobilenetv2-fpn.cfg lays the triples out) WITHOUT materialising the expanded E-channel tensor:
+ *   out[b,oy,ox,c] = sum_taps wd[c][tap] * mid'(sum_i we[c][i] * in'[b, oy*s+ky-1, ox*s+kx-1, i])      (zero padding of mid')
+ * mid'(v) = act(mid.scale[c] * v + mid.shift[c]): the BatchNorm of the expanded tensor; its train-mode statistics come from
+ * pq_xstat_fwd in front of this call (vectors mid.scale / mid.shift), or from a statistics-only pq_conv1x1_fwd (out == NULL), either
+ * finalised or handed over (mid.stat, pq_bn_stat: this call is the first consumer, its first workgroup per chunk stores the vectors).
+ * mid.x is ignored.  in.act must be PQ_ACT_LINEAR (the expand layer of an inverted-residual block reads a linear bottleneck or a
+ * materialised sum): the operand's affine is folded into the weights.  The call emits the depthwise output's own statistics like
+ * pq_dw3x3_fwd (partial rows or stat_acc).
+ * pq_xdw_fwd_blocks: partial-sum rows = walkers of the launch; 0 => shape outside the kernel's range (I in {16, 24, 32}; stride 2
+ * needs even plane sizes) -- use the unfused entries.  yexp != NULL: the raw expanded tensor is ALSO written (pitch ldy; for
+ * a backward that reads it and for tests). */
+typedef struct pq_xdw_fwd_args {
+    pq_src in;           /* block input, (B, IH, IW, I) */
+    const float* we;     /* [E][I] expand weights */
+    pq_src mid;          /* BatchNorm + activation of the expanded tensor */
+    float* yexp;         /* optional [B*IH*IW][ldy] raw expanded tensor, or NULL */
+    const float* wd;     /* [E][1][3][3] depthwise weights */
+    float* out;          /* [B*OH*OW][ldo] raw depthwise output */
+    float* partial;      /* [pq_xdw_fwd_blocks][2][ldp] or NULL */
+    int32_t B, IH, IW, OH, OW, I, E, stride, ldy, ldo, ldp;
+    int64_t* stat_acc;   /* as in pq_conv1x1_fwd_args */
+    uint32_t* stat_bad;
+    int32_t stat_slots;
+} pq_xdw_fwd_args;
+int pq_xdw_fwd(const pq_xdw_fwd_args* a, void* stream);
+int32_t pq_xdw_fwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t I, int32_t E, int32_t stride);
+
+/* Train-mode BatchNorm statistics of the expanded tensor y = we x' of such a block WITHOUT computing it (nn.BatchNorm2d semantics,
+ * model/parser.py:404-405): per expanded channel c, sum y_c = we_c . s and sum y_c^2 = we_c^T G we_c with s = sum x', G = sum x' x'^T
+ * over the M pixels -- one pass over the I-channel input (workgroup partials added into exact fixed-point accumulators in `scratch`:
+ * order independent, run-to-run deterministic), then a finalize that writes mean / invstd / scale / shift and the running statistics
+ * exactly like pq_bn_fwd_finalize(train).  I in {16, 24, 32}. */
+typedef struct pq_xstat_fwd_args {
+    pq_src in;           /* block input, M rows of I channels */
+    const float* we;     /* [E][I] */
+    const float* gamma;
+    const float* beta;
+    float* running_mean; /* updated in place; may be NULL */
+    float* running_var;
+    int64_t* num_batches_tracked;
+    float* mean;         /* out [E] */
+    float* invstd;
+    float* scale;
+    float* shift;
+    float* scratch;      /* >= pq_xstat_fwd_scratch_bytes(M, I), 16-byte aligned: exact accumulators; ZERO before the first call, the
+                          * call leaves them zero again (self re-arming) */
+    int32_t M, I, E;
+    float eps, momentum;
+} pq_xstat_fwd_args;
+int pq_xstat_fwd(const pq_xstat_fwd_args* a, void* stream);
+int64_t pq_xstat_fwd_scratch_bytes(int32_t M, int32_t I);
 
 /* ------------------------------------------------------------------ forward-only layers of the classifier cfgs
  * replaces FC (model/parser.py:122-137), nn.MaxPool2d / nn.AdaptiveAvgPool2d (:441-449), dense k x k nn.Conv2d beyond the grouped
@@ -714,7 +769,8 @@ enum {
     PQ_OP_GCONV_FWD, PQ_OP_GCONV_DGRAD, PQ_OP_GCONV_WGRAD, PQ_OP_TRANSPOSE,
     PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE, PQ_OP_CONV1X1_BWD,
     PQ_OP_BN_EVAL,
-    PQ_OP_LAYER_FWD
+    PQ_OP_LAYER_FWD,
+    PQ_OP_XDW_FWD, PQ_OP_XSTAT_FWD
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -738,6 +794,7 @@ typedef struct pq_op {
         pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill; pq_transpose_args tr;
         pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr; pq_conv1x1_bwd_args c1b; pq_bn_eval_args bne;
         pq_layer_fwd_args lay;
+        pq_xdw_fwd_args xdf; pq_xstat_fwd_args xsf;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);

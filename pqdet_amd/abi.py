@@ -250,6 +250,18 @@ class LayerFwd(C.Structure):
                 ('act', i32), ('nchw', i32)]
 
 
+class XdwFwd(C.Structure):
+    _fields_ = [('inp', Src), ('we', c_fp), ('mid', Src), ('yexp', c_fp), ('wd', c_fp), ('out', c_fp), ('partial', c_fp),
+                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('I', i32), ('E', i32), ('stride', i32),
+                ('ldy', i32), ('ldo', i32), ('ldp', i32), ('stat_acc', c_fp), ('stat_bad', c_fp), ('stat_slots', i32)]
+
+
+class XstatFwd(C.Structure):
+    _fields_ = [('inp', Src), ('we', c_fp), ('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp),
+                ('num_batches_tracked', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp), ('shift', c_fp), ('scratch', c_fp),
+                ('M', i32), ('I', i32), ('E', i32), ('eps', f32), ('momentum', f32)]
+
+
 LAYER_MAXPOOL, LAYER_AVGPOOL, LAYER_IM2COL, LAYER_FC, LAYER_ACT, LAYER_PADROWS = range(6)
 
 
@@ -260,7 +272,7 @@ class _OpU(C.Union):
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
                 ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose),
                 ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce), ('c1b', Conv1x1Bwd), ('bne', BnEval),
-                ('lay', LayerFwd)]
+                ('lay', LayerFwd), ('xdf', XdwFwd), ('xsf', XstatFwd)]
 
 
 OPF_SIDE = 1
@@ -276,7 +288,7 @@ class Op(C.Structure):
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
  OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE, OP_QAT_WPREP, OP_QAT_WGRAD, OP_QACT_FWD,
- OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL, OP_LAYER_FWD) = range(1, 31)
+ OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL, OP_LAYER_FWD, OP_XDW_FWD, OP_XSTAT_FWD) = range(1, 33)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
@@ -284,7 +296,7 @@ OP_FIELD = {
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
     OP_TRANSPOSE: 'tr', OP_QAT_WPREP: 'qw', OP_QAT_WGRAD: 'qw', OP_QACT_FWD: 'qa', OP_QACT_BWD: 'qb',
-    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b', OP_BN_EVAL: 'bne', OP_LAYER_FWD: 'lay',
+    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b', OP_BN_EVAL: 'bne', OP_LAYER_FWD: 'lay', OP_XDW_FWD: 'xdf', OP_XSTAT_FWD: 'xsf',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -317,6 +329,10 @@ SIGNATURES = {
     'pq_bn_fwd_finalize': (C.c_int, [C.POINTER(BnFwdFin), C.c_void_p]),
     'pq_bn_eval_batch': (C.c_int, [C.POINTER(BnEval), C.c_void_p]),
     'pq_layer_fwd': (C.c_int, [C.POINTER(LayerFwd), C.c_void_p]),
+    'pq_xdw_fwd': (C.c_int, [C.POINTER(XdwFwd), C.c_void_p]),
+    'pq_xdw_fwd_blocks': (i32, [i32, i32, i32, i32, i32, i32]),
+    'pq_xstat_fwd': (C.c_int, [C.POINTER(XstatFwd), C.c_void_p]),
+    'pq_xstat_fwd_scratch_bytes': (i64, [i32, i32]),
     'pq_bn_bwd_finalize': (C.c_int, [C.POINTER(BnBwdFin), C.c_void_p]),
     'pq_bn_finalize_scratch_bytes': (i64, [i32]),
     'pq_bn_finalize_tickets': (i32, [i32]),

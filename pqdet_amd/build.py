@@ -23,6 +23,7 @@ SOURCES = {            # file -> extra flags
     'layers.hip': [],
     'gconv.hip': [],
     'pwbwd.hip': [],
+    'irblock.hip': [],
     'qat.hip': ['-ffp-contract=off'],
     'ew.hip': [],
     'yolo.hip': [],

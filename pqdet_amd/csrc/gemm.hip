@@ -727,10 +727,12 @@ static void launch_nt(const GemmP& p, hipStream_t st, int bm, pq_gemm_plan* plan
 }
 
 static int conv1x1_fwd_impl(const pq_conv1x1_fwd_args* a, void* stream, pq_gemm_plan* plan) {
-    PQ_CHECK_ARG(a && a->in.x && a->w && a->out, "null pointer");
+    PQ_CHECK_ARG(a && a->in.x && a->w, "null pointer");
+    // out == NULL: statistics only (the first pass of a fused expand + depthwise block: pq_xdw_fwd recomputes the values)
+    PQ_CHECK_ARG(a->out || ((a->partial || a->stat_acc) && !a->minmax && !a->bias), "out == NULL needs statistics (no min / max, no bias)");
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->in.ld & 3) == 0 && (((uintptr_t)a->in.x) & 15) == 0, "input pitch/pointer must be 16B aligned");
-    PQ_CHECK_ARG(a->ldo >= a->O && a->in.ld >= a->I, "pitch smaller than channel count");
+    PQ_CHECK_ARG((!a->out || a->ldo >= a->O) && a->in.ld >= a->I, "pitch smaller than channel count");
     PQ_CHECK_ARG(a->partial == nullptr || a->ldp >= a->O, "stats pitch too small");
     PQ_CHECK_ARG(a->sub >= 1, "sub must be >= 1");
     if (act_is_special(a->in.act)) { pq_set_error("pq_conv1x1_fwd: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }

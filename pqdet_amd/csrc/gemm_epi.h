@@ -25,12 +25,15 @@ __device__ __forceinline__ int epi_rowc(int r) { return (r & 3) + 8 * (r >> 2); 
 
 // ---------------------------------------------------------------------------------------------- store (+ bias, + statistics)
 // EMODE 0: store; 1: + per-column sum / sum of squares into t1 / t2; 3: + per-column min / max (QAT observers)
+// out == NULL (uniform; EMODE 1 only, pq_conv1x1_fwd_args.out): statistics ONLY, nothing is stored -- the first pass of a fused
+// expand + depthwise block (irblock.hip), whose expanded tensor is never materialised
 template <int TI, int TJ, int EMODE, bool F>
 __device__ __forceinline__ void epi_store(const f32x16 (&acc)[TI][TJ], float* out, int ldo, const float* bias, const EpiGeom& g,
                                           float (&t1)[TJ], float (&t2)[TJ], float (&mn)[TJ], float (&mx)[TJ]) {
     // every column block's bias first: loaded inside the block loop, the (conditional) load's wait sat in front of each block's first
     // store as s_waitcnt vmcnt(0) -- with or without a bias it drained the PREVIOUS block's 16 stores, TJ - 1 store round trips per tile
     float bjv[TJ];
+    const bool st = out != nullptr;                                     // uniform
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int n = g.n0w + 32 * j + g.lrow;
@@ -54,8 +57,8 @@ __device__ __forceinline__ void epi_store(const f32x16 (&acc)[TI][TJ], float* ou
                 const int row = epi_rowc(r);
                 const float v = acc[i][j][r] + bj;
                 const bool ok = nok && (F || mb + 4 * g.lh + row < g.M);
-                if (F) { if (nok) (out + (size_t)(mb + row) * (size_t)ldo + (g.n0w + 32 * j))[oo] = v; }
-                else if (ok) out[(size_t)(mb + 4 * g.lh + row) * ldo + n] = v;
+                if (F) { if (nok && st) (out + (size_t)(mb + row) * (size_t)ldo + (g.n0w + 32 * j))[oo] = v; }
+                else if (ok && st) out[(size_t)(mb + 4 * g.lh + row) * ldo + n] = v;
                 if (EMODE != 0 && ok) {
                     t1[j] += v; t2[j] = fmaf(v, v, t2[j]);
                     if (EMODE == 3) { mn[j] = fminf(mn[j], v); mx[j] = fmaxf(mx[j], v); }
