@@ -350,9 +350,41 @@ typedef struct pq_xstat_fwd_args {
                           * call leaves them zero again (self re-arming) */
     int32_t M, I, E;
     float eps, momentum;
+    double* moments;     /* out, optional: [I * I + I] fp64 -- G (row-major) and s, what pq_xdw_bwd needs of the forward */
 } pq_xstat_fwd_args;
 int pq_xstat_fwd(const pq_xstat_fwd_args* a, void* stream);
 int64_t pq_xstat_fwd_scratch_bytes(int32_t M, int32_t I);
+
+/* Backward of the chain pq_xdw_fwd computes, in one pass over (g_d, y_d, x) with the expanded tensor recomputed (csrc/irbwd.hip):
+ * gradient w.r.t. the block input (through the sink dx: activation derivative, BatchNorm-backward sums, accumulation), the two weight
+ * gradients and the BatchNorm parameter gradients of the expanded tensor.  Train-mode statistics only (the closed-form BatchNorm
+ * backward of the expanded tensor is folded analytically into the expand layer's two products, which needs the moments of x' that
+ * pq_xstat_fwd kept in `moments`).  Three launches: the walking kernel, a fold over its partial rows, a fix-up pass over the
+ * I-channel gradient.  dx.partial (if the sink has statistics) has pq_xdw_bwd_fix_blocks(M, I) rows.
+ * pq_xdw_bwd_blocks == 0: shape outside the kernel's range (today: 16 -> 96 stride 2, 24 -> 144 stride 1 | 2). */
+typedef struct pq_xdw_bwd_args {
+    pq_src in;           /* block input x (linear operand), (B, IH, IW, I) */
+    const float* we;     /* [E][I] */
+    const float* mid_scale; const float* mid_shift; const float* mid_mean; const float* mid_invstd; const float* mid_gamma;   /* [E] */
+    int32_t mid_act;     /* PQ_ACT_RELU6 */
+    int32_t pad_;
+    pq_gsrc dy;          /* gradient pair of the depthwise output, (B, OH, OW, E) */
+    const float* wd;     /* [E][1][3][3] */
+    pq_gsink dx;         /* gradient sink of the block input */
+    float* dwe;          /* out [E][I] */
+    float* dwd;          /* out [E][9] */
+    float* dgamma;       /* out [E]: BatchNorm of the expanded tensor */
+    float* dbeta;
+    const double* moments;   /* [I * I + I] from pq_xstat_fwd */
+    float* scratch;      /* >= pq_xdw_bwd_scratch_bytes, 16-byte aligned */
+    float* gexp;         /* optional (tests): gradient w.r.t. the BatchNorm output of the expanded tensor, [B*IH*IW][ldge] */
+    int32_t ldge;
+    int32_t B, IH, IW, OH, OW, I, E, stride;
+} pq_xdw_bwd_args;
+int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream);
+int32_t pq_xdw_bwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t I, int32_t E, int32_t stride);
+int32_t pq_xdw_bwd_fix_blocks(int32_t M, int32_t I);
+int64_t pq_xdw_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t I, int32_t E, int32_t stride);
 
 /* ------------------------------------------------------------------ forward-only layers of the classifier cfgs
  * replaces FC (model/parser.py:122-137), nn.MaxPool2d / nn.AdaptiveAvgPool2d (:441-449), dense k x k nn.Conv2d beyond the grouped
@@ -770,7 +802,7 @@ enum {
     PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE, PQ_OP_CONV1X1_BWD,
     PQ_OP_BN_EVAL,
     PQ_OP_LAYER_FWD,
-    PQ_OP_XDW_FWD, PQ_OP_XSTAT_FWD
+    PQ_OP_XDW_FWD, PQ_OP_XSTAT_FWD, PQ_OP_XDW_BWD
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -794,7 +826,7 @@ typedef struct pq_op {
         pq_decode_args dec; pq_yolo_loss_args loss; pq_adam_args adam; pq_fill_args fill; pq_transpose_args tr;
         pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr; pq_conv1x1_bwd_args c1b; pq_bn_eval_args bne;
         pq_layer_fwd_args lay;
-        pq_xdw_fwd_args xdf; pq_xstat_fwd_args xsf;
+        pq_xdw_fwd_args xdf; pq_xstat_fwd_args xsf; pq_xdw_bwd_args xdb;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);

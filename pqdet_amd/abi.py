@@ -259,7 +259,14 @@ class XdwFwd(C.Structure):
 class XstatFwd(C.Structure):
     _fields_ = [('inp', Src), ('we', c_fp), ('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp),
                 ('num_batches_tracked', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp), ('shift', c_fp), ('scratch', c_fp),
-                ('M', i32), ('I', i32), ('E', i32), ('eps', f32), ('momentum', f32)]
+                ('M', i32), ('I', i32), ('E', i32), ('eps', f32), ('momentum', f32), ('moments', c_fp)]
+
+
+class XdwBwd(C.Structure):
+    _fields_ = [('inp', Src), ('we', c_fp), ('mid_scale', c_fp), ('mid_shift', c_fp), ('mid_mean', c_fp), ('mid_invstd', c_fp),
+                ('mid_gamma', c_fp), ('mid_act', i32), ('pad_', i32), ('dy', GSrc), ('wd', c_fp), ('dx', GSink), ('dwe', c_fp), ('dwd', c_fp),
+                ('dgamma', c_fp), ('dbeta', c_fp), ('moments', c_fp), ('scratch', c_fp), ('gexp', c_fp), ('ldge', i32),
+                ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('I', i32), ('E', i32), ('stride', i32)]
 
 
 LAYER_MAXPOOL, LAYER_AVGPOOL, LAYER_IM2COL, LAYER_FC, LAYER_ACT, LAYER_PADROWS = range(6)
@@ -272,7 +279,7 @@ class _OpU(C.Union):
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
                 ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose),
                 ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce), ('c1b', Conv1x1Bwd), ('bne', BnEval),
-                ('lay', LayerFwd), ('xdf', XdwFwd), ('xsf', XstatFwd)]
+                ('lay', LayerFwd), ('xdf', XdwFwd), ('xsf', XstatFwd), ('xdb', XdwBwd)]
 
 
 OPF_SIDE = 1
@@ -288,7 +295,7 @@ class Op(C.Structure):
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
  OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE, OP_QAT_WPREP, OP_QAT_WGRAD, OP_QACT_FWD,
- OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL, OP_LAYER_FWD, OP_XDW_FWD, OP_XSTAT_FWD) = range(1, 33)
+ OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL, OP_LAYER_FWD, OP_XDW_FWD, OP_XSTAT_FWD, OP_XDW_BWD) = range(1, 34)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
@@ -296,7 +303,7 @@ OP_FIELD = {
     OP_COPY_FWD: 'cp', OP_ROUTE_BWD: 'rb', OP_DECODE: 'dec', OP_LOSS_FWD: 'loss', OP_LOSS_BWD: 'loss', OP_ADAM: 'adam',
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
     OP_TRANSPOSE: 'tr', OP_QAT_WPREP: 'qw', OP_QAT_WGRAD: 'qw', OP_QACT_FWD: 'qa', OP_QACT_BWD: 'qb',
-    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b', OP_BN_EVAL: 'bne', OP_LAYER_FWD: 'lay', OP_XDW_FWD: 'xdf', OP_XSTAT_FWD: 'xsf',
+    OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b', OP_BN_EVAL: 'bne', OP_LAYER_FWD: 'lay', OP_XDW_FWD: 'xdf', OP_XSTAT_FWD: 'xsf', OP_XDW_BWD: 'xdb',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -333,6 +340,10 @@ SIGNATURES = {
     'pq_xdw_fwd_blocks': (i32, [i32, i32, i32, i32, i32, i32]),
     'pq_xstat_fwd': (C.c_int, [C.POINTER(XstatFwd), C.c_void_p]),
     'pq_xstat_fwd_scratch_bytes': (i64, [i32, i32]),
+    'pq_xdw_bwd': (C.c_int, [C.POINTER(XdwBwd), C.c_void_p]),
+    'pq_xdw_bwd_blocks': (i32, [i32, i32, i32, i32, i32, i32]),
+    'pq_xdw_bwd_fix_blocks': (i32, [i32, i32]),
+    'pq_xdw_bwd_scratch_bytes': (i64, [i32, i32, i32, i32, i32, i32]),
     'pq_bn_bwd_finalize': (C.c_int, [C.POINTER(BnBwdFin), C.c_void_p]),
     'pq_bn_finalize_scratch_bytes': (i64, [i32]),
     'pq_bn_finalize_tickets': (i32, [i32]),

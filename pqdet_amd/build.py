@@ -24,6 +24,7 @@ SOURCES = {            # file -> extra flags
     'gconv.hip': [],
     'pwbwd.hip': [],
     'irblock.hip': [],
+    'irbwd.hip': [],
     'qat.hip': ['-ffp-contract=off'],
     'ew.hip': [],
     'yolo.hip': [],

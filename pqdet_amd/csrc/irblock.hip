@@ -72,8 +72,9 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
 
 // KS = I / 4 (k-steps of the 16x16x4 MFMA; lane group g = lane >> 4 contracts over input channels g * KS .. g * KS + KS - 1: the
 // B fragment of a lane is KS CONSECUTIVE floats of one pixel of x, loaded straight from global memory -- no staging of x).
-// The input operand's BatchNorm is LINEAR (every expand layer of MobileNetV2 reads a linear bottleneck or a materialised sum), so
-// it is folded into the weights once per lane:  w . (a x + b) = (w a) . x + w . b  -- the second term initialises the accumulator.
+// The input operand is LINEAR (every expand layer of MobileNetV2 reads a linear bottleneck or a materialised sum): x' = a x + b is
+// one fma per fragment element; the backward (irbwd.hip) recomputes y_e with the same fma, the same MFMA and the same k order, so
+// both passes see bit-identical expanded values (the ReLU6 masks of the two passes agree exactly).
 // One barrier per step: while the depthwise stage consumes the ring rows of step k, the expand stage fills those of step k + 1
 // (the ring holds R + TH rows), and the fragments of step k + 2 are in flight; expand and depthwise code of a step form ONE
 // basic block (tile numbers are compile-time constants, every load is unconditional at a clamped address), so the MFMA chains
@@ -119,24 +120,14 @@ __global__ __launch_bounds__(256, 2) void xdw_fwd_kernel(XdwP p) {
             for (int k = 0; k < 9; ++k) e[k][j] = wp[k];
         }
     }
-    float wa[KS];
-    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f};                         // w . shift for the four channels of the lane's accumulator
+    float wa[KS], xa[KS], xb[KS];
     {
         const int ch = min(cq0 * 4 + 16 * sub + l15, p.E - 1);
         load_frag<KS>(p.we + (size_t)ch * I + g * KS, wa);
-        if (p.in.scale != nullptr) {                            // uniform
-            float bsum = 0.f;
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                bsum = fmaf(wa[k], p.in.shift[g * KS + k], bsum);
-                wa[k] *= p.in.scale[g * KS + k];
-            }
-            bsum += __shfl_xor(bsum, 16);                       // over the four k groups: w . shift of channel 16 * sub + l15
-            bsum += __shfl_xor(bsum, 32);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bias0[r] = __shfl(bsum, 4 * g + r);
-        }
     }
+    const bool xaff = p.in.scale != nullptr;                    // uniform
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { xa[k] = xaff ? p.in.scale[g * KS + k] : 1.f; xb[k] = xaff ? p.in.shift[g * KS + k] : 0.f; }
     const SrcCoef4 mk = p.mid.stat.acc ? src_coef4_chunk32(p.mid, cq0 * 4, qm, p.E, tIdx == 0, reinterpret_cast<float*>(ring))
                                        : src_coef4(p.mid, cmok ? cm : 0, p.E);
     if (pl == 8) {
@@ -178,9 +169,9 @@ __global__ __launch_bounds__(256, 2) void xdw_fwd_kernel(XdwP p) {
     // ---- ... and the tile itself: KS MFMAs of the fragment against the lane's weights -> BatchNorm + activation -> ring; returns the raw values
     auto expand_tile = [&](int l0, auto nr, auto tile, const float (&f)[KS]) -> f32x4 {
         constexpr int NR = decltype(nr)::value, T = decltype(tile)::value;
-        f32x4 acc = bias0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KS; ++k) acc = mfma16(wa[k], f[k], acc);
+        for (int k = 0; k < KS; ++k) acc = mfma16(wa[k], fmaf(xa[k], f[k], xb[k]), acc);
         int lr, lc; bool on, in_img;
         if constexpr (T < NR * G::TPR) {
             lr = T / G::TPR; lc = 1 + 16 * (T % G::TPR) + l15; on = true;
@@ -412,7 +403,7 @@ __global__ __launch_bounds__(256) void xgram_kernel(XgramP p) {
 }
 
 struct XstatFinP {
-    int64_t* acc; uint32_t* bad;
+    int64_t* acc; uint32_t* bad; double* moments;
     const float* we; const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* nbt;
     float* mean; float* invstd; float* scale; float* shift;
     int I, E; float count, eps, momentum;
@@ -432,6 +423,7 @@ __global__ __launch_bounds__(1024) void xstat_finalize_kernel(XstatFinP p) {
 #pragma unroll
         for (int sl = 0; sl < XSLOTS; ++sl) { lo += v[sl].x; hi += v[sl].y; }
         G[el] = (double)hi + (double)lo * 0x1p-50;
+        if (p.moments) p.moments[el] = G[el];                   // kept for the backward (pq_xdw_bwd)
     }
     __syncthreads();
     const bool bad = s_bad != 0;
@@ -584,7 +576,7 @@ extern "C" int pq_xstat_fwd(const pq_xstat_fwd_args* a, void* stream) {
     if (a->I == 16) hipLaunchKernelGGL((xgram_kernel<16>), dim3(nwg), dim3(256), 0, st, g);
     else if (a->I == 24) hipLaunchKernelGGL((xgram_kernel<24>), dim3(nwg), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((xgram_kernel<32>), dim3(nwg), dim3(256), 0, st, g);
-    XstatFinP f{acc, bad, a->we, a->gamma, a->beta, a->running_mean, a->running_var, a->num_batches_tracked,
+    XstatFinP f{acc, bad, a->moments, a->we, a->gamma, a->beta, a->running_mean, a->running_var, a->num_batches_tracked,
                 a->mean, a->invstd, a->scale, a->shift, a->I, a->E, (float)a->M, a->eps, a->momentum};
     hipLaunchKernelGGL(xstat_finalize_kernel, dim3(1), dim3(1024), 0, st, f);
     PQ_CHECK_LAUNCH();

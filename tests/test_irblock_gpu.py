@@ -181,6 +181,89 @@ def test_xstat_fwd_equals_batchnorm_statistics_of_the_expanded_tensor(M, I, E, x
     assert not bool(scratch.view(torch.int32).any()), 'the accumulators are not re-armed'
 
 
+@pytest.mark.parametrize('B,H,W,I,E,stride,affine,accumulate', [
+    (2, 16, 32, 24, 144, 1, True, 0),
+    (1, 22, 24, 24, 144, 1, False, 1),      # rows that are not a whole number of steps; residual block: running gradient in the sink
+    (2, 16, 32, 16, 96, 2, True, 0),
+    (1, 24, 40, 24, 144, 2, True, 0),
+    (2, 34, 20, 24, 144, 1, True, 0),       # partial strip (20 columns), several segments
+    (1, 128, 128, 24, 144, 1, True, 0),     # benchmark-step plane (one image)
+])
+def test_xdw_bwd_matches_autograd_through_expand_batchnorm_relu6_depthwise(B, H, W, I, E, stride, affine, accumulate):
+    """pq_xdw_bwd (recompute + analytic BatchNorm-backward fold) against torch autograd (fp64) through
+    x' -> conv1x1 -> BatchNorm(train) -> ReLU6 -> depthwise 3x3; the sink of the block input with its own statistics."""
+    l = abi.lib()
+    g, x, xsc, xsh, we, wd = _case(B, H, W, I, E, stride, seed=11)
+    if not affine:
+        xsc, xsh = torch.ones(I), torch.zeros(I)
+    gamma, beta = torch.rand(E, generator=g) + 0.5, rnd(E, g=g, scale=0.5) + 0.5
+    eps = 1e-5
+    M = B * H * W
+    xp = (x.double() * xsc.double() + xsh.double()).requires_grad_(True)
+    wed, wdd = we.double().requires_grad_(True), wd.double().requires_grad_(True)
+    gm, bt = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ye = xp @ wed.t()
+    mean, var = ye.view(M, E).mean(0), ye.view(M, E).var(0, unbiased=False)
+    inv = 1 / torch.sqrt(var + eps)
+    u = (ye - mean) * inv * gm + bt
+    u.retain_grad()
+    h = u.clamp(0, 6)
+    yd = F.conv2d(h.permute(0, 3, 1, 2), wdd, stride=stride, padding=1, groups=E).permute(0, 2, 3, 1)
+    OH, OW = yd.shape[1:3]
+    gd = rnd(B, OH, OW, E, g=g)
+    pd, qd = torch.rand(E, generator=g) + 0.5, rnd(E, g=g, scale=0.05)
+    mud, rd = yd.detach().view(-1, E).mean(0).float(), rnd(E, g=g, scale=0.05)
+    dyp = pd.double() * gd.double() + qd.double() * (yd.detach() - mud.double()) + rd.double()
+    (yd * dyp).sum().backward()
+    prev = rnd(B, H, W, I, g=g) if accumulate else None
+    gx_want = xp.grad + (prev.double() if accumulate else 0)                      # linear operand: act' = 1
+    mean_x = x.view(M, I).double().mean(0)
+    inv_x = 1 / torch.sqrt(x.view(M, I).double().var(0, unbiased=False) + eps)
+    xd, wedev, wddev = x.to(DEV), we.to(DEV), wd.to(DEV)
+    ydd, gdd = yd.detach().float().to(DEV).contiguous(), gd.to(DEV)
+    vec = lambda v: chan_vec(v.detach().float())
+    v_x = [vec(xsc), vec(xsh), vec(mean_x), vec(inv_x)]
+    v_e = [vec(gm * inv), vec(bt - mean * gm * inv), vec(mean), vec(inv), vec(gamma)]
+    v_d = [vec(pd), vec(qd), vec(mud), vec(rd)]
+    mom = torch.cat([(xp.detach().view(M, I).t() @ xp.detach().view(M, I)).reshape(-1), xp.detach().view(M, I).sum(0)]).to(DEV)
+    assert mom.dtype == torch.float64
+    nfix = l.pq_xdw_bwd_fix_blocks(M, I)
+    ldp = 32
+    gdst = prev.to(DEV).clone() if accumulate else torch.full((B, H, W, I), float('nan'), device=DEV)
+    partial = torch.full((nfix * 2 * ldp,), float('nan'), device=DEV)
+    assert l.pq_xdw_bwd_blocks(B, H, W, I, E, stride) > 0
+    scratch = torch.full((l.pq_xdw_bwd_scratch_bytes(B, H, W, I, E, stride) // 4,), float('nan'), device=DEV)
+    outs = [torch.full((E * I,), float('nan'), device=DEV), torch.full((E * 9,), float('nan'), device=DEV),
+            torch.full((E,), float('nan'), device=DEV), torch.full((E,), float('nan'), device=DEV)]
+    gexp = torch.full((B, H, W, E), float('nan'), device=DEV)
+    a = abi.XdwBwd()
+    a.inp = abi.Src(xd.data_ptr(), v_x[0].data_ptr() if affine else None, v_x[1].data_ptr() if affine else None, I, 0)
+    a.we, a.wd = wedev.data_ptr(), wddev.data_ptr()
+    a.mid_scale, a.mid_shift, a.mid_mean, a.mid_invstd, a.mid_gamma = [v.data_ptr() for v in v_e]
+    a.mid_act = 2
+    a.dy = abi.GSrc(gdd.data_ptr(), ydd.data_ptr(), *[v.data_ptr() for v in v_d], E, E)
+    a.dx = abi.GSink(gdst.data_ptr(), xd.data_ptr(), v_x[0].data_ptr() if affine else None, v_x[1].data_ptr() if affine else None,
+                     v_x[2].data_ptr(), v_x[3].data_ptr(), partial.data_ptr(), I, I, 0, accumulate, 1, ldp)
+    a.dwe, a.dwd, a.dgamma, a.dbeta = [o.data_ptr() for o in outs]
+    a.moments, a.scratch, a.gexp, a.ldge = mom.data_ptr(), scratch.data_ptr(), gexp.data_ptr(), E
+    a.B, a.IH, a.IW, a.OH, a.OW, a.I, a.E, a.stride = B, H, W, OH, OW, I, E, stride
+    abi.check(l.pq_xdw_bwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(gexp, u.grad.float(), what='gradient w.r.t. the BatchNorm output of the expanded tensor')
+    close(outs[1].view(E, 1, 3, 3), wdd.grad.float(), rt=1e-3, at=1e-3, what='depthwise weight gradient')
+    close(outs[3], bt.grad.float(), rt=1e-3, at=1e-3, what='dbeta')
+    close(outs[2], gm.grad.float(), rt=1e-3, at=1e-3, what='dgamma')
+    close(outs[0].view(E, I), wed.grad.float(), rt=1e-3, at=1e-3, what='expand weight gradient')
+    close(gdst, gx_want.float(), what='block input gradient')
+    s1, s2 = reduce_partial(partial, nfix, ldp, I)
+    xh = (x.double() - mean_x) * inv_x
+    # (the first sum is ~0 by construction -- BatchNorm's backward removes the mean of the gradient -- so both are judged against
+    # the size of their summands, not of the result)
+    for got, terms, what in ((s1, gx_want, 'sink sum'), (s2, gx_want * xh, 'sink sum xhat')):
+        err = (got - terms.sum((0, 1, 2))).abs()
+        assert bool((err <= 1e-5 * terms.abs().sum((0, 1, 2)) + 1e-6).all()), '%s: max err %g' % (what, err.max().item())
+
+
 def test_xdw_fwd_refuses_what_it_does_not_cover():
     l = abi.lib()
     assert l.pq_xdw_fwd_blocks(2, 16, 16, 64, 384, 1) == 0            # contraction outside {16, 24, 32}
