@@ -388,6 +388,7 @@ __global__ __launch_bounds__(256) void xgram_kernel(XgramP p) {
         float a = 0.f;
         if (el < I * I) {
             const int r = el / I, c = el - r * I;
+            if (r > c) continue;                               // G is symmetric: the finalize kernel mirrors the upper triangle
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) a += gl[ww][r * NL + c];
         } else {
@@ -423,9 +424,15 @@ __global__ __launch_bounds__(1024) void xstat_finalize_kernel(XstatFinP p) {
 #pragma unroll
         for (int sl = 0; sl < XSLOTS; ++sl) { lo += v[sl].x; hi += v[sl].y; }
         G[el] = (double)hi + (double)lo * 0x1p-50;
-        if (p.moments) p.moments[el] = G[el];                   // kept for the backward (pq_xdw_bwd)
     }
     __syncthreads();
+    for (int el = t; el < I * I; el += 1024) {                  // mirror (the producers only add the upper triangle)
+        const int r = el / I, c = el - r * I;
+        if (r > c) G[el] = G[c * I + r];
+    }
+    __syncthreads();
+    if (p.moments)
+        for (int el = t; el < n; el += 1024) p.moments[el] = G[el];            // kept for the backward (pq_xdw_bwd)
     const bool bad = s_bad != 0;
     for (int el = t; el < n; el += 1024) {                      // re-arm: the next call finds zeros
 #pragma unroll
@@ -436,12 +443,25 @@ __global__ __launch_bounds__(1024) void xstat_finalize_kernel(XstatFinP p) {
         const int c = cb + (t >> 2), part = t & 3;
         const int cc = min(c, p.E - 1);
         const float* w = p.we + (size_t)cc * I;
+        float wr[32];                                           // the channel's weight row, loaded once
+#pragma unroll
+        for (int j = 0; j < 32; j += 4) {
+            const float4 v = j < I ? ldg4(w + j) : f4zero();
+            wr[j] = v.x; wr[j + 1] = v.y; wr[j + 2] = v.z; wr[j + 3] = v.w;
+        }
         double q = 0.0, m = 0.0;
-        for (int i = part; i < I; i += 4) {
-            double r = 0.0;
-            for (int j = 0; j < I; ++j) r = fma(G[i * I + j], (double)w[j], r);
-            q = fma((double)w[i], r, q);
-            m = fma((double)w[i], G[I * I + i], m);
+#pragma unroll
+        for (int i4 = 0; i4 < 8; ++i4) {
+            const int i = part + 4 * i4;
+            if (i < I) {
+                double r = 0.0;
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    if (j < I) r = fma(G[i * I + j], (double)wr[j], r);
+                const double wi = (double)w[i];
+                q = fma(wi, r, q);
+                m = fma(wi, G[I * I + i], m);
+            }
         }
         q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
         m += __shfl_xor(m, 1); m += __shfl_xor(m, 2);
@@ -550,7 +570,7 @@ extern "C" int pq_xdw_fwd(const pq_xdw_fwd_args* a, void* stream) {
 // ---- statistics of the expanded tensor from the moments of the block input
 static void xstat_plan(int M, int I, int& rows, int& nwg) {
     const int unit = I <= 16 ? 128 : 64;                       // pixels one workgroup iteration covers (4 waves x 8 MFMAs)
-    rows = ((M + 511) / 512 + unit - 1) / unit * unit;
+    rows = ((M + 255) / 256 + unit - 1) / unit * unit;          // at most 256 workgroups add into the accumulators
     if (rows < unit) rows = unit;
     nwg = (M + rows - 1) / rows;
 }

@@ -30,6 +30,10 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef XB_SKIP
+#define XB_SKIP 0      // diagnostic builds only (scripts/irbwd_phases.sh): bit mask of phases to leave out -- results are then WRONG
+#endif
+
 namespace pq {
 
 __device__ __forceinline__ f32x4 mfma16b(float a, float b, f32x4 c) {
@@ -49,8 +53,12 @@ template <int S> struct XBG;
 template <> struct XBG<1> { static constexpr int TH = 4, DR = 6, DC = 18, DN = 4; };   // dy' ring: rows y0 - 1 .. y0 + 4, columns x0 - 1 .. x0 + 16
 template <> struct XBG<2> { static constexpr int TH = 8, DR = 5, DC = 9, DN = 4; };    // dy' ring (output plane): rows y0 / 2 .. + 4, columns x0 / 2 .. + 8
 
-// S: stride; KS = I / 4; NQ = E / 4 (channel quads).  512 threads.
-template <int S, int KS, int NQ>
+// S: stride; KS = I / 4; NQ = E / 4 (channel quads).  512 threads.  GE: also store g_e (tests).
+// Between the request of a step's global loads [A] and their use at the end of the step there is NO vector-memory instruction inside
+// a loop or a condition (the Z1 stores are straight-line code, the optional g_e store is a template flavour): the compiler can
+// then COUNT the outstanding loads (s_waitcnt vmcnt(N)) instead of draining them in front of the first loop -- with the Z1 store
+// inside a run-time loop it waited for the whole batch right after issuing it, every step.
+template <int S, int KS, int NQ, bool GE>
 __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
     using G = XBG<S>;
     constexpr int I = 4 * KS, E = 4 * NQ, TH = G::TH;
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
     constexpr int NPL = 512 / NQ;                               // pixel lanes of the depthwise stage
     constexpr int KE = E / 4;                                   // k-steps of the Z1 contraction (lane group g: channels g * KE ..)
     constexpr int RING_F4 = G::DR * G::DC * NQ;
-    constexpr int UD = (G::DN * G::DC * NQ + 511) / 512;        // dy' float4 pairs a thread stages per step
+    constexpr int UD = (G::DN * G::DC + NPL - 1) / NPL;         // dy' pixels (float4 pairs of its quad) a thread stages per step
     constexpr int UX = (NPXS * KS + 511) / 512;                 // x float4 a thread stages per step
     constexpr int NUE = NPT * NCT, NUZ = NPT * NI, NUG = NCT * NI;       // work units of the three MFMA stages
     constexpr int MUG = (NUG + 7) / 8;
@@ -89,6 +97,10 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
     const int yend = ys + rows_here;
     const size_t img = (size_t)b * p.IH * p.IW, oimg = (size_t)b * p.OH * p.OW;
     const bool two = p.dy.y != nullptr;
+    // every load of a staging batch is unconditional (a load inside a condition is waited for before the next one is issued: one
+    // exposed memory round trip per element instead of one per batch)
+    const float* ysrc = two ? p.dy.y : p.dy.g;
+    const int yld = two ? p.dy.ldy : p.dy.ldg;
 
     // ---- tables
     for (int e = t; e < E * KS; e += 512) {                     // W_e rows, pitch WP
@@ -122,45 +134,46 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
     }
     __syncthreads();
 
-    // ---- staging (element e = t + 512 u of a batch of whole rows): dy' rows into the ring, x rows into an x' tile
-    // (the element -> (pixel, quad) arithmetic of a thread is the same in every step: left alone the compiler hoists all of it out
-    // of the step loop -- ~60 VGPRs held across the walk, spilled; an opaque copy of the thread index per call keeps it temporary)
-    auto load_dy = [&](float4 (&rg)[UD], float4 (&ry)[UD], int l0, int nrows) {
-        const int nel = nrows * G::DC * NQ;
-        int t = threadIdx.x;
-        asm volatile("" : "+v"(t));
+    // ---- staging: dy' rows into the ring -- thread (quad qd, pixel lane pl) takes the pixels pl, pl + NPL, ... of a batch of whole rows
+    // for ITS quad (the mapping of the depthwise stage: the four coefficient quads of dy' are read once per batch, there is no
+    // per-element table lookup or quad arithmetic) -- and x rows into an x' tile
+    // (the pixel -> (row, column) arithmetic of a thread is the same in every step: left alone the compiler hoists all of it out
+    // of the step loop -- VGPRs held across the walk, spilled; an opaque copy of the lane index per call keeps it temporary)
+    auto load_dy = [&](float4 (&rg)[UD], float4 (&ry)[UD], int l0, int nrows, int ua, int ub) {
+        const int npx = nrows * G::DC;
+        int plv = pl;
+        asm volatile("" : "+v"(plv));
 #pragma unroll
         for (int u = 0; u < UD; ++u) {
-            const int el = min(t + 512 * u, nel - 1);
-            const int pxi = el / NQ, qq = el - pxi * NQ;
+            if (u < ua || u >= ub) continue;
+            const int pxi = min(plv + NPL * u, npx - 1);
             const int lr = pxi / G::DC, lc = pxi - lr * G::DC;
             const int oy = S == 1 ? ys - 1 + l0 + lr : ys / 2 + l0 + lr, ox = S == 1 ? x0 - 1 + lc : x0 / 2 + lc;
             const size_t r = oimg + (size_t)min(max(oy, 0), p.OH - 1) * p.OW + min(max(ox, 0), p.OW - 1);
-            rg[u] = ldg4(p.dy.g + r * p.dy.ldg + 4 * qq);
-            ry[u] = two ? ldg4(p.dy.y + r * p.dy.ldy + 4 * qq) : f4zero();
+            rg[u] = ldg4(p.dy.g + r * p.dy.ldg + 4 * qd);
+            ry[u] = ldg4(ysrc + r * yld + 4 * qd);              // (one-tensor operand: g again, its coefficients are q = 0)
         }
     };
     auto store_dy = [&](const float4 (&rg)[UD], const float4 (&ry)[UD], int l0, int nrows) {
-        const int nel = nrows * G::DC * NQ;
-        int t = threadIdx.x;
-        asm volatile("" : "+v"(t));
+        const int npx = nrows * G::DC;
+        const float4 cdp = cd[4 * qd], cdq = cd[4 * qd + 1], cdm = cd[4 * qd + 2], cdr = cd[4 * qd + 3];     // once per batch
+        int plv = pl;
+        asm volatile("" : "+v"(plv));
 #pragma unroll
         for (int u = 0; u < UD; ++u) {
-            const int el = t + 512 * u;
-            if (el < nel) {
-                const int pxi = el / NQ, qq = el - pxi * NQ;
+            const int pxi = plv + NPL * u;
+            if (pxi < npx && dact) {
                 const int lr = pxi / G::DC, lc = pxi - lr * G::DC;
                 const int oy = S == 1 ? ys - 1 + l0 + lr : ys / 2 + l0 + lr, ox = S == 1 ? x0 - 1 + lc : x0 / 2 + lc;
                 const bool ok = (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
-                const float4 cpv = cd[4 * qq], cq = cd[4 * qq + 1], cm = cd[4 * qq + 2], cr = cd[4 * qq + 3];
                 float4 o;
-                o.x = ok ? fmaf(cpv.x, rg[u].x, fmaf(cq.x, ry[u].x - cm.x, cr.x)) : 0.f;
-                o.y = ok ? fmaf(cpv.y, rg[u].y, fmaf(cq.y, ry[u].y - cm.y, cr.y)) : 0.f;
-                o.z = ok ? fmaf(cpv.z, rg[u].z, fmaf(cq.z, ry[u].z - cm.z, cr.z)) : 0.f;
-                o.w = ok ? fmaf(cpv.w, rg[u].w, fmaf(cq.w, ry[u].w - cm.w, cr.w)) : 0.f;
+                o.x = ok ? fmaf(cdp.x, rg[u].x, fmaf(cdq.x, ry[u].x - cdm.x, cdr.x)) : 0.f;
+                o.y = ok ? fmaf(cdp.y, rg[u].y, fmaf(cdq.y, ry[u].y - cdm.y, cdr.y)) : 0.f;
+                o.z = ok ? fmaf(cdp.z, rg[u].z, fmaf(cdq.z, ry[u].z - cdm.z, cdr.z)) : 0.f;
+                o.w = ok ? fmaf(cdp.w, rg[u].w, fmaf(cdq.w, ry[u].w - cdm.w, cdr.w)) : 0.f;
                 int slot = l0 + lr;
                 slot -= (slot / G::DR) * G::DR;
-                ring[(slot * G::DC + lc) * NQ + qq] = o;
+                ring[(slot * G::DC + lc) * NQ + qd] = o;
             }
         }
     };
@@ -198,11 +211,11 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
         }
         float4 rg[UD], ry[UD], rx[UX];
         // first step: ring rows 0 .. DR - 1 (DR <= 2 DN: two batches)
-        load_dy(rg, ry, 0, G::DN);
+        load_dy(rg, ry, 0, G::DN, 0, UD);
         load_x(rx, 0);
         store_dy(rg, ry, 0, G::DN);
         store_x(rx, 0);
-        load_dy(rg, ry, G::DN, G::DR - G::DN);
+        load_dy(rg, ry, G::DN, G::DR - G::DN, 0, UD);
         store_dy(rg, ry, G::DN, G::DR - G::DN);
     }
     float4 dwacc[9];
@@ -222,7 +235,16 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
         const int cur = k & 1;
         const float* xc = xt + cur * (NPXS * XP);
         const int y0 = ys + TH * k;
+        // ---- [A] the next step's dy' rows and x rows: in flight across the whole step, written to LDS at its end
+        // (UNCONDITIONAL -- the last step requests clamped rows it never uses: inside `if (more)` the loaded registers become phi
+        // copies at the end of the block, and every copy waits for its load: the whole batch was drained right after it was issued)
+        float4 rg[UD], ry[UD], rx[UX];
+        if constexpr (!(XB_SKIP & 16)) {
+            load_dy(rg, ry, G::DR + G::DN * k, G::DN, 0, UD);
+            load_x(rx, k + 1);
+        }
         // ---- [B] expand: unit u = (pixel tile pt, 16-channel tile ct), wave w takes u = w, w + 8, ...; two chains at a time
+        if constexpr (!(XB_SKIP & 1))
         for (int u0 = w; u0 < NUE; u0 += 16) {
             const int u1 = u0 + 8;
             const int pa = u0 / NCT, ca = u0 - pa * NCT;
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
         }
         __syncthreads();
         // ---- [C] depthwise stage
-        if (dact) {
+        if (dact && !(XB_SKIP & 2)) {
             if constexpr (S == 1) {
                 for (int px = pl; px < NPXS; px += NPL) {
                     const int r = px >> 4, c = px & 15;
@@ -274,8 +296,7 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
                     s1 = f4add(s1, ge);
                     s2 = f4fma(ge, make_float4((y.x - cem.x) * cei.x, (y.y - cem.y) * cei.y, (y.z - cem.z) * cei.z, (y.w - cem.w) * cei.w), s2);
                     *reinterpret_cast<float4*>(yp) = make_float4(ge.x * cpe.x, ge.y * cpe.y, ge.z * cpe.z, ge.w * cpe.w);
-                    if (p.gexp != nullptr && valid)
-                        stg4(p.gexp + (img + (size_t)(y0 + r) * p.IW + x0 + c) * p.ldge + 4 * qd, ge);
+                    if constexpr (GE) { if (valid) stg4(p.gexp + (img + (size_t)(y0 + r) * p.IW + x0 + c) * p.ldge + 4 * qd, ge); }
                 }
             } else {
                 for (int bq = pl; bq < NPXS / 4; bq += NPL) {       // 2 x 2 input pixels <-> one output neighbourhood
@@ -306,8 +327,7 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
                         s1 = f4add(s1, ge);
                         s2 = f4fma(ge, make_float4((y.x - cem.x) * cei.x, (y.y - cem.y) * cei.y, (y.z - cem.z) * cei.z, (y.w - cem.w) * cei.w), s2);
                         *reinterpret_cast<float4*>(yp) = make_float4(ge.x * cpe.x, ge.y * cpe.y, ge.z * cpe.z, ge.w * cpe.w);
-                        if (p.gexp != nullptr && valid)
-                            stg4(p.gexp + (img + (size_t)(y0 + r) * p.IW + x0 + c) * p.ldge + 4 * qd, ge);
+                        if constexpr (GE) { if (valid) stg4(p.gexp + (img + (size_t)(y0 + r) * p.IW + x0 + c) * p.ldge + 4 * qd, ge); }
                     }
                     dwacc[4] = f4fma(da0, h4[0], dwacc[4]);
                     dwacc[3] = f4fma(da1, h4[1], dwacc[3]); dwacc[5] = f4fma(da0, h4[1], dwacc[5]);
@@ -318,16 +338,12 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
             }
         }
         __syncthreads();
-        // ---- [A] the next step's dy' rows and x rows: requested here (not at the top of the step: the depthwise stage needs the
-        // registers), in flight across the two MFMA stages below, written to LDS at the end of the step
-        float4 rg[UD], ry[UD], rx[UX];
-        if (more) {
-            load_dy(rg, ry, G::DR + G::DN * k, G::DN);
-            load_x(rx, k + 1);
-        }
         // ---- [D] Z1 = W_e^T (p_e g_e): unit (pixel tile pt, input-channel tile it); A[i][k] = W_e[c(k)][i], B[k][px] = (p_e g_e)[px][c(k)],
         // c(g, kk) = g * KE + kk; two chains over the even / odd k-steps
-        for (int u = w; u < NUZ; u += 8) {
+        if constexpr (!(XB_SKIP & 4))
+#pragma unroll
+        for (int uj = 0; uj < (NUZ + 7) / 8; ++uj) {
+            const int u = min(w + 8 * uj, NUZ - 1);             // (NUZ is a multiple of 8 for every instantiation)
             const int pt = u / NI, it = u - pt * NI;
             const float* ap = wx + (g * KE) * WP + it * 16 + l15;
             const float* bp = yt + (pt * 16 + l15) * EP + g * KE;
@@ -348,12 +364,12 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
 #pragma unroll
         for (int j = 0; j < MUG; ++j) {
             const int u = w + 8 * j;
-            if (u < NUG) {                                      // uniform
+            if (u < NUG && !(XB_SKIP & 8)) {                    // uniform
                 const int ct = u / NI, it = u - ct * NI;
                 const float* ap = yt + g * EP + ct * 16 + l15;
                 const float* bp = xc + g * XP + it * 16 + l15;
                 f32x4 a0 = g1[j], a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
                 for (int kk = 0; kk < NPXS / 4; kk += 2) {
                     a0 = mfma16b(ap[(4 * kk) * EP], bp[(4 * kk) * XP], a0);
                     a1 = mfma16b(ap[(4 * kk + 4) * EP], bp[(4 * kk + 4) * XP], a1);
@@ -361,7 +377,11 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
                 g1[j] = f32x4{a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]};
             }
         }
-        if (more) {
+        if constexpr ((XB_SKIP & 48) == 32) {                   // diagnostic: the loads are waited for, nothing is written
+#pragma unroll
+            for (int u = 0; u < UD; ++u) asm volatile("" :: "v"(rg[u].x), "v"(rg[u].w), "v"(ry[u].x), "v"(ry[u].w));
+        } else
+        if (more && !(XB_SKIP & 16)) {
             store_dy(rg, ry, G::DR + G::DN * k, G::DN);         // the new rows take the slots of the window's oldest rows
             store_x(rx, cur ^ 1);
         }
@@ -408,6 +428,23 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
 //   p_e = gamma invstd, q_e = -p_e invstd S2 / n, r_e = -p_e S1 / n;  dgamma = S2, dbeta = S1;  dW_d = sum of the rows;
 //   dW_e[c][i] = G1[c][i] + q_e[c] (sum_j W_e[c][j] Gxx[j][i] - mu_e[c] sx[i]) + r_e[c] sx[i]
 // and its share of  A = W_e^T diag(q_e) W_e,  b' = W_e^T (r_e - q_e mu_e)  as a partial row (the fix-up kernel sums the E / 16 rows).
+// rows r = s, s + NS, ... of the walkers' partial rows -> slice s (fixed order): the 256 x 20 K-float reduction spread over the chip
+__global__ __launch_bounds__(256) void xslice_kernel(const float* part, int nblk, int rowf, int ns, float* out) {
+    const int e = blockIdx.x * 256 + threadIdx.x, s0 = blockIdx.y;
+    if (e >= rowf) return;
+    float a = 0.f;
+    int r = s0;
+    for (; r + 7 * ns < nblk; r += 8 * ns) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(r + u * ns) * rowf + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; r < nblk; r += ns) a += part[(size_t)r * rowf + e];
+    out[(size_t)s0 * rowf + e] = a;
+}
+
 struct XfoldP {
     const float* part; int nblk, row_floats;
     const double* mom;                       // [I * I + I]: Gxx, sx of x' (pq_xstat_fwd)
@@ -573,6 +610,7 @@ static XbPlan xb_plan(int B, int IH, int IW, int I, int E, int stride) {
     return w;
 }
 static int xb_row_floats(int I, int E) { return E * I + E * 9 + 2 * E; }
+constexpr int XB_SLICES = 16;
 
 extern "C" int32_t pq_xdw_bwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t I, int32_t E, int32_t stride) {
     if (!xb_shape_ok(I, E, stride, IH, IW)) return 0;
@@ -581,22 +619,26 @@ extern "C" int32_t pq_xdw_bwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t 
 extern "C" int64_t pq_xdw_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, int32_t I, int32_t E, int32_t stride) {
     if (!xb_shape_ok(I, E, stride, IH, IW)) return 0;
     const XbPlan w = xb_plan(B, IH, IW, I, E, stride);
-    // partial rows | A / b' rows of the fold | Z1
-    return ((int64_t)w.nblk * xb_row_floats(I, E) + (int64_t)(E / 16) * (I * I + I) + (int64_t)B * IH * IW * I) * 4 + 256;
+    // partial rows | their slices | A / b' rows of the fold | Z1
+    return ((int64_t)(w.nblk + XB_SLICES) * xb_row_floats(I, E) + (int64_t)(E / 16) * (I * I + I) + (int64_t)B * IH * IW * I) * 4 + 256;
 }
 
-template <int S, int KS, int NQ>
-static int xb_launch(const XbwdP& p, const XbPlan& w, hipStream_t st) {
+template <int S, int KS, int NQ, bool GE>
+static int xb_launch1(const XbwdP& p, const XbPlan& w, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)xdwb_kernel<S, KS, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)xdwb_kernel<S, KS, NQ, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             pq_set_error("pq_xdw_bwd: cannot raise the dynamic LDS limit");
             return PQ_ELAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((xdwb_kernel<S, KS, NQ>), dim3(w.nblk), dim3(512), w.lds, st, p);
+    hipLaunchKernelGGL((xdwb_kernel<S, KS, NQ, GE>), dim3(w.nblk), dim3(512), w.lds, st, p);
     return PQ_OK;
+}
+template <int S, int KS, int NQ>
+static int xb_launch(const XbwdP& p, const XbPlan& w, hipStream_t st) {
+    return p.gexp ? xb_launch1<S, KS, NQ, true>(p, w, st) : xb_launch1<S, KS, NQ, false>(p, w, st);
 }
 
 extern "C" int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream) {
@@ -623,7 +665,8 @@ extern "C" int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream) {
     const int M = a->B * a->IH * a->IW;
     const int rowf = xb_row_floats(a->I, a->E);
     float* part = a->scratch;
-    float* ab = part + (size_t)w.nblk * rowf;
+    float* slices = part + (size_t)w.nblk * rowf;
+    float* ab = slices + (size_t)XB_SLICES * rowf;
     float* z1 = ab + (size_t)(a->E / 16) * (a->I * a->I + a->I);
     z1 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(z1) + 63) & ~(uintptr_t)63);
     hipStream_t st = (hipStream_t)stream;
@@ -638,7 +681,9 @@ extern "C" int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream) {
     else if (a->stride == 1) rc = xb_launch<1, 6, 36>(p, w, st);
     else rc = xb_launch<2, 6, 36>(p, w, st);
     if (rc != PQ_OK) return rc;
-    XfoldP f{part, w.nblk, rowf, a->moments, a->we, a->mid_gamma, a->mid_invstd, a->mid_mean, a->dwe, a->dwd, a->dgamma, a->dbeta, ab,
+    const int ns = w.nblk < XB_SLICES ? w.nblk : XB_SLICES;
+    hipLaunchKernelGGL(xslice_kernel, dim3((rowf + 255) / 256, ns), dim3(256), 0, st, (const float*)part, w.nblk, rowf, ns, slices);
+    XfoldP f{slices, ns, rowf, a->moments, a->we, a->mid_gamma, a->mid_invstd, a->mid_mean, a->dwe, a->dwd, a->dgamma, a->dbeta, ab,
              a->I, a->E, (float)((double)a->B * a->IH * a->IW)};
     hipLaunchKernelGGL(xfold_kernel, dim3(a->E / 16), dim3(256), 0, st, f);
     XfixP x{z1, a->I, a->in, a->dx, ab, a->E / 16, M, a->I};

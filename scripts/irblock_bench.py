@@ -19,7 +19,7 @@ def timeit(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 tot = [0.0] * 5
-for (B, H, W, I, E, s) in SHAPES:
+for (B, H, W, I, E, s) in ([] if os.environ.get('BWD_ONLY') else SHAPES):
     OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
     M = B * H * W
     x = torch.randn(B, H, W, I, device=dev); we = torch.randn(E, I, device=dev) * 0.2; wd = torch.randn(E, 9, device=dev)
@@ -63,3 +63,57 @@ for (B, H, W, I, E, s) in SHAPES:
               B, H, W, I, E, s, t_e, t_d, t_e + t_d, t_g, t_0, t_x, t_g + t_x, byt / t_x / 1e6, fl / t_x / 1e9, nb3), flush=True)
 print('sum: unfused %.3f + %.3f = %.3f ms | fused %.3f + %.3f = %.3f ms (statistics-only GEMM instead of the moments pass: %.3f)' % (
     tot[0], tot[1], tot[0] + tot[1], tot[4], tot[3], tot[4] + tot[3], tot[2]))
+
+# ---- backward: walking depthwise backward + fused narrow 1x1 backward (expand layer)  vs  pq_xdw_bwd
+print('backward')
+totb = [0.0] * 3
+for (B, H, W, I, E, s) in SHAPES:
+    if not l.pq_xdw_bwd_blocks(B, H, W, I, E, s):
+        continue
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    M = B * H * W
+    x = torch.randn(B, H, W, I, device=dev); we = torch.randn(E, I, device=dev) * 0.2; wd = torch.randn(E, 9, device=dev)
+    ye = torch.randn(B, H, W, E, device=dev); ge = torch.empty(B, H, W, E, device=dev)
+    yd = torch.randn(B, OH, OW, E, device=dev); gd = torch.randn(B, OH, OW, E, device=dev); gx = torch.empty(B, H, W, I, device=dev)
+    vI = [vec(I) for _ in range(4)]; vE = [vec(E) for _ in range(13)]
+    # unfused: pq_dw3x3_bwd part 5 (+6) then pq_conv1x1_bwd
+    nbw = l.pq_dw3x3_bwd_walk_blocks(B, H, W, E, s)
+    pw_ = torch.empty(nbw * 2 * E, device=dev); scw = torch.empty(nbw * E * 9 + 16, device=dev); dwd = torch.empty(E * 9, device=dev)
+    gsd = abi.GSrc(gd.data_ptr(), yd.data_ptr(), vE[0].data_ptr(), vE[1].data_ptr(), vE[2].data_ptr(), vE[3].data_ptr(), E, E)
+    srce = abi.Src(ye.data_ptr(), vE[4].data_ptr(), vE[5].data_ptr(), E, 2)
+    sinke = abi.GSink(ge.data_ptr(), ye.data_ptr(), vE[4].data_ptr(), vE[5].data_ptr(), vE[6].data_ptr(), vE[7].data_ptr(), pw_.data_ptr(), E, E, 2, 0, 1, E)
+    f5 = abi.DwBwd(gsd, srce, wd.data_ptr(), sinke, None, scw.data_ptr(), B, H, W, OH, OW, E, s, 5)
+    f6 = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), dwd.data_ptr(), scw.data_ptr(), B, H, W, OH, OW, E, s, 6)
+    t_dw = timeit(lambda: (abi.check(l.pq_dw3x3_bwd(C.byref(f5), st)), abi.check(l.pq_dw3x3_bwd(C.byref(f6), st))))
+    nb1 = l.pq_conv1x1_bwd_blocks(M, I, E)
+    t_pw = float('nan')
+    if nb1:
+        p1 = torch.empty(nb1 * 2 * 32, device=dev); dwe = torch.empty(E * I, device=dev)
+        sc1 = torch.empty(l.pq_conv1x1_bwd_scratch_bytes(M, I, E) // 4 + 16, device=dev)
+        gse = abi.GSrc(ge.data_ptr(), ye.data_ptr(), vE[8].data_ptr(), vE[9].data_ptr(), vE[10].data_ptr(), vE[11].data_ptr(), E, E)
+        sinkx = abi.GSink(gx.data_ptr(), x.data_ptr(), vI[0].data_ptr(), vI[1].data_ptr(), vI[2].data_ptr(), vI[3].data_ptr(), p1.data_ptr(), I, I, 0, 0, 1, 32)
+        c1 = abi.Conv1x1Bwd(gse, we.data_ptr(), abi.Src(x.data_ptr(), vI[0].data_ptr(), vI[1].data_ptr(), I, 0), sinkx, dwe.data_ptr(), sc1.data_ptr(), M, I, E)
+        t_pw = timeit(lambda: abi.check(l.pq_conv1x1_bwd(C.byref(c1), st)))
+    # fused
+    nfix = l.pq_xdw_bwd_fix_blocks(M, I)
+    p2 = torch.empty(nfix * 2 * 32, device=dev)
+    scr = torch.empty(l.pq_xdw_bwd_scratch_bytes(B, H, W, I, E, s) // 4, device=dev)
+    mom = torch.rand(I * I + I, device=dev, dtype=torch.float64)
+    outs = [torch.empty(E * I, device=dev), torch.empty(E * 9, device=dev), torch.empty(E, device=dev), torch.empty(E, device=dev)]
+    a = abi.XdwBwd()
+    a.inp = abi.Src(x.data_ptr(), vI[0].data_ptr(), vI[1].data_ptr(), I, 0)
+    a.we, a.wd = we.data_ptr(), wd.data_ptr()
+    a.mid_scale, a.mid_shift, a.mid_mean, a.mid_invstd, a.mid_gamma = [v.data_ptr() for v in vE[4:9]]
+    a.mid_act = 2
+    a.dy = gsd
+    a.dx = abi.GSink(gx.data_ptr(), x.data_ptr(), vI[0].data_ptr(), vI[1].data_ptr(), vI[2].data_ptr(), vI[3].data_ptr(), p2.data_ptr(), I, I, 0, 0, 1, 32)
+    a.dwe, a.dwd, a.dgamma, a.dbeta = [o.data_ptr() for o in outs]
+    a.moments, a.scratch = mom.data_ptr(), scr.data_ptr()
+    a.B, a.IH, a.IW, a.OH, a.OW, a.I, a.E, a.stride = B, H, W, OH, OW, I, E, s
+    t_q = timeit(lambda: abi.check(l.pq_xdw_bwd(C.byref(a), st)))
+    byt = 4.0 * (2 * B * OH * OW * E + 3 * M * I)
+    totb[0] += t_dw; totb[1] += t_pw; totb[2] += t_q
+    print('B=%d %dx%d %d->%d s=%d | unfused: depthwise backward %.3f + narrow 1x1 backward %.3f = %.3f ms | fused (3 launches) %.3f ms '
+          '(%.0f GB/s of minimal traffic, %d walkers)' % (B, H, W, I, E, s, t_dw, t_pw, t_dw + t_pw, t_q, byt / t_q / 1e6,
+                                                          l.pq_xdw_bwd_blocks(B, H, W, I, E, s)), flush=True)
+print('sum backward: unfused %.3f + %.3f = %.3f ms | fused %.3f ms' % (totb[0], totb[1], totb[0] + totb[1], totb[2]))
