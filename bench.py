@@ -107,6 +107,9 @@ KERNEL_CLASS = {
     abi.OP_BN_EVAL: ('bn vectors from running statistics (one launch)', 'hbm'),
     abi.OP_QAT_WPREP: ('qat weight scale+observe+quantise (one launch)', 'hbm'),
     abi.OP_QACT_FWD: ('qat activation observe+quantise', 'hbm'), abi.OP_QACT_BWD: ('qat activation backward', 'hbm'),
+    abi.OP_XSTAT_FWD: ('xstat_fwd (expanded-tensor BN statistics from input moments)', 'hbm'),
+    abi.OP_XDW_FWD: ('xdw_fwd (fused expand 1x1 + BN + ReLU6 + dw3x3)', 'hbm'),
+    abi.OP_XDW_BWD: ('xdw_bwd (fused dw3x3 + expand 1x1 backward, recompute)', 'hbm'),
 }
 
 
@@ -146,6 +149,19 @@ def op_work(op):
         a = op.u.rb
         n = a.B * a.H * a.W * a.C
         return float(n), 4.0 * n * 2
+    # fused inverted-residual ops: the counting rule of the layers they replace (expand 1x1 + depthwise 3x3)
+    if c == abi.OP_XSTAT_FWD:
+        a = op.u.xsf
+        return 2.0 * a.M * a.I * a.I, 4.0 * a.M * a.I
+    if c == abi.OP_XDW_FWD:
+        a = op.u.xdf
+        m_in, n_out = a.B * a.IH * a.IW, a.B * a.OH * a.OW * a.E
+        return 2.0 * m_in * a.I * a.E + 2.0 * 9 * n_out, 4.0 * (m_in * a.I + m_in * a.E + a.I * a.E) + 4.0 * (m_in * a.E + n_out + 9 * a.E)
+    if c == abi.OP_XDW_BWD:
+        a = op.u.xdb
+        m_in, n_out = a.B * a.IH * a.IW, a.B * a.OH * a.OW * a.E
+        return (2.0 * 2.0 * m_in * a.I * a.E + 2.0 * 2.0 * 9 * n_out,
+                4.0 * (2 * m_in * a.I + m_in * a.E + 2 * a.I * a.E) + 2.0 * 4.0 * (m_in * a.E + n_out + 9 * a.E))
     if c in (abi.OP_LOSS_FWD, abi.OP_LOSS_BWD):
         a = op.u.loss
         n = a.B * a.H * a.W * a.A * (5 + a.C)

@@ -325,6 +325,41 @@ class Plan:
                 raise NotImplementedError("layer type '%s' is not supported by the HIP engine yet" % t)
             shapes.append((h, w, c))
 
+        # ---- inverted-residual fusion (csrc/irblock.hip, irbwd.hip): a 1x1 expand conv + BN + ReLU6 whose ONLY consumer is the next
+        # layer, a depthwise 3x3 + BN (MobileNetV2's expand -> depthwise pair), runs as pq_xstat_fwd + pq_xdw_fwd in the forward and
+        # pq_xdw_bwd in the backward: the expanded tensor and its gradient are never materialised.  Train-mode plans with a loss
+        # only (the fused backward folds the train-mode BatchNorm backward analytically), never QAT; PQ_IRFUSE=0 switches it off.
+        self.ir_fused: Dict[int, int] = {}                     # depthwise layer index -> its expand layer index
+        if self.with_loss and self.bn_train and not self.qat and os.environ.get('PQ_IRFUSE', '1') != '0':
+            hw_ = [(self.IH, self.IW)]
+            for i, m in enumerate(mods[:-1]):
+                d = mods[i + 1]
+                if i == 0 or m._type != 'convolutional' or d._type != 'convolutional' or not hasattr(m, 'bn') or not hasattr(d, 'bn'):
+                    continue
+                ce, cd_ = m.conv, d.conv
+                if not (ce.kernel_size[0] == 1 and ce.stride[0] == 1 and ce.groups == 1 and ce.bias is None and ce.padding[0] == 0):
+                    continue
+                E_, I_ = ce.out_channels, ce.in_channels
+                if not (cd_.kernel_size[0] == 3 and cd_.groups == E_ and cd_.in_channels == E_ and cd_.out_channels == E_ and
+                        cd_.padding[0] == 1 and cd_.bias is None and cd_.stride[0] in (1, 2)):
+                    continue
+                if act_code_of(getattr(m, 'act', None)) != abi.ACT_RELU6 or consumers.get(i, 0) != 1 or resolve(i, i + 1) != i:
+                    continue
+                sidx = resolve(i - 1, i)
+                sm = mods[sidx]
+                # the block input must be a linear operand: a conv + BN without activation, or a materialised shortcut sum
+                if sm._type == 'convolutional':
+                    if act_code_of(getattr(sm, 'act', None)) != abi.ACT_LINEAR or not hasattr(sm, 'bn'):
+                        continue
+                elif sm._type != 'shortcut' or act_code_of(sm.act) != abi.ACT_LINEAR:
+                    continue
+                H_, W_ = shapes[i][0], shapes[i][1]
+                if l.pq_xdw_fwd_blocks(B, H_, W_, I_, E_, cd_.stride[0]) <= 0 or l.pq_xdw_bwd_blocks(B, H_, W_, I_, E_, cd_.stride[0]) <= 0:
+                    continue
+                self.ir_fused[i + 1] = i
+        ir_expand = set(self.ir_fused.values())
+        self.ir_expand = ir_expand
+
         # ---- pass 1: forward ops ---------------------------------------------------------------------
         T: List[Optional[TensorRef]] = []
         self.tensors = T
@@ -362,6 +397,20 @@ class Plan:
                 if special_act and (train_graph or self.qat):
                     raise NotImplementedError('logistic / tanh as a conv activation have no backward / QAT support (forward only; '
                                               'the gate of a scale_channels layer is the exception)')
+                if i in ir_expand:
+                    # fused expand layer: no tensor (the depthwise kernel recomputes its values), only the BatchNorm vectors, which
+                    # pq_xstat_fwd derives from the moments of the block input (kept in fp64 for the backward)
+                    src = T[resolve(i - 1, i)]
+                    out = TensorRef(None, B, OH, OW, Cout, ld, bn, act)
+                    out.is_gate = False
+                    out.ir_src = src
+                    out.ir_moments = torch.zeros(Cin * Cin + Cin, device=self.device, dtype=torch.float64)
+                    out.ir_scratch = self._new(l.pq_xstat_fwd_scratch_bytes(rows, Cin) // 4 + 16, fill=0.0)
+                    self.keep.append(out.ir_moments)
+                    bn.fwd_nblk = 0
+                    self._deferred.append(('xstat', i, out, src))
+                    T.append(out)
+                    continue
                 raw = self._new(rows, ld) if ld == Cout else self._new(rows, ld, fill=0.0)
                 out = TensorRef(raw, B, OH, OW, Cout, ld, bn, act)
                 out.is_gate = is_gate
@@ -412,6 +461,9 @@ class Plan:
                     if k == 1 and groups == 1:
                         nblk = l.pq_conv1x1_blocks_k(rows, Cout, Cin, 0)
                         self._deferred.append(('c1_fwd', i, out, nblk, src, s))
+                    elif i in self.ir_fused:
+                        nblk = l.pq_xdw_fwd_blocks(B, src.H, src.W, src.ir_src.C, Cout, s)
+                        self._deferred.append(('xdw_fwd', i, out, nblk, src, s))
                     elif k == 3 and groups == Cin == Cout and conv.padding[0] == 1:
                         nblk = l.pq_dw3x3_fwd_blocks(B, OH, OW, Cout, s)
                         self._deferred.append(('dw_fwd', i, out, nblk, src, s))
@@ -617,6 +669,23 @@ class Plan:
                                    ptr(out.raw), ptr(part), out.rows, src.C, out.C, out.ld, out.bn.ldp if out.bn else 0,
                                    s, out.H, out.W, src.H, src.W, int(getattr(out, 'fold_obs', False)))
                 self._op(self.fwd, abi.OP_CONV1X1_FWD, a)
+            elif kind == 'xstat':
+                _, i, out, src = item
+                b = out.bn
+                bm = b.module
+                a = abi.XstatFwd(src.src(), wptr(i), ptr(bm.weight), ptr(bm.bias), ptr(bm.running_mean), ptr(bm.running_var),
+                                 ptr(bm.num_batches_tracked), ptr(b.mean), ptr(b.invstd), ptr(b.scale), ptr(b.shift),
+                                 ptr(out.ir_scratch), out.rows, src.C, out.C, float(bm.eps),
+                                 float(bm.momentum if bm.momentum is not None else 0.1), out.ir_moments.data_ptr())
+                self._op(self.fwd, abi.OP_XSTAT_FWD, a)
+            elif kind == 'xdw_fwd':
+                _, i, out, nblk, mid, s = item
+                x_in = mid.ir_src
+                part = out.bn.fwd_partial if (out.bn and self.bn_train) else None
+                a = abi.XdwFwd(x_in.src(), wptr(self.ir_fused[i]), abi.Src(None, ptr(mid.bn.scale), ptr(mid.bn.shift), 0, mid.act), None,
+                               wptr(i), ptr(out.raw), ptr(part), B, mid.H, mid.W, out.H, out.W, x_in.C, out.C, s, 0, out.ld,
+                               out.bn.ldp if out.bn else 0)
+                self._op(self.fwd, abi.OP_XDW_FWD, a)
             elif kind == 'dw_fwd':
                 _, i, out, nblk, src, s = item
                 conv = mods[i].conv
@@ -992,6 +1061,35 @@ class Plan:
                     # are latency bound, ~26 us each on the critical chain whatever the head size
                     self._loss_extra.append(la)
                     self.loss_ops_b.append((-len(self._loss_extra), slot, stride))
+            elif t == 'convolutional' and i in self.ir_expand:
+                pass             # fused expand layer: every gradient of it was written by the pq_xdw_bwd of its depthwise layer
+            elif t == 'convolutional' and i in self.ir_fused and T[i].grad is not None and T[i].n_consumers > 0:
+                # fused depthwise + expand backward (irbwd.hip): walking kernel + fold + fix-up, main stream
+                out, mid = T[i], T[self.ir_fused[i]]
+                ie = self.ir_fused[i]
+                conv, conv_e = m.conv, mods[ie].conv
+                x_in = mid.ir_src
+                if out.bn.bwd_partial is None:
+                    raise RuntimeError('internal: BN layer %d never finalised its gradient' % i)
+                bn_bwd(out)
+                be = mid.bn
+                M_ = x_in.rows
+                need = l.pq_xdw_bwd_scratch_bytes(B, x_in.H, x_in.W, x_in.C, out.C, conv.stride[0])
+                buf = self._new(need // 4 + 64)
+                a = abi.XdwBwd()
+                a.inp, a.we = x_in.src(), ptr(conv_e.weight)
+                a.mid_scale, a.mid_shift, a.mid_mean, a.mid_invstd, a.mid_gamma = ptr(be.scale), ptr(be.shift), ptr(be.mean), ptr(be.invstd), \
+                    ptr(be.module.weight)
+                a.mid_act = mid.act
+                a.dy, a.wd = out.gsrc(self.bn_train), ptr(conv.weight)
+                a.dx = self._sink(x_in, l.pq_xdw_bwd_fix_blocks(M_, x_in.C))
+                a.dwe, a.dwd = flat.grad_ptr(conv_e.weight), flat.grad_ptr(conv.weight)
+                a.dgamma, a.dbeta = flat.grad_ptr(be.module.weight), flat.grad_ptr(be.module.bias)
+                a.moments, a.scratch = mid.ir_moments.data_ptr(), ptr(buf)
+                a.B, a.IH, a.IW, a.OH, a.OW, a.I, a.E, a.stride = B, x_in.H, x_in.W, out.H, out.W, x_in.C, out.C, conv.stride[0]
+                self._op(self.bwd, abi.OP_XDW_BWD, a)
+                lo = min(flat.offsets[flat.index[id(p_)]] for p_ in list(m.parameters()) + list(mods[ie].parameters()))
+                self.segments.append((len(self.bwd), lo))
             elif t == 'convolutional':
                 out = T[i]
                 conv = m.conv
