@@ -781,6 +781,25 @@ __global__ __launch_bounds__(1024) void dww_partial_reduce_kernel(const float* p
     }
 }
 
+// Long partial lists (the 256 x 256 planes leave 512 rows): rows r = s, s + ns, ... are first summed INTO row s by (column tile, s)
+// workgroups spread over the chip (fixed order; a row is only touched by the workgroups of its own slice, so in place is safe), and
+// dww_partial_reduce_kernel then sums ns rows.  One launch over 9 workgroups walking 512 rows took 79 us at the tail of the step.
+__global__ __launch_bounds__(256) void dww_slice_rows_kernel(float* part, int nblk, int n, int ns) {
+    const int e = blockIdx.x * 256 + threadIdx.x, s0 = blockIdx.y;
+    if (e >= n) return;
+    float a = 0.f;
+    int r = s0;
+    for (; r + 7 * ns < nblk; r += 8 * ns) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(r + u * ns) * n + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; r < nblk; r += ns) a += part[(size_t)r * n + e];
+    part[(size_t)s0 * n + e] = a;
+}
+
 }  // namespace pq
 
 using namespace pq;
@@ -816,7 +835,13 @@ int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->part == 6) {
         const int n = a->C * 9;
-        hipLaunchKernelGGL(dww_partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, w.nblk, n, a->dw);
+        int rows = w.nblk;
+        if (rows > 64) {
+            constexpr int NS = 16;
+            hipLaunchKernelGGL(dww_slice_rows_kernel, dim3((n + 255) / 256, NS), dim3(256), 0, st, a->scratch, rows, n, NS);
+            rows = NS;
+        }
+        hipLaunchKernelGGL(dww_partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, rows, n, a->dw);
         return PQ_OK;
     }
     DwWP p{};

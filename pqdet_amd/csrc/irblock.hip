@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256, 2) void xdw_fwd_kernel(XdwP p) {
             wtab[q][k] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
         }
     }
-    const ActParam mact = act_param(p.mid.act);
+    // the expanded tensor's activation is linear / ReLU / ReLU6 (host-checked): a clamp; a padding pixel clamps to [0, 0]
+    const float mlo = p.mid.act == PQ_ACT_LINEAR ? -__builtin_huge_valf() : 0.f, mhi = p.mid.act == PQ_ACT_RELU6 ? 6.f : __builtin_huge_valf();
     const size_t img = (size_t)b * p.IH * p.IW;
     // per-lane constants of the walk: element offset of the lane's fragment inside a plane row and the column's padding test, for
     // the row tiles (one per tile of a row) and for the halo tile (whose row differs per lane)
@@ -180,11 +181,12 @@ __global__ __launch_bounds__(256, 2) void xdw_fwd_kernel(XdwP p) {
             lr = hrow; lc = hcol; on = S == 1 ? hrow < NR : l15 < NR;
             in_img = on && hcolok && (unsigned)(ys - 1 + l0 + lr) < (unsigned)p.IH;
         }
+        const float lo = in_img ? mlo : 0.f, hi = in_img ? mhi : 0.f;
         float4 o;
-        o.x = in_img ? act_fwd(fmaf(mk.a[0], acc[0], mk.b[0]), mact) : 0.f;
-        o.y = in_img ? act_fwd(fmaf(mk.a[1], acc[1], mk.b[1]), mact) : 0.f;
-        o.z = in_img ? act_fwd(fmaf(mk.a[2], acc[2], mk.b[2]), mact) : 0.f;
-        o.w = in_img ? act_fwd(fmaf(mk.a[3], acc[3], mk.b[3]), mact) : 0.f;
+        o.x = fminf(fmaxf(fmaf(mk.a[0], acc[0], mk.b[0]), lo), hi);
+        o.y = fminf(fmaxf(fmaf(mk.a[1], acc[1], mk.b[1]), lo), hi);
+        o.z = fminf(fmaxf(fmaf(mk.a[2], acc[2], mk.b[2]), lo), hi);
+        o.w = fminf(fmaxf(fmaf(mk.a[3], acc[3], mk.b[3]), lo), hi);
         int slot = l0 + lr;
         slot -= (slot / G::RT) * G::RT;
         if (on) ring[G::px(slot, lc) * XPQ + qm] = o;
@@ -250,11 +252,12 @@ __global__ __launch_bounds__(256, 2) void xdw_fwd_kernel(XdwP p) {
         float4 acc[G::NO];
 #pragma unroll
         for (int u = 0; u < G::NO; ++u) acc[u] = f4zero();
-        const int base = TH * k + S * G::NO * rp;                // ring-local row of the lane's first window row
+        const int kb = (TH * k) % G::RT;                         // uniform: ring slot of the step's first window row
+        const int base = kb + S * G::NO * rp;                    // the lane's first window row: < 2 RT, one conditional subtraction
 #pragma unroll
         for (int wr = 0; wr < G::WR; ++wr) {
             int slot = base + wr;
-            slot -= (slot / G::RT) * G::RT;
+            slot = slot >= G::RT ? slot - G::RT : slot;
             float4 xr[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) xr[j] = ring[G::px(slot, S * col + j) * XPQ + q];
@@ -531,8 +534,8 @@ extern "C" int pq_xdw_fwd(const pq_xdw_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a->partial == nullptr || a->ldp >= a->E, "stats pitch too small");
     PQ_CHECK_ARG(a->stat_acc == nullptr || (a->stat_bad != nullptr && a->ldp >= a->E), "stat_acc needs stat_bad");
     PQ_CHECK_ARG(a->mid.stat.acc != nullptr || a->mid.scale != nullptr, "mid needs scale / shift or statistics accumulators");
-    if (a->in.act != PQ_ACT_LINEAR || act_is_special(a->mid.act) || a->in.qstate || a->mid.qstate || a->in.stat.acc) {
-        pq_set_error("pq_xdw_fwd: the input operand must be linear (BatchNorm affine only); logistic / tanh on the expanded tensor, QAT "
+    if (a->in.act != PQ_ACT_LINEAR || act_is_special(a->mid.act) || a->mid.act == PQ_ACT_LEAKY || a->in.qstate || a->mid.qstate || a->in.stat.acc) {
+        pq_set_error("pq_xdw_fwd: the input operand must be linear (BatchNorm affine only); leaky / logistic / tanh on the expanded tensor, QAT "
                      "observers and in.stat are not supported");
         return PQ_EUNSUPPORTED;
     }

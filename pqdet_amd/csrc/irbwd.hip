@@ -456,8 +456,10 @@ struct XfoldP {
 __global__ __launch_bounds__(256) void xfold_kernel(XfoldP p) {
     __shared__ float sums[16 * (32 + 11)];   // [16 channels][I + 9 + 2]
     __shared__ float qv[16], rv[16], mu[16];
+    __shared__ float wl[16][33];             // the group's weight rows (the loops below re-read them I times)
     const int t = threadIdx.x, c0 = blockIdx.x * 16;
     const int I = p.I, E = p.E, W = I + 11;
+    for (int e = t; e < 16 * I; e += 256) wl[e / I][e % I] = p.we[(size_t)c0 * I + e];
     // element e of the channel group: (channel cl, column j): j < I: G1, j < I + 9: dW_d tap, then S1, S2
     for (int e = t; e < 16 * W; e += 256) {
         const int cl = e / W, j = e - cl * W, c = c0 + cl;
@@ -494,9 +496,8 @@ __global__ __launch_bounds__(256) void xfold_kernel(XfoldP p) {
     __syncthreads();
     for (int e = t; e < 16 * I; e += 256) {
         const int cl = e / I, i = e - cl * I, c = c0 + cl;
-        const float* wr = p.we + (size_t)c * I;
         double acc = 0.0;
-        for (int j = 0; j < I; ++j) acc = fma((double)wr[j], p.mom[j * I + i], acc);
+        for (int j = 0; j < I; ++j) acc = fma((double)wl[cl][j], p.mom[j * I + i], acc);
         const double sx = p.mom[I * I + i];
         p.dwe[(size_t)c * I + i] = (float)((double)sums[cl * W + i] + (double)qv[cl] * (acc - (double)mu[cl] * sx) + (double)rv[cl] * sx);
     }
@@ -506,10 +507,10 @@ __global__ __launch_bounds__(256) void xfold_kernel(XfoldP p) {
         double acc = 0.0;
         if (e < I * I) {
             const int i = e / I, j = e - i * I;
-            for (int cl = 0; cl < 16; ++cl) acc = fma((double)p.we[(size_t)(c0 + cl) * I + i] * (double)qv[cl], (double)p.we[(size_t)(c0 + cl) * I + j], acc);
+            for (int cl = 0; cl < 16; ++cl) acc = fma((double)wl[cl][i] * (double)qv[cl], (double)wl[cl][j], acc);
         } else {
             const int i = e - I * I;
-            for (int cl = 0; cl < 16; ++cl) acc = fma((double)p.we[(size_t)(c0 + cl) * I + i], (double)rv[cl] - (double)qv[cl] * (double)mu[cl], acc);
+            for (int cl = 0; cl < 16; ++cl) acc = fma((double)wl[cl][i], (double)rv[cl] - (double)qv[cl] * (double)mu[cl], acc);
         }
         ab[e] = (float)acc;
     }
@@ -521,46 +522,61 @@ __global__ __launch_bounds__(256) void xfold_kernel(XfoldP p) {
 struct XfixP {
     const float* z1; int ldz; pq_src in; pq_gsink dx; const float* ab; int nab; int M, I;
 };
+// The operand's affine is folded in once per workgroup:  A (a x + b) + b' = (A diag(a)) x + (A b + b'); a thread keeps the four rows
+// of that matrix its channel quad needs in registers for all its pixels.
 template <int KS>
 __global__ __launch_bounds__(256) void xfix_kernel(XfixP p) {
     constexpr int I = 4 * KS;
     constexpr int PY = 256 / KS;                                // pixels per block pass (KS quads x PY pixel lanes; 256 % KS threads idle)
     __shared__ float A[I * I + I];
     __shared__ float red[256 * 8];
-    __shared__ float xas[I], xbs[I];
     const int t = threadIdx.x;
     for (int e = t; e < I * I + I; e += 256) {
         float a = 0.f;
         for (int k = 0; k < p.nab; ++k) a += p.ab[(size_t)k * (I * I + I) + e];
         A[e] = a;
     }
-    if (t < I) { xas[t] = p.in.scale ? p.in.scale[t] : 1.f; xbs[t] = p.in.scale ? p.in.shift[t] : 0.f; }
+    __syncthreads();
     const int qx = t % KS, py = t / KS;
     const bool act_t = py < PY;
     const int c0 = 4 * qx;
+    float ar[4][I], br[4];
+    {
+        const bool aff = p.in.scale != nullptr;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            float bsum = A[I * I + c0 + ii];
+#pragma unroll
+            for (int j = 0; j < I; ++j) {
+                const float av = A[(c0 + ii) * I + j];
+                ar[ii][j] = aff ? av * p.in.scale[j] : av;
+                bsum = aff ? fmaf(av, p.in.shift[j], bsum) : bsum;
+            }
+            br[ii] = bsum;
+        }
+    }
     const SinkCoef4 sk = sink_coef4(p.dx, c0, I);
-    __syncthreads();
     float4 s1 = f4zero(), s2 = f4zero();
     const int rows_per = (p.M + gridDim.x - 1) / gridDim.x;
     const int m0 = blockIdx.x * rows_per, m1 = min(m0 + rows_per, p.M);
     if (act_t)
     for (int m = m0 + py; m < m1; m += PY) {
-        // x' of the whole pixel (I floats: the row of every thread that works on this pixel comes from the same cache lines)
-        const float* xr = p.in.x + (size_t)m * p.in.ld;
-        float4 dz = ldg4(p.z1 + (size_t)m * p.ldz + c0);
-        float acc[4] = {A[I * I + c0], A[I * I + c0 + 1], A[I * I + c0 + 2], A[I * I + c0 + 3]};
+        const float* xr = p.in.x + (size_t)m * p.in.ld;           // the KS threads of a pixel read the same cache lines
+        float4 xv[KS];
+#pragma unroll
+        for (int j4 = 0; j4 < KS; ++j4) xv[j4] = ldg4(xr + 4 * j4);
+        const float4 zz = ldg4(p.z1 + (size_t)m * p.ldz + c0);
+        const SinkOps so = sink_load4(p.dx, sk, (size_t)m, c0);
+        float acc[4] = {br[0], br[1], br[2], br[3]};
 #pragma unroll
         for (int j4 = 0; j4 < KS; ++j4) {
-            const float4 xv = ldg4(xr + 4 * j4);
-            const float xs[4] = {fmaf(xas[4 * j4], xv.x, xbs[4 * j4]), fmaf(xas[4 * j4 + 1], xv.y, xbs[4 * j4 + 1]),
-                                 fmaf(xas[4 * j4 + 2], xv.z, xbs[4 * j4 + 2]), fmaf(xas[4 * j4 + 3], xv.w, xbs[4 * j4 + 3])};
+            const float xs[4] = {xv[j4].x, xv[j4].y, xv[j4].z, xv[j4].w};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) acc[ii] = fmaf(A[(c0 + ii) * I + 4 * j4 + jj], xs[jj], acc[ii]);
+                for (int ii = 0; ii < 4; ++ii) acc[ii] = fmaf(ar[ii][4 * j4 + jj], xs[jj], acc[ii]);
         }
-        dz = f4add(dz, make_float4(acc[0], acc[1], acc[2], acc[3]));
-        sink_emit4(p.dx, sk, (size_t)m, c0, dz, s1, s2);
+        sink_store4(p.dx, sk, (size_t)m, c0, make_float4(zz.x + acc[0], zz.y + acc[1], zz.z + acc[2], zz.w + acc[3]), so, s1, s2);
     }
     if (p.dx.finalize && p.dx.mean && p.dx.partial) {          // uniform
         float* slot = red + t * 8;
