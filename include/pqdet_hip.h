@@ -310,7 +310,7 @@ int32_t pq_dw3x3_bwd_walk_blocks(int32_t B, int32_t IH, int32_t IW, int32_t C, i
  * mid.x is ignored.  in.act must be PQ_ACT_LINEAR (the expand layer of an inverted-residual block reads a linear bottleneck or a
  * materialised sum): the operand's affine is folded into the weights.  The call emits the depthwise output's own statistics like
  * pq_dw3x3_fwd (partial rows or stat_acc).
- * pq_xdw_fwd_blocks: partial-sum rows = walkers of the launch; 0 => shape outside the kernel's range (I in {16, 24, 32}; stride 2
+ * pq_xdw_fwd_blocks: partial-sum rows = walkers of the launch; 0 => shape outside the kernel's range (I in {16, 24}; stride 2
  * needs even plane sizes) -- use the unfused entries.  yexp != NULL: the raw expanded tensor is ALSO written (pitch ldy; for
  * a backward that reads it and for tests). */
 typedef struct pq_xdw_fwd_args {
@@ -333,7 +333,7 @@ int32_t pq_xdw_fwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t I, int32_t 
  * model/parser.py:404-405): per expanded channel c, sum y_c = we_c . s and sum y_c^2 = we_c^T G we_c with s = sum x', G = sum x' x'^T
  * over the M pixels -- one pass over the I-channel input (workgroup partials added into exact fixed-point accumulators in `scratch`:
  * order independent, run-to-run deterministic), then a finalize that writes mean / invstd / scale / shift and the running statistics
- * exactly like pq_bn_fwd_finalize(train).  I in {16, 24, 32}. */
+ * exactly like pq_bn_fwd_finalize(train).  I in {16, 24}. */
 typedef struct pq_xstat_fwd_args {
     pq_src in;           /* block input, M rows of I channels */
     const float* we;     /* [E][I] */

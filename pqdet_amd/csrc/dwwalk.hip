@@ -836,7 +836,7 @@ int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream) {
     if (a->part == 6) {
         const int n = a->C * 9;
         int rows = w.nblk;
-        if (rows > 64) {
+        if (rows > 32) {
             constexpr int NS = 16;
             hipLaunchKernelGGL(dww_slice_rows_kernel, dim3((n + 255) / 256, NS), dim3(256), 0, st, a->scratch, rows, n, NS);
             rows = NS;

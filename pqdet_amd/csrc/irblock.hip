@@ -513,7 +513,7 @@ static XdwPlan xdw_plan(int B, int IH, int IW, int E, int stride) {
 }
 
 static bool xdw_shape_ok(int I, int E, int stride, int IH, int IW) {
-    if (!(I == 16 || I == 24 || I == 32) || E < 4) return false;
+    if (!(I == 16 || I == 24) || E < 4) return false;       // (32 -> 192 on the 64 x 64 planes measured at break-even: not built)
     if (stride == 2) return (IH % 2 == 0) && (IW % 2 == 0);
     return stride == 1;
 }
@@ -540,7 +540,7 @@ extern "C" int pq_xdw_fwd(const pq_xdw_fwd_args* a, void* stream) {
         return PQ_EUNSUPPORTED;
     }
     if (!xdw_shape_ok(a->I, a->E, a->stride, a->IH, a->IW)) {
-        pq_set_error("pq_xdw_fwd: I must be 16 / 24 / 32 (stride 2: even plane sizes); ask pq_xdw_fwd_blocks first");
+        pq_set_error("pq_xdw_fwd: I must be 16 / 24 (stride 2: even plane sizes); ask pq_xdw_fwd_blocks first");
         return PQ_EUNSUPPORTED;
     }
     const XdwPlan w = xdw_plan(a->B, a->IH, a->IW, a->E, a->stride);
@@ -561,10 +561,8 @@ extern "C" int pq_xdw_fwd(const pq_xdw_fwd_args* a, void* stream) {
     switch (key) {
         case 116: hipLaunchKernelGGL((xdw_fwd_kernel<1, 4>), grid, blk, 0, st, p); break;
         case 124: hipLaunchKernelGGL((xdw_fwd_kernel<1, 6>), grid, blk, 0, st, p); break;
-        case 132: hipLaunchKernelGGL((xdw_fwd_kernel<1, 8>), grid, blk, 0, st, p); break;
         case 216: hipLaunchKernelGGL((xdw_fwd_kernel<2, 4>), grid, blk, 0, st, p); break;
-        case 224: hipLaunchKernelGGL((xdw_fwd_kernel<2, 6>), grid, blk, 0, st, p); break;
-        default: hipLaunchKernelGGL((xdw_fwd_kernel<2, 8>), grid, blk, 0, st, p); break;
+        default: hipLaunchKernelGGL((xdw_fwd_kernel<2, 6>), grid, blk, 0, st, p); break;
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -578,14 +576,14 @@ static void xstat_plan(int M, int I, int& rows, int& nwg) {
     nwg = (M + rows - 1) / rows;
 }
 extern "C" int64_t pq_xstat_fwd_scratch_bytes(int32_t M, int32_t I) {
-    if (M <= 0 || !(I == 16 || I == 24 || I == 32)) return 0;
+    if (M <= 0 || !(I == 16 || I == 24)) return 0;
     return (int64_t)XSLOTS * 2 * (I * I + I) * 2 * 8 + 64;      // [XSLOTS][2][N][2] int64 (plane 1 unused) + the `bad` word
 }
 extern "C" int pq_xstat_fwd(const pq_xstat_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->in.x && a->we && a->gamma && a->beta && a->mean && a->invstd && a->scale && a->shift && a->scratch, "null pointer");
     PQ_CHECK_ARG(a->M > 0 && a->E > 0 && a->in.ld >= a->I && (((uintptr_t)a->scratch) & 15) == 0, "bad shape / scratch alignment");
-    if (!(a->I == 16 || a->I == 24 || a->I == 32) || act_is_special(a->in.act) || a->in.qstate || a->in.stat.acc) {
-        pq_set_error("pq_xstat_fwd: I must be 16 / 24 / 32; logistic / tanh operands, QAT observers and in.stat are not supported");
+    if (!(a->I == 16 || a->I == 24) || act_is_special(a->in.act) || a->in.qstate || a->in.stat.acc) {
+        pq_set_error("pq_xstat_fwd: I must be 16 / 24; logistic / tanh operands, QAT observers and in.stat are not supported");
         return PQ_EUNSUPPORTED;
     }
     int rows, nwg;
@@ -597,8 +595,7 @@ extern "C" int pq_xstat_fwd(const pq_xstat_fwd_args* a, void* stream) {
     uint32_t* bad = reinterpret_cast<uint32_t*>(acc + (size_t)XSLOTS * 2 * n * 2);
     XgramP g{a->in, acc, bad, a->M, rows};
     if (a->I == 16) hipLaunchKernelGGL((xgram_kernel<16>), dim3(nwg), dim3(256), 0, st, g);
-    else if (a->I == 24) hipLaunchKernelGGL((xgram_kernel<24>), dim3(nwg), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((xgram_kernel<32>), dim3(nwg), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((xgram_kernel<24>), dim3(nwg), dim3(256), 0, st, g);
     XstatFinP f{acc, bad, a->moments, a->we, a->gamma, a->beta, a->running_mean, a->running_var, a->num_batches_tracked,
                 a->mean, a->invstd, a->scale, a->shift, a->I, a->E, (float)a->M, a->eps, a->momentum};
     hipLaunchKernelGGL(xstat_finalize_kernel, dim3(1), dim3(1024), 0, st, f);

@@ -49,18 +49,21 @@ struct XbwdP {
     int strips, segs, seg_rows, row_floats;
 };
 
-template <int S> struct XBG;
-template <> struct XBG<1> { static constexpr int TH = 4, DR = 6, DC = 18, DN = 4; };   // dy' ring: rows y0 - 1 .. y0 + 4, columns x0 - 1 .. x0 + 16
-template <> struct XBG<2> { static constexpr int TH = 8, DR = 5, DC = 9, DN = 4; };    // dy' ring (output plane): rows y0 / 2 .. + 4, columns x0 / 2 .. + 8
+// a step = TH input rows x 16 columns; dy' ring: stride 1: rows y0 - 1 .. y0 + TH, columns x0 - 1 .. x0 + 16; stride 2 (output plane):
+// rows y0 / 2 .. y0 / 2 + TH / 2, columns x0 / 2 .. x0 / 2 + 8.  DN new rows per step.  TH is chosen so that all of E fits the LDS.
+template <int S, int TH_> struct XBG;
+template <int TH_> struct XBG<1, TH_> { static constexpr int TH = TH_, DR = TH_ + 2, DC = 18, DN = TH_; };
+template <int TH_> struct XBG<2, TH_> { static constexpr int TH = TH_, DR = TH_ / 2 + 1, DC = 9, DN = TH_ / 2; };
 
 // S: stride; KS = I / 4; NQ = E / 4 (channel quads).  512 threads.  GE: also store g_e (tests).
 // Between the request of a step's global loads [A] and their use at the end of the step there is NO vector-memory instruction inside
 // a loop or a condition (the Z1 stores are straight-line code, the optional g_e store is a template flavour): the compiler can
 // then COUNT the outstanding loads (s_waitcnt vmcnt(N)) instead of draining them in front of the first loop -- with the Z1 store
 // inside a run-time loop it waited for the whole batch right after issuing it, every step.
-template <int S, int KS, int NQ, bool GE>
+template <int S, int KS, int NQ, int TH_, bool GE>
 __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
-    using G = XBG<S>;
+    using G = XBG<S, TH_>;
+    static_assert(G::DR <= 2 * G::DN, "the first step's ring is filled in two batches");
     constexpr int I = 4 * KS, E = 4 * NQ, TH = G::TH;
     constexpr int NPXS = TH * 16, NPT = TH;                     // owned pixels / 16-pixel tiles (= rows) of a step
     constexpr int NI = (I + 15) / 16, NCT = E / 16;             // 16-wide tiles of the input / expanded channels
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
                     float4 tt = f4zero();
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
-                        int slot = 4 * k + r + 2 - ky;
+                        int slot = G::DN * k + r + 2 - ky;
                         slot -= (slot / G::DR) * G::DR;
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
             } else {
                 for (int bq = pl; bq < NPXS / 4; bq += NPL) {       // 2 x 2 input pixels <-> one output neighbourhood
                     const int by = bq >> 3, bx = bq & 7;
-                    int sa = 4 * k + by, sb = sa + 1;
+                    int sa = G::DN * k + by, sb = sa + 1;
                     sa -= (sa / G::DR) * G::DR; sb -= (sb / G::DR) * G::DR;
                     const float4 da0 = ring[(sa * G::DC + bx) * NQ + qd], da1 = ring[(sa * G::DC + bx + 1) * NQ + qd];
                     const float4 db0 = ring[(sb * G::DC + bx) * NQ + qd], db1 = ring[(sb * G::DC + bx + 1) * NQ + qd];
@@ -343,7 +346,8 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
         if constexpr (!(XB_SKIP & 4))
 #pragma unroll
         for (int uj = 0; uj < (NUZ + 7) / 8; ++uj) {
-            const int u = min(w + 8 * uj, NUZ - 1);             // (NUZ is a multiple of 8 for every instantiation)
+            const bool uon = w + 8 * uj < NUZ;                  // uniform (NUZ < 8: the upper waves repeat the last unit and store nothing)
+            const int u = min(w + 8 * uj, NUZ - 1);
             const int pt = u / NI, it = u - pt * NI;
             const float* ap = wx + (g * KE) * WP + it * 16 + l15;
             const float* bp = yt + (pt * 16 + l15) * EP + g * KE;
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
             }
             const int r = pt, c = l15;                          // rows of D: input channels it * 16 + 4 g + j; column: pixel
             const int i0 = it * 16 + 4 * g;
-            if (i0 < I && y0 + r < yend && x0 + c < p.IW)
+            if (uon && i0 < I && y0 + r < yend && x0 + c < p.IW)
                 stg4(p.z1 + (img + (size_t)(y0 + r) * p.IW + x0 + c) * p.ldz + i0,
                      make_float4(z0[0] + z1v[0], z0[1] + z1v[1], z0[2] + z1v[2], z0[3] + z1v[3]));
         }
@@ -601,11 +605,13 @@ struct XbPlan { int strips, segs, seg_rows, nblk, th; size_t lds; };
 static bool xb_shape_ok(int I, int E, int stride, int IH, int IW) {
     if (stride == 2 && ((IH & 1) || (IW & 1))) return false;
     if (stride != 1 && stride != 2) return false;
+    // (32 -> 192 on the 64 x 64 planes was built with two-row steps and measured at break-even against the unfused kernels: 112 / 86 us
+    //  against 104 / 93 alone, 8.96 against 8.94 ms per step -- not shipped)
     return (I == 16 && E == 96 && stride == 2) || (I == 24 && E == 144);
 }
 static XbPlan xb_plan(int B, int IH, int IW, int I, int E, int stride) {
     XbPlan w{};
-    w.th = stride == 1 ? 4 : 8;
+    w.th = stride == 1 ? 4 : 8;                                // input rows per step: all E channels of a step must fit the LDS
     w.strips = (IW + 15) / 16;
     const int steps_total = (IH + w.th - 1) / w.th;
     const long base = (long)B * w.strips;
@@ -618,7 +624,7 @@ static XbPlan xb_plan(int B, int IH, int IW, int I, int E, int stride) {
     w.seg_rows = seg_steps * w.th;
     w.nblk = B * w.strips * w.segs;
     const int nq = E / 4, npxs = w.th * 16;
-    const int dr = stride == 1 ? 6 : 5, dc = stride == 1 ? 18 : 9;
+    const int dr = stride == 1 ? w.th + 2 : w.th / 2 + 1, dc = stride == 1 ? 18 : 9;
     w.lds = (size_t)dr * dc * nq * 16 + (size_t)npxs * (E + 4) * 4 + (size_t)2 * npxs * (I + 4) * 4 + (size_t)E * (I + 4) * 4 +
             (size_t)nq * 9 * 16 + (size_t)nq * 9 * 16 + (size_t)(I / 4) * 2 * 16;
     const size_t red = (size_t)512 * 44 * 4;
@@ -639,22 +645,22 @@ extern "C" int64_t pq_xdw_bwd_scratch_bytes(int32_t B, int32_t IH, int32_t IW, i
     return ((int64_t)(w.nblk + XB_SLICES) * xb_row_floats(I, E) + (int64_t)(E / 16) * (I * I + I) + (int64_t)B * IH * IW * I) * 4 + 256;
 }
 
-template <int S, int KS, int NQ, bool GE>
+template <int S, int KS, int NQ, int TH_, bool GE>
 static int xb_launch1(const XbwdP& p, const XbPlan& w, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)xdwb_kernel<S, KS, NQ, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)xdwb_kernel<S, KS, NQ, TH_, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             pq_set_error("pq_xdw_bwd: cannot raise the dynamic LDS limit");
             return PQ_ELAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((xdwb_kernel<S, KS, NQ, GE>), dim3(w.nblk), dim3(512), w.lds, st, p);
+    hipLaunchKernelGGL((xdwb_kernel<S, KS, NQ, TH_, GE>), dim3(w.nblk), dim3(512), w.lds, st, p);
     return PQ_OK;
 }
-template <int S, int KS, int NQ>
+template <int S, int KS, int NQ, int TH_>
 static int xb_launch(const XbwdP& p, const XbPlan& w, hipStream_t st) {
-    return p.gexp ? xb_launch1<S, KS, NQ, true>(p, w, st) : xb_launch1<S, KS, NQ, false>(p, w, st);
+    return p.gexp ? xb_launch1<S, KS, NQ, TH_, true>(p, w, st) : xb_launch1<S, KS, NQ, TH_, false>(p, w, st);
 }
 
 extern "C" int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream) {
@@ -693,9 +699,8 @@ extern "C" int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream) {
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW;
     p.strips = w.strips; p.segs = w.segs; p.seg_rows = w.seg_rows; p.row_floats = rowf;
     int rc;
-    if (a->I == 16) rc = xb_launch<2, 4, 24>(p, w, st);
-    else if (a->stride == 1) rc = xb_launch<1, 6, 36>(p, w, st);
-    else rc = xb_launch<2, 6, 36>(p, w, st);
+    if (a->I == 16) rc = xb_launch<2, 4, 24, 8>(p, w, st);
+    else rc = a->stride == 1 ? xb_launch<1, 6, 36, 4>(p, w, st) : xb_launch<2, 6, 36, 8>(p, w, st);
     if (rc != PQ_OK) return rc;
     const int ns = w.nblk < XB_SLICES ? w.nblk : XB_SLICES;
     hipLaunchKernelGGL(xslice_kernel, dim3((rowf + 255) / 256, ns), dim3(256), 0, st, (const float*)part, w.nblk, rowf, ns, slices);
@@ -705,8 +710,7 @@ extern "C" int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream) {
     XfixP x{z1, a->I, a->in, a->dx, ab, a->E / 16, M, a->I};
     const int nfix = pq_xdw_bwd_fix_blocks(M, a->I);
     if (a->I == 16) hipLaunchKernelGGL((xfix_kernel<4>), dim3(nfix), dim3(256), 0, st, x);
-    else if (a->I == 24) hipLaunchKernelGGL((xfix_kernel<6>), dim3(nfix), dim3(256), 0, st, x);
-    else hipLaunchKernelGGL((xfix_kernel<8>), dim3(nfix), dim3(256), 0, st, x);
+    else hipLaunchKernelGGL((xfix_kernel<6>), dim3(nfix), dim3(256), 0, st, x);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -714,7 +718,7 @@ extern "C" int32_t pq_xdw_bwd_fix_blocks(int32_t M, int32_t I) {
     if (M <= 0 || I <= 0) return 0;
     const int py = 256 / (I / 4);
     long want = ((long)M + py * 8 - 1) / (py * 8);             // >= 8 pixels per thread
-    if (want > 1024) want = 1024;
+    if (want > 512) want = 512;                                // two workgroups per CU are resident (register budget): ONE round
     if (want < 1) want = 1;
     return (int32_t)want;
 }

@@ -7,8 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from pqdet_amd import abi
-SHAPES = [(16, 256, 256, 16, 96, 2), (16, 128, 128, 24, 144, 1), (16, 128, 128, 24, 144, 2), (16, 64, 64, 32, 192, 1),
-          (16, 64, 64, 32, 192, 2)]
+SHAPES = [(16, 256, 256, 16, 96, 2), (16, 128, 128, 24, 144, 1), (16, 128, 128, 24, 144, 2)]
 l = abi.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream); dev = 'cuda'
 def vec(n): return torch.rand(n + 32, device=dev) + 0.5
 def timeit(fn, reps=20):

@@ -41,8 +41,8 @@ def _reference(x, xsc, xsh, xact, we, msc, msh, wd, stride):
     (1, 19, 21, 24, 144, 1, 0),       # odd plane, partial strips and steps
     (2, 16, 32, 16, 96, 2, 0),
     (1, 40, 72, 16, 96, 2, 0),        # more than one strip and segment at stride 2
-    (2, 24, 24, 32, 192, 1, 0),
-    (1, 20, 36, 32, 192, 2, 0),
+    (2, 24, 24, 16, 96, 1, 0),
+    (1, 20, 36, 24, 144, 2, 0),
     (2, 12, 20, 24, 40, 2, 0),        # E not a multiple of the 32-channel chunk
     (1, 9, 13, 16, 36, 1, 0),
     (1, 128, 128, 24, 144, 1, 0),     # benchmark-step plane sizes (one image)
@@ -85,7 +85,7 @@ def test_xdw_fwd_matches_the_unfused_chain(B, H, W, I, E, stride, xact):
     assert torch.equal(out2[..., :E], out[..., :E])
 
 
-@pytest.mark.parametrize('B,H,W,I,E,stride', [(2, 32, 32, 24, 144, 1), (2, 32, 32, 16, 96, 2), (2, 16, 48, 32, 192, 1)])
+@pytest.mark.parametrize('B,H,W,I,E,stride', [(2, 32, 32, 24, 144, 1), (2, 32, 32, 16, 96, 2), (2, 16, 48, 24, 96, 1)])
 def test_xdw_fwd_with_statistics_handed_over_by_the_statistics_only_expand_pass(B, H, W, I, E, stride):
     """pq_conv1x1_fwd(out = NULL, stat_acc) -> pq_xdw_fwd(mid.stat): train-mode BatchNorm of the expanded tensor without the tensor,
     without a finalize launch; running statistics updated by the consumer's first workgroup like nn.BatchNorm2d does."""
@@ -140,7 +140,7 @@ def test_xdw_fwd_with_statistics_handed_over_by_the_statistics_only_expand_pass(
     close(out, want, what='fused output with handed-over statistics')
 
 
-@pytest.mark.parametrize('M,I,E,xact,affine', [(3000, 16, 96, 0, True), (5000, 24, 144, 0, False), (4097, 32, 192, 2, True),
+@pytest.mark.parametrize('M,I,E,xact,affine', [(3000, 16, 96, 0, True), (5000, 24, 144, 0, False), (4097, 24, 192, 2, True),
                                                 (70, 24, 40, 0, True), (262144, 24, 144, 0, True)])
 def test_xstat_fwd_equals_batchnorm_statistics_of_the_expanded_tensor(M, I, E, xact, affine):
     """mean / biased variance of y = we x' from the moments of x' (sum x', sum x' x'^T) against nn.BatchNorm2d's statistics of y."""
@@ -266,7 +266,8 @@ def test_xdw_bwd_matches_autograd_through_expand_batchnorm_relu6_depthwise(B, H,
 
 def test_xdw_fwd_refuses_what_it_does_not_cover():
     l = abi.lib()
-    assert l.pq_xdw_fwd_blocks(2, 16, 16, 64, 384, 1) == 0            # contraction outside {16, 24, 32}
+    assert l.pq_xdw_fwd_blocks(2, 16, 16, 64, 384, 1) == 0            # contraction outside {16, 24}
+    assert l.pq_xdw_fwd_blocks(2, 16, 16, 32, 192, 1) == 0 and l.pq_xdw_bwd_blocks(2, 16, 16, 32, 192, 1) == 0
     assert l.pq_xdw_fwd_blocks(2, 15, 16, 16, 96, 2) == 0             # stride 2 on an odd plane
     x = torch.zeros(2 * 16 * 16 * 64, device=DEV)
     a = abi.XdwFwd()
