@@ -847,6 +847,12 @@ int pq_run_ops_timed(const pq_op* ops, int32_t n, void* stream, float* ms);
 /* same for the two-stream replay: every op is bracketed on the stream it is launched on, so the figures are the in-situ
  * durations (overlapping kernels share the chip), i.e. what a rocprofv3 kernel trace of the training step reports */
 int pq_run_ops2_timed(const pq_op* ops, int32_t n, void* stream, void* side_stream, float* ms);
+/* Test hook: while enabled, every kernel launch of the library notes "kernel expression | enclosing function" (the pretty name of a
+ * templated dispatcher carries its template arguments) in a set; pq_launch_log(enable) clears the set and switches the log,
+ * pq_launch_log_dump writes the entries, newline separated, and returns the bytes needed.  The suite uses it to prove that every
+ * kernel instantiation the plans of the BASELINE nets launch is also launched by a value test. */
+void pq_launch_log(int32_t enable);
+int64_t pq_launch_log_dump(char* buf, int64_t cap);
 /* index of the first failing op of the last pq_run_ops (or -1) and its message */
 int pq_last_failed_op(void);
 const char* pq_last_error(void);

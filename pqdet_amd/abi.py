@@ -387,6 +387,8 @@ SIGNATURES = {
     'pq_run_ops2_nojoin': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p]),
     'pq_run_ops_timed': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.POINTER(C.c_float)]),
     'pq_run_ops2_timed': (C.c_int, [C.POINTER(Op), i32, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    'pq_launch_log': (None, [i32]),
+    'pq_launch_log_dump': (i64, [C.c_char_p, i64]),
     'pq_last_failed_op': (C.c_int, []),
     'pq_last_error': (C.c_char_p, []),
     'pq_version': (C.c_char_p, []),

@@ -1,6 +1,7 @@
 // Error plumbing and the batched op executor of libpqdet_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -16,6 +17,34 @@ void pq_set_error(const char* fmt, ...) {
 extern "C" const char* pq_last_error(void) { return g_err; }
 extern "C" int pq_last_failed_op(void) { return g_failed_op; }
 extern "C" const char* pq_version(void) { return "pqdet_hip 0.1 (gfx950)"; }
+
+// ---- launch log (tests): the set of (kernel expression | enclosing function) strings launched since it was switched on
+#include <mutex>
+#include <set>
+#include <string>
+bool pq_launch_log_on = false;
+static std::mutex g_log_mu;
+static std::set<std::string> g_log;
+void pq_note_launch(const char* kernel, const char* where) {
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    g_log.insert(std::string(kernel) + " | " + where);
+}
+extern "C" void pq_launch_log(int32_t enable) {
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    g_log.clear();
+    pq_launch_log_on = enable != 0;
+}
+extern "C" int64_t pq_launch_log_dump(char* buf, int64_t cap) {
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    std::string all;
+    for (const auto& e : g_log) { all += e; all += '\n'; }
+    if (buf && cap > 0) {
+        const size_t n = all.size() < (size_t)cap - 1 ? all.size() : (size_t)cap - 1;
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)all.size() + 1;
+}
 
 static thread_local hipEvent_t g_stop_event = nullptr;
 hipEvent_t pq_take_stop_event() {

@@ -540,8 +540,20 @@ void pq_set_error(const char* fmt, ...);
 // (hipExtLaunchKernelGGL stopEvent) instead of recording it afterwards: a separate hipEventRecord is a barrier packet that
 // delays the next kernel of the same queue by 5-8 us.  pq_take_stop_event() returns that event once (nullptr otherwise).
 hipEvent_t pq_take_stop_event();
+// EVERY kernel launch of the library goes through PQ_LAUNCH / PQ_LAUNCH_BINDABLE: with the launch log on (pq_launch_log, tests only)
+// the kernel expression and the enclosing function (whose pretty name carries the template arguments of templated dispatchers) are
+// noted, so the suite can prove that every kernel instantiation a plan of the BASELINE nets launches is also launched by a value test
+// (tests/test_zz_instantiations_gpu.py).  Off: one predictable branch per launch.
+extern bool pq_launch_log_on;
+void pq_note_launch(const char* kernel, const char* where);
+#define PQ_LAUNCH(kernel, grid, block, shmem, st, ...)                                                       \
+    do {                                                                                                      \
+        if (pq_launch_log_on) pq_note_launch(#kernel, __PRETTY_FUNCTION__);                                   \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                      \
+    } while (0)
 #define PQ_LAUNCH_BINDABLE(kernel, grid, block, shmem, st, ...)                                              \
     do {                                                                                                      \
+        if (pq_launch_log_on) pq_note_launch(#kernel, __PRETTY_FUNCTION__);                                   \
         hipEvent_t stop_ = pq_take_stop_event();                                                              \
         if (stop_) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, nullptr, stop_, 0, __VA_ARGS__);     \
         else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                 \

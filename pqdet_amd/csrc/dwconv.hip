@@ -796,7 +796,7 @@ int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream) {
     size_t sh = (size_t)g.cx * g.py * 8 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (a->stride == 1) { pq_set_error("pq_dw3x3_fwd: internal -- stride 1 runs on the walking kernel"); return PQ_EINVAL; }
-    hipLaunchKernelGGL((dw_fwd_kernel<2, 2, false>), grid, blk, sh, st, p);
+    PQ_LAUNCH((dw_fwd_kernel<2, 2, false>), grid, blk, sh, st, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -818,12 +818,12 @@ extern "C" int pq_dw3x3_dgrad(const pq_dw3x3_dgrad_args* a, void* stream) {
         q.IH = a->OH; q.IW = a->OW; q.OH = a->IH; q.OW = a->IW;   // "input" = dy plane, "output" = dx plane
         // the column-walk kernel only pays on the largest planes (256x256: 0.167 -> 0.144 ms); below that the per-row kernel
         // has more parallelism and is as fast
-        if ((long)a->IH * a->IW >= 256L * 256L) hipLaunchKernelGGL((dw_dgrad_s1_walk_kernel<4, 4>), grid, blk, sh, st, q);
-        else hipLaunchKernelGGL((dw_fwd_kernel<1, 4, true>), grid, blk, sh, st, q);
+        if ((long)a->IH * a->IW >= 256L * 256L) PQ_LAUNCH((dw_dgrad_s1_walk_kernel<4, 4>), grid, blk, sh, st, q);
+        else PQ_LAUNCH((dw_fwd_kernel<1, 4, true>), grid, blk, sh, st, q);
     } else if ((a->IH & 1) == 0 && (a->IW & 1) == 0) {
-        hipLaunchKernelGGL(dw_dgrad_s2_quad_kernel, grid, blk, sh, st, p);
+        PQ_LAUNCH(dw_dgrad_s2_quad_kernel, grid, blk, sh, st, p);
     } else {
-        hipLaunchKernelGGL((dw_dgrad_kernel<2>), grid, blk, sh, st, p);
+        PQ_LAUNCH((dw_dgrad_kernel<2>), grid, blk, sh, st, p);
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -850,11 +850,11 @@ extern "C" int pq_dw3x3_wgrad(const pq_dw3x3_wgrad_args* a, void* stream) {
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     size_t sh = (size_t)g.cx * g.py * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (a->stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<1, 4>), grid, blk, sh, st, p);
-    else hipLaunchKernelGGL((dw_wgrad_kernel<2, 2>), grid, blk, sh, st, p);
+    if (a->stride == 1) PQ_LAUNCH((dw_wgrad_kernel<1, 4>), grid, blk, sh, st, p);
+    else PQ_LAUNCH((dw_wgrad_kernel<2, 2>), grid, blk, sh, st, p);
     PQ_CHECK_LAUNCH();
     const int n = a->C * 9;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
+    PQ_LAUNCH(partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -878,11 +878,11 @@ extern "C" int pq_stem3x3_fwd(const pq_stem3x3_fwd_args* a, void* stream) {
     dim3 grid(g.gx, g.gy), blk(g.cx, g.py);
     const int npatch_f = 3 * (3 * a->stride + 3) * (31 * a->stride + 3);
     if (npatch_f > 8 * g.cx * g.py) {           // patch too large for the LDS-tiled kernel: per-pixel global loads
-        hipLaunchKernelGGL((stem_fwd_kernel<3>), grid, blk, (size_t)g.cx * g.py * 8 * sizeof(float), (hipStream_t)stream, p);
+        PQ_LAUNCH((stem_fwd_kernel<3>), grid, blk, (size_t)g.cx * g.py * 8 * sizeof(float), (hipStream_t)stream, p);
     } else {
         const int PH = 3 * a->stride + 3, PW = 31 * a->stride + 3;
         const size_t sh = ((size_t)256 * 8 + (size_t)3 * PH * (PW + 1) + 16) * sizeof(float);
-        hipLaunchKernelGGL((stem_fwd_tiled_kernel<3>), grid, blk, sh, (hipStream_t)stream, p);
+        PQ_LAUNCH((stem_fwd_tiled_kernel<3>), grid, blk, sh, (hipStream_t)stream, p);
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -910,15 +910,15 @@ extern "C" int pq_stem3x3_wgrad(const pq_stem3x3_wgrad_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int npatch_w = 3 * (3 * a->stride + 3) * (31 * a->stride + 3);
     if (npatch_w > 8 * g.cx * g.py) {
-        hipLaunchKernelGGL((stem_wgrad_kernel<3>), grid, blk, (size_t)g.cx * g.py * 4 * sizeof(float), st, p);
+        PQ_LAUNCH((stem_wgrad_kernel<3>), grid, blk, (size_t)g.cx * g.py * 4 * sizeof(float), st, p);
     } else {
         const int PH = 3 * a->stride + 3, PW = 31 * a->stride + 3;
         const size_t sh = ((size_t)256 * 4 + (size_t)3 * PH * (PW + 1) + 16) * sizeof(float);
-        hipLaunchKernelGGL((stem_wgrad_tiled_kernel<3>), grid, blk, sh, st, p);
+        PQ_LAUNCH((stem_wgrad_tiled_kernel<3>), grid, blk, sh, st, p);
     }
     PQ_CHECK_LAUNCH();
     const int n = a->O * a->CI * 9;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
+    PQ_LAUNCH(partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, g.gx, n, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -217,7 +217,7 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     fwd_tiles(a->OH, a->OW, a->stride, p.tilesH, p.tilesW);
     dim3 grid(a->B * p.tilesH * p.tilesW, (p.C4 + CBQ - 1) / CBQ), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((dwt_fwd_kernel<2>), grid, blk, 0, st, p);          // (stride 1 never gets here: walking kernel)
+    PQ_LAUNCH((dwt_fwd_kernel<2>), grid, blk, 0, st, p);          // (stride 1 never gets here: walking kernel)
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -838,10 +838,10 @@ int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream) {
         int rows = w.nblk;
         if (rows > 32) {
             constexpr int NS = 16;
-            hipLaunchKernelGGL(dww_slice_rows_kernel, dim3((n + 255) / 256, NS), dim3(256), 0, st, a->scratch, rows, n, NS);
+            PQ_LAUNCH(dww_slice_rows_kernel, dim3((n + 255) / 256, NS), dim3(256), 0, st, a->scratch, rows, n, NS);
             rows = NS;
         }
-        hipLaunchKernelGGL(dww_partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, rows, n, a->dw);
+        PQ_LAUNCH(dww_partial_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, rows, n, a->dw);
         return PQ_OK;
     }
     DwWP p{};
@@ -874,6 +874,6 @@ int dw_fwd_walk_launch(const pq_dw3x3_fwd_args* a, void* stream) {
     p.strips = w.strips; p.segs = w.segs; p.seg_rows = w.seg_rows;
     p.minmax = (a->partial && a->minmax) ? 1 : 0;
     p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
-    hipLaunchKernelGGL(dw_fwd_walk_s1_kernel, dim3(w.chunks, w.nblk), dim3(256), 0, (hipStream_t)stream, p);     // (see dw_walk_launch)
+    PQ_LAUNCH(dw_fwd_walk_s1_kernel, dim3(w.chunks, w.nblk), dim3(256), 0, (hipStream_t)stream, p);     // (see dw_walk_launch)
     return PQ_OK;
 }

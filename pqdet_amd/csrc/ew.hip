@@ -545,7 +545,7 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
     const bool mmode = a->train && a->planes == 4 && a->qstate != nullptr;
     PQ_CHECK_ARG(a->planes == 0 || a->planes == 2 || a->planes == 4, "planes must be 2 or 4");
     PQ_CHECK_ARG(!mmode || a->mm, "the folded observer needs its 3-word scratch");
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, (a->train && !mmode) ? bn_row_groups(a->nblk, a->scratch && a->tickets) : 1),
+    PQ_LAUNCH(bn_fwd_finalize_kernel, dim3((a->C + BNF_CH - 1) / BNF_CH, (a->train && !mmode) ? bn_row_groups(a->nblk, a->scratch && a->tickets) : 1),
                        dim3(BNF_CH * BNF_RL), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -553,7 +553,7 @@ extern "C" int pq_bn_fwd_finalize(const pq_bn_fwd_finalize_args* a, void* stream
 
 extern "C" int pq_bn_eval_batch(const pq_bn_eval_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->items && a->n_items > 0, "bad args");
-    hipLaunchKernelGGL(bn_eval_batch_kernel, dim3(a->n_items), dim3(256), 0, (hipStream_t)stream, a->items);
+    PQ_LAUNCH(bn_eval_batch_kernel, dim3(a->n_items), dim3(256), 0, (hipStream_t)stream, a->items);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -566,7 +566,7 @@ __global__ void bn_stat_selftest_kernel(const float* v, int n, int64_t* acc, uin
 extern "C" int pq_bn_stat_selftest(const float* values, int32_t n, int32_t slots, int32_t ldp, int64_t* acc, uint32_t* bad, void* stream) {
     PQ_CHECK_ARG(values && acc && bad && n > 0 && slots >= 1 && slots <= 4 && ldp >= 1, "bad arguments");
     if (!stat_adds_ok(n, slots)) { pq_set_error("pq_bn_stat_selftest: more than %d partials per accumulator slot", PQ_STAT_MAX_ADDS); return PQ_EUNSUPPORTED; }
-    hipLaunchKernelGGL(bn_stat_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, values, n, acc, bad, slots, ldp);
+    PQ_LAUNCH(bn_stat_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, values, n, acc, bad, slots, ldp);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -590,7 +590,7 @@ extern "C" int pq_copy_fwd(const pq_copy_args* a, void* stream) {
     if (act_is_special(a->a.act) || (a->b.x && act_is_special(a->b.act))) { pq_set_error("pq_copy_fwd: logistic/tanh operands are not supported yet"); return PQ_EUNSUPPORTED; }
     CopyP p{*a, (a->C + 3) / 4, ((a->C & 3) || (a->coff & 3)) ? 1 : 0};   // odd widths / offsets: masked scalar stores
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
-    hipLaunchKernelGGL(copy_fwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), 0, (hipStream_t)stream, p);
+    PQ_LAUNCH(copy_fwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), 0, (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -611,7 +611,7 @@ extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     if (act_is_special(a->dx.act)) { pq_set_error("pq_route_bwd: logistic/tanh sinks are not supported yet"); return PQ_EUNSUPPORTED; }
     RouteP p{*a, (a->C + 3) / 4, ((a->C & 3) || (a->coff & 3)) ? 1 : 0};
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
-    hipLaunchKernelGGL(route_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float),
+    PQ_LAUNCH(route_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float),
                        (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -623,14 +623,14 @@ extern "C" int pq_pool_reduce(const pq_pool_reduce_args* a, void* stream) {
     if (act_is_special(a->a.act)) { pq_set_error("pq_pool_reduce: logistic/tanh operands are not supported"); return PQ_EUNSUPPORTED; }
     PoolP p{*a, a->C / 4};
     const int cx = pick_cx(p.C4), py = 256 / cx, gy = (p.C4 + cx - 1) / cx;
-    hipLaunchKernelGGL(pool_reduce_kernel, dim3(a->B, gy), dim3(cx, py), (size_t)cx * py * 4 * sizeof(float), (hipStream_t)stream, p);
+    PQ_LAUNCH(pool_reduce_kernel, dim3(a->B, gy), dim3(cx, py), (size_t)cx * py * 4 * sizeof(float), (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
 
 extern "C" int pq_transpose_batch(const pq_transpose_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->items && a->n_items > 0 && a->total_tiles > 0, "bad args");
-    hipLaunchKernelGGL(transpose_batch_kernel, dim3(a->total_tiles), dim3(256), 0, (hipStream_t)stream, a->items, a->n_items);
+    PQ_LAUNCH(transpose_batch_kernel, dim3(a->total_tiles), dim3(256), 0, (hipStream_t)stream, a->items, a->n_items);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -643,7 +643,7 @@ extern "C" int pq_adam_step(const pq_adam_args* a, void* stream) {
     int64_t nb = (a->n / 4 + 255) / 256;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_LAUNCH(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -653,7 +653,7 @@ extern "C" int pq_fill(float* dst, float value, int64_t n, void* stream) {
     if (n == 0) return PQ_OK;
     int64_t nb = (n + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dst, value, n);
+    PQ_LAUNCH(fill_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dst, value, n);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -662,7 +662,7 @@ extern "C" int pq_sign_l1(float* grad, const float* weight, int64_t n, float rat
     PQ_CHECK_ARG(grad && weight && n > 0, "bad args");
     int64_t nb = (n + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(sign_l1_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, grad, weight, n, ratio);
+    PQ_LAUNCH(sign_l1_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, grad, weight, n, ratio);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

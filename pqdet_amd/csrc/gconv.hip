@@ -668,7 +668,7 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
     const dim3 grid(a->B * p.tilesH * p.tilesW, a->C / a->gw);
     if (a->stride == 1) {
         (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((gconv_kernel<1, 1>), grid, dim3(256), lds, (hipStream_t)stream, p);
+        PQ_LAUNCH((gconv_kernel<1, 1>), grid, dim3(256), lds, (hipStream_t)stream, p);
     } else {
         // big stride-2 layers: persistent workgroups (one resident wave of them), at least 8 tiles each
         const int G = a->C / a->gw, ntiles = a->B * p.tilesH * p.tilesW;
@@ -677,10 +677,10 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
         const int per = (ntiles + nb - 1) / nb;
         if (nb < ntiles && per >= 8) {
             (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((gconv_kernel<1, 2, true>), dim3((ntiles + per - 1) / per, G), dim3(256), lds, (hipStream_t)stream, p);
+            PQ_LAUNCH((gconv_kernel<1, 2, true>), dim3((ntiles + per - 1) / per, G), dim3(256), lds, (hipStream_t)stream, p);
         } else {
             (void)hipFuncSetAttribute((const void*)gconv_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((gconv_kernel<1, 2>), grid, dim3(256), lds, (hipStream_t)stream, p);
+            PQ_LAUNCH((gconv_kernel<1, 2>), grid, dim3(256), lds, (hipStream_t)stream, p);
         }
     }
     PQ_CHECK_LAUNCH();
@@ -700,7 +700,7 @@ extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) 
         const int pitch = a->gw / 4 + 1;
         const size_t lds2 = ((size_t)9 * 17 * pitch * 4 + 32 * (9 * a->gw + 4) + 2 * 4 * 32) * sizeof(float);
         (void)hipFuncSetAttribute((const void*)gconv_dgrad_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(gconv_dgrad_s2_kernel, dim3(a->B * q.tilesH * q.tilesW, a->C / a->gw), dim3(256), lds2, (hipStream_t)stream, q);
+        PQ_LAUNCH(gconv_dgrad_s2_kernel, dim3(a->B * q.tilesH * q.tilesW, a->C / a->gw), dim3(256), lds2, (hipStream_t)stream, q);
         PQ_CHECK_LAUNCH();
         return PQ_OK;
     }
@@ -713,7 +713,7 @@ extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) 
     p.tilesH = (a->IH + GTH - 1) / GTH; p.tilesW = (a->IW + GTW - 1) / GTW;
     const size_t lds = gc_lds_bytes(a->gw, 1);
     (void)hipFuncSetAttribute((const void*)gconv_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((gconv_kernel<2, 1>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
+    PQ_LAUNCH((gconv_kernel<2, 1>), dim3(a->B * p.tilesH * p.tilesW, a->C / a->gw), dim3(256), lds, (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -753,7 +753,7 @@ extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) 
 #define PQ_GCW_LAUNCH(NCH_, S_)                                                                                              \
     do {                                                                                                                     \
         (void)hipFuncSetAttribute((const void*)gconv_wgrad_kernel<NCH_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((gconv_wgrad_kernel<NCH_, S_>), wgrid, dim3(256), lds, st, p);                                     \
+        PQ_LAUNCH((gconv_wgrad_kernel<NCH_, S_>), wgrid, dim3(256), lds, st, p);                                     \
     } while (0)
     if (S == 1) {
         if (nch <= 3) PQ_GCW_LAUNCH(3, 1); else if (nch <= 5) PQ_GCW_LAUNCH(5, 1); else if (nch <= 7) PQ_GCW_LAUNCH(7, 1); else PQ_GCW_LAUNCH(9, 1);
@@ -763,7 +763,7 @@ extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) 
 #undef PQ_GCW_LAUNCH
     PQ_CHECK_LAUNCH();
     const int total = G * a->gw * 9 * a->gw;
-    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, G, p.nsplit, a->gw, a->dw);
+    PQ_LAUNCH(gconv_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, G, p.nsplit, a->gw, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -907,9 +907,9 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
             if (plan) return PQ_OK;
             PQ_CHECK_LAUNCH();
             const int n0 = a->O * a->I;
-            if (s2 <= 64) hipLaunchKernelGGL(slab_reduce_cols_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
+            if (s2 <= 64) PQ_LAUNCH(slab_reduce_cols_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
                                              stride2, s2, a->dw, n0, (float*)nullptr, 0);
-            else hipLaunchKernelGGL(slab_reduce_kernel, dim3((n0 + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, stride2, s2,
+            else PQ_LAUNCH(slab_reduce_kernel, dim3((n0 + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, stride2, s2,
                                     a->dw, n0, (float*)nullptr, 0);
             PQ_CHECK_LAUNCH();
             return PQ_OK;
@@ -932,17 +932,17 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
     }
     p.slab_stride = (size_t)a->O * a->I + a->O;
     dim3 grid(tiles, splits), blk(256);
-    hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
+    PQ_LAUNCH((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
     const int n0 = a->O * a->I, n1 = a->dbias ? a->O : 0;
     if (splits <= 64) {
-        hipLaunchKernelGGL(slab_reduce_cols_kernel, dim3((n0 + n1 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
+        PQ_LAUNCH(slab_reduce_cols_kernel, dim3((n0 + n1 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
                            p.slab_stride, splits, a->dw, n0, a->dbias, n1);
         PQ_CHECK_LAUNCH();
         return PQ_OK;
     }
     const int rb = (n0 + n1 + 31) / 32;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(32, 32), 0, st, (const float*)a->scratch, p.slab_stride, splits,
+    PQ_LAUNCH(slab_reduce_kernel, dim3(rb), dim3(32, 32), 0, st, (const float*)a->scratch, p.slab_stride, splits,
                        a->dw, n0, a->dbias, n1);
     PQ_CHECK_LAUNCH();
     return PQ_OK;

@@ -663,7 +663,7 @@ static int g2_launch_tn_nw(const G2TP& p, const G2WPlan& pl, hipStream_t st, pq_
     constexpr size_t bytes = (size_t)S * ((TWO ? 2 : 1) * 32 * 128 + 32 * 128) * 4;        // 144 / 96 KiB (>= the 64 KiB epilogue tile)
     static bool ok = g2_raise_lds((const void*)gemm2_tn_kernel<TWO, XA, S, NW>, bytes);
     if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
-    hipLaunchKernelGGL((gemm2_tn_kernel<TWO, XA, S, NW>), dim3(pl.tiles, pl.splits), dim3(NW * 64), bytes, st, p);
+    PQ_LAUNCH((gemm2_tn_kernel<TWO, XA, S, NW>), dim3(pl.tiles, pl.splits), dim3(NW * 64), bytes, st, p);
     return PQ_OK;
 }
 template <bool TWO, bool XA>

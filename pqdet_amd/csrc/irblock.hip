@@ -559,10 +559,10 @@ extern "C" int pq_xdw_fwd(const pq_xdw_fwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int key = a->stride * 100 + a->I;
     switch (key) {
-        case 116: hipLaunchKernelGGL((xdw_fwd_kernel<1, 4>), grid, blk, 0, st, p); break;
-        case 124: hipLaunchKernelGGL((xdw_fwd_kernel<1, 6>), grid, blk, 0, st, p); break;
-        case 216: hipLaunchKernelGGL((xdw_fwd_kernel<2, 4>), grid, blk, 0, st, p); break;
-        default: hipLaunchKernelGGL((xdw_fwd_kernel<2, 6>), grid, blk, 0, st, p); break;
+        case 116: PQ_LAUNCH((xdw_fwd_kernel<1, 4>), grid, blk, 0, st, p); break;
+        case 124: PQ_LAUNCH((xdw_fwd_kernel<1, 6>), grid, blk, 0, st, p); break;
+        case 216: PQ_LAUNCH((xdw_fwd_kernel<2, 4>), grid, blk, 0, st, p); break;
+        default: PQ_LAUNCH((xdw_fwd_kernel<2, 6>), grid, blk, 0, st, p); break;
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -594,11 +594,11 @@ extern "C" int pq_xstat_fwd(const pq_xstat_fwd_args* a, void* stream) {
     int64_t* acc = reinterpret_cast<int64_t*>(a->scratch);
     uint32_t* bad = reinterpret_cast<uint32_t*>(acc + (size_t)XSLOTS * 2 * n * 2);
     XgramP g{a->in, acc, bad, a->M, rows};
-    if (a->I == 16) hipLaunchKernelGGL((xgram_kernel<16>), dim3(nwg), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((xgram_kernel<24>), dim3(nwg), dim3(256), 0, st, g);
+    if (a->I == 16) PQ_LAUNCH((xgram_kernel<16>), dim3(nwg), dim3(256), 0, st, g);
+    else PQ_LAUNCH((xgram_kernel<24>), dim3(nwg), dim3(256), 0, st, g);
     XstatFinP f{acc, bad, a->moments, a->we, a->gamma, a->beta, a->running_mean, a->running_var, a->num_batches_tracked,
                 a->mean, a->invstd, a->scale, a->shift, a->I, a->E, (float)a->M, a->eps, a->momentum};
-    hipLaunchKernelGGL(xstat_finalize_kernel, dim3(1), dim3(1024), 0, st, f);
+    PQ_LAUNCH(xstat_finalize_kernel, dim3(1), dim3(1024), 0, st, f);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

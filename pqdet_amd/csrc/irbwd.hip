@@ -655,7 +655,7 @@ static int xb_launch1(const XbwdP& p, const XbPlan& w, hipStream_t st) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((xdwb_kernel<S, KS, NQ, TH_, GE>), dim3(w.nblk), dim3(512), w.lds, st, p);
+    PQ_LAUNCH((xdwb_kernel<S, KS, NQ, TH_, GE>), dim3(w.nblk), dim3(512), w.lds, st, p);
     return PQ_OK;
 }
 template <int S, int KS, int NQ, int TH_>
@@ -703,14 +703,14 @@ extern "C" int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream) {
     else rc = a->stride == 1 ? xb_launch<1, 6, 36, 4>(p, w, st) : xb_launch<2, 6, 36, 8>(p, w, st);
     if (rc != PQ_OK) return rc;
     const int ns = w.nblk < XB_SLICES ? w.nblk : XB_SLICES;
-    hipLaunchKernelGGL(xslice_kernel, dim3((rowf + 255) / 256, ns), dim3(256), 0, st, (const float*)part, w.nblk, rowf, ns, slices);
+    PQ_LAUNCH(xslice_kernel, dim3((rowf + 255) / 256, ns), dim3(256), 0, st, (const float*)part, w.nblk, rowf, ns, slices);
     XfoldP f{slices, ns, rowf, a->moments, a->we, a->mid_gamma, a->mid_invstd, a->mid_mean, a->dwe, a->dwd, a->dgamma, a->dbeta, ab,
              a->I, a->E, (float)((double)a->B * a->IH * a->IW)};
-    hipLaunchKernelGGL(xfold_kernel, dim3(a->E / 16), dim3(256), 0, st, f);
+    PQ_LAUNCH(xfold_kernel, dim3(a->E / 16), dim3(256), 0, st, f);
     XfixP x{z1, a->I, a->in, a->dx, ab, a->E / 16, M, a->I};
     const int nfix = pq_xdw_bwd_fix_blocks(M, a->I);
-    if (a->I == 16) hipLaunchKernelGGL((xfix_kernel<4>), dim3(nfix), dim3(256), 0, st, x);
-    else hipLaunchKernelGGL((xfix_kernel<6>), dim3(nfix), dim3(256), 0, st, x);
+    if (a->I == 16) PQ_LAUNCH((xfix_kernel<4>), dim3(nfix), dim3(256), 0, st, x);
+    else PQ_LAUNCH((xfix_kernel<6>), dim3(nfix), dim3(256), 0, st, x);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

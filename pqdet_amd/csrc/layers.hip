@@ -127,26 +127,26 @@ extern "C" int pq_layer_fwd(const pq_layer_fwd_args* a, void* stream) {
                 PQ_CHECK_ARG(a->k >= 1 && a->stride >= 1 && a->pad >= 0 && 2 * a->pad <= a->k, "bad window");
                 PQ_CHECK_ARG(a->OH == (a->IH + 2 * a->pad - a->k) / a->stride + 1 && a->OW == (a->IW + 2 * a->pad - a->k) / a->stride + 1, "output size");
             }
-            hipLaunchKernelGGL(pool2d_kernel, dim3(blocks_for((long)a->B * a->OH * a->OW * a->C)), dim3(256), 0, st, *a);
+            PQ_LAUNCH(pool2d_kernel, dim3(blocks_for((long)a->B * a->OH * a->OW * a->C)), dim3(256), 0, st, *a);
             break;
         case PQ_LAYER_IM2COL:
             PQ_CHECK_ARG(a->in.x && a->B > 0 && a->C > 0 && a->k >= 1 && a->stride >= 1 && a->pad >= 0, "bad shape");
             PQ_CHECK_ARG(a->ldo >= a->C * a->k * a->k && (a->ldo & 3) == 0, "patch pitch must cover C*k*k and be a multiple of 4");
             PQ_CHECK_ARG(a->OH == (a->IH + 2 * a->pad - a->k) / a->stride + 1 && a->OW == (a->IW + 2 * a->pad - a->k) / a->stride + 1, "output size");
             PQ_CHECK_ARG(!a->nchw || (a->in.scale == nullptr && a->in.act == PQ_ACT_LINEAR), "the NCHW network input carries no transform");
-            hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for((long)a->B * a->OH * a->OW * a->ldo)), dim3(256), 0, st, *a);
+            PQ_LAUNCH(im2col_kernel, dim3(blocks_for((long)a->B * a->OH * a->OW * a->ldo)), dim3(256), 0, st, *a);
             break;
         case PQ_LAYER_FC:
             PQ_CHECK_ARG(a->in.x && a->w && a->B == 1 && a->C > 0 && a->IH > 0 && a->IW > 0 && a->O > 0, "bad shape (nn.Linear on x.view(input): one image)");
-            hipLaunchKernelGGL(fc_kernel, dim3((a->O + 3) / 4), dim3(256), 0, st, *a);
+            PQ_LAUNCH(fc_kernel, dim3((a->O + 3) / 4), dim3(256), 0, st, *a);
             break;
         case PQ_LAYER_ACT:
             PQ_CHECK_ARG(a->in.x && a->B > 0 && a->IH > 0 && a->IW > 0 && a->C > 0 && a->ldo >= a->C, "bad shape");
-            hipLaunchKernelGGL(act_kernel, dim3(blocks_for((long)a->B * a->IH * a->IW * a->ldo)), dim3(256), 0, st, *a);
+            PQ_LAUNCH(act_kernel, dim3(blocks_for((long)a->B * a->IH * a->IW * a->ldo)), dim3(256), 0, st, *a);
             break;
         case PQ_LAYER_PADROWS:
             PQ_CHECK_ARG(a->w && a->O > 0 && a->k > 0 && a->ldo >= a->k, "bad shape");
-            hipLaunchKernelGGL(padrows_kernel, dim3(blocks_for((long)a->O * a->ldo)), dim3(256), 0, st, *a);
+            PQ_LAUNCH(padrows_kernel, dim3(blocks_for((long)a->O * a->ldo)), dim3(256), 0, st, *a);
             break;
         default:
             pq_set_error("pq_layer_fwd: unknown kind %d", a->kind);

@@ -648,7 +648,7 @@ extern "C" int pq_recover(const pq_recover_args* a, void* stream) {
     PQ_CHECK_ARG(a->B > 0 && a->N > 0 && a->C > 0, "bad shape");
     long rows = (long)a->B * a->N;
     long nb = (rows + 255) / 256; if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(recover_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_LAUNCH(recover_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -658,9 +658,9 @@ extern "C" int pq_create_label(const pq_create_label_args* a, void* stream) {
     PQ_CHECK_ARG(a->B > 0 && a->G > 0 && a->C > 0 && a->gt_per_grid == 3 && a->cap > 0, "bad shape (3 anchors per scale)");
     for (int s = 0; s < 3; ++s) PQ_CHECK_ARG(a->label[s] && a->boxes[s] && a->H[s] > 0 && a->W[s] > 0 && a->stride[s] > 0, "bad scale description");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(label_init_kernel, dim3(1024), dim3(256), 0, st, *a);
+    PQ_LAUNCH(label_init_kernel, dim3(1024), dim3(256), 0, st, *a);
     PQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(label_assign_kernel, dim3(a->B), dim3(64), 0, st, *a);
+    PQ_LAUNCH(label_assign_kernel, dim3(a->B), dim3(64), 0, st, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -750,15 +750,15 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
     long nb = (S + 255) / 256; if (nb > 2048) nb = 2048;
     if (S == E) {
         long nbe = (E + 255) / 256; if (nbe > 2048) nbe = 2048;
-        hipLaunchKernelGGL(nms_mark_kernel, dim3((unsigned)nbe), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, keys0, vals0, meta, maxb, a->N);
+        PQ_LAUNCH(nms_mark_kernel, dim3((unsigned)nbe), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, keys0, vals0, meta, maxb, a->N);
         PQ_CHECK_LAUNCH();
     } else {
         unsigned* bcnt = (unsigned*)(base + L.bcnt);
         const int G = (int)((E + NMS_CHUNK - 1) / NMS_CHUNK);
-        hipLaunchKernelGGL(nms_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, keys0, vals0, (int)S);
-        hipLaunchKernelGGL(nms_count_kernel, dim3(G), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, bcnt, meta, maxb, a->N);
-        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, bcnt, G, meta, (unsigned)S);
-        hipLaunchKernelGGL(nms_write_kernel, dim3(G), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, (const unsigned*)bcnt, keys0, vals0,
+        PQ_LAUNCH(nms_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, keys0, vals0, (int)S);
+        PQ_LAUNCH(nms_count_kernel, dim3(G), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, bcnt, meta, maxb, a->N);
+        PQ_LAUNCH(nms_scan_kernel, dim3(1), dim3(64), 0, st, bcnt, G, meta, (unsigned)S);
+        PQ_LAUNCH(nms_write_kernel, dim3(G), dim3(256), 0, st, a->bboxes, Ntot, a->C, a->score_thr, (const unsigned*)bcnt, keys0, vals0,
                            (unsigned)S);
         PQ_CHECK_LAUNCH();
     }
@@ -772,7 +772,7 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
         static bool raised2 = hipFuncSetAttribute((const void*)nms_sort_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   NMS_SMALL_MAX * 8) == hipSuccess;
         if (!raised2) { pq_set_error("pq_nms: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
-        hipLaunchKernelGGL(nms_sort_seg_kernel, dim3(B), dim3(1024), (size_t)NMS_SMALL_MAX * 8, st, (const float*)keys0, (const unsigned*)vals0, (int)S,
+        PQ_LAUNCH(nms_sort_seg_kernel, dim3(B), dim3(1024), (size_t)NMS_SMALL_MAX * 8, st, (const float*)keys0, (const unsigned*)vals0, (int)S,
                            a->C, NC, a->N, meta, keys1, vals1, rk1, offs);
         PQ_CHECK_LAUNCH();
     } else if (small) {
@@ -781,7 +781,7 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
         static bool raised = hipFuncSetAttribute((const void*)nms_sort_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  NMS_SMALL_MAX * 8) == hipSuccess;
         if (!raised) { pq_set_error("pq_nms: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
-        hipLaunchKernelGGL(nms_sort_small_kernel, dim3(1), dim3(1024), (size_t)P * 8, st, (const float*)keys0, (const unsigned*)vals0, (int)S, P,
+        PQ_LAUNCH(nms_sort_small_kernel, dim3(1), dim3(1024), (size_t)P * 8, st, (const float*)keys0, (const unsigned*)vals0, (int)S, P,
                            S == E ? 0 : 1, a->C, NC, a->N, (const NmsMeta*)meta, keys1, vals1, rk1, offs);
         PQ_CHECK_LAUNCH();
     } else {
@@ -790,9 +790,9 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
     if (e != hipSuccess || need > tmp_avail) { pq_set_error("pq_nms: sort scratch (%zu needed, %zu available)", need, tmp_avail); return PQ_EINVAL; }
     e = rocprim::radix_sort_pairs_desc(tmp, need, keys0, keys1, vals0, vals1, (size_t)S, 0, 32, st);
     if (e != hipSuccess) { pq_set_error("pq_nms: radix sort failed: %s", hipGetErrorString(e)); return PQ_ELAUNCH; }
-    hipLaunchKernelGGL(nms_classkey_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const unsigned*)vals1, S, a->C, (const NmsMeta*)meta, ck0, rk0, hist, a->N);
+    PQ_LAUNCH(nms_classkey_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const unsigned*)vals1, S, a->C, (const NmsMeta*)meta, ck0, rk0, hist, a->N);
     PQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)hist, NC, offs);
+    PQ_LAUNCH(nms_offsets_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)hist, NC, offs);
     PQ_CHECK_LAUNCH();
     size_t need2 = 0;
     e = rocprim::radix_sort_pairs(nullptr, need2, ck0, ck1, rk0, rk1, (size_t)S, 0, 16, st);
@@ -804,15 +804,15 @@ extern "C" int pq_nms(const pq_nms_args* a, void* stream) {
                    (unsigned long long)(L.mask_bytes / 8)};
     static const char* greedy_env = getenv("PQ_NMS_GREEDY");          // "1": always the chunk-walking kernel (A/B timing, tests)
     if (greedy_env && greedy_env[0] == '1') mp.budget_words = 0;
-    hipLaunchKernelGGL(nms_mask_plan_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)offs, NC, mp, meta);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(8192), dim3(64), 0, st, a->bboxes, a->C, NC, (const unsigned*)vals1, (const unsigned*)rk1,
+    PQ_LAUNCH(nms_mask_plan_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)offs, NC, mp, meta);
+    PQ_LAUNCH(nms_mask_kernel, dim3(8192), dim3(64), 0, st, a->bboxes, a->C, NC, (const unsigned*)vals1, (const unsigned*)rk1,
                        (const unsigned*)offs, (const unsigned*)maxb, a->iou_thr, mp, (const NmsMeta*)meta);
-    hipLaunchKernelGGL(nms_mask_scan_kernel, dim3(NC), dim3(256), 0, st, (const unsigned*)rk1, (const unsigned*)offs, mp, (const NmsMeta*)meta, keep);
+    PQ_LAUNCH(nms_mask_scan_kernel, dim3(NC), dim3(256), 0, st, (const unsigned*)rk1, (const unsigned*)offs, mp, (const NmsMeta*)meta, keep);
     PQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(NC), dim3(256), 0, st, a->bboxes, a->C, (const unsigned*)vals1, (const unsigned*)rk1,
+    PQ_LAUNCH(nms_greedy_kernel, dim3(NC), dim3(256), 0, st, a->bboxes, a->C, (const unsigned*)vals1, (const unsigned*)rk1,
                        (const unsigned*)offs, (const unsigned*)maxb, a->iou_thr, kept, keep, (const NmsMeta*)meta);
     PQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(1024), 0, st, a->bboxes, a->C, (const float*)keys1, (const unsigned*)vals1,
+    PQ_LAUNCH(nms_compact_kernel, dim3(1), dim3(1024), 0, st, a->bboxes, a->C, (const float*)keys1, (const unsigned*)vals1,
                        (const unsigned*)keep, meta, a->dets, a->cap, a->count, a->img, a->N);
     PQ_CHECK_LAUNCH();
     return PQ_OK;

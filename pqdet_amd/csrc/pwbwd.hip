@@ -472,7 +472,7 @@ static int pw_launch(const PwP& p, const PwPlan& pl, hipStream_t st) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((pw_bwd_kernel<TD, NZ, NX, OCC>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, p);
+    PQ_LAUNCH((pw_bwd_kernel<TD, NZ, NX, OCC>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, p);
     return PQ_OK;
 }
 
@@ -533,7 +533,7 @@ extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
     if (rc != PQ_OK) return rc;
     PQ_CHECK_LAUNCH();
     const int n = a->O * a->I;
-    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, n, pl.grid, a->dw);
+    PQ_LAUNCH(pw_slab_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, n, pl.grid, a->dw);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

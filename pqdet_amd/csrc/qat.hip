@@ -247,14 +247,14 @@ using namespace pq;
 
 extern "C" int pq_qat_weight_prep(const pq_qat_weight_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->items && a->n_items > 0, "bad args");
-    hipLaunchKernelGGL(qat_wprep_kernel, dim3(a->n_items), dim3(1024), 0, (hipStream_t)stream, a->items, a->observe, a->quantise, a->avg_const);
+    PQ_LAUNCH(qat_wprep_kernel, dim3(a->n_items), dim3(1024), 0, (hipStream_t)stream, a->items, a->observe, a->quantise, a->avg_const);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
 
 extern "C" int pq_qat_weight_grad(const pq_qat_weight_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->items && a->n_items > 0, "bad args");
-    hipLaunchKernelGGL(qat_wfix_kernel, dim3(a->n_items), dim3(1024), 0, (hipStream_t)stream, a->items, a->quantise);
+    PQ_LAUNCH(qat_wfix_kernel, dim3(a->n_items), dim3(1024), 0, (hipStream_t)stream, a->items, a->quantise);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -275,15 +275,15 @@ extern "C" int pq_qact_fwd(const pq_qact_args* a, void* stream) {
     const bool vec = !a->flat && (a->C & 3) == 0 && (a->in.ld & 3) == 0 && (!a->out || (a->ldo & 3) == 0) &&
                      (((uintptr_t)a->in.x | (uintptr_t)a->out) & 15) == 0;
     if (a->observe) {
-        if (vec) hipLaunchKernelGGL(qact_minmax4_kernel, dim3(nb), dim3(256), 0, st, *a, a->partial);
-        else hipLaunchKernelGGL(qact_minmax_kernel, dim3(nb), dim3(256), 0, st, *a, a->partial);
+        if (vec) PQ_LAUNCH(qact_minmax4_kernel, dim3(nb), dim3(256), 0, st, *a, a->partial);
+        else PQ_LAUNCH(qact_minmax_kernel, dim3(nb), dim3(256), 0, st, *a, a->partial);
         PQ_CHECK_LAUNCH();
-        hipLaunchKernelGGL(qact_observe_kernel, dim3(1), dim3(256), 0, st, (const float*)a->partial, nb, a->state, a->avg_const);
+        PQ_LAUNCH(qact_observe_kernel, dim3(1), dim3(256), 0, st, (const float*)a->partial, nb, a->state, a->avg_const);
         PQ_CHECK_LAUNCH();
     }
     if (!a->out) return PQ_OK;                 // observer only: the consumers fake-quantise while loading (pq_src.qstate)
-    if (vec) hipLaunchKernelGGL(qact_apply4_kernel, dim3(nb), dim3(256), 0, st, *a);
-    else hipLaunchKernelGGL(qact_apply_kernel, dim3(nb), dim3(256), 0, st, *a);
+    if (vec) PQ_LAUNCH(qact_apply4_kernel, dim3(nb), dim3(256), 0, st, *a);
+    else PQ_LAUNCH(qact_apply_kernel, dim3(nb), dim3(256), 0, st, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -294,7 +294,7 @@ extern "C" int pq_qact_bwd(const pq_qact_bwd_args* a, void* stream) {
                  "channels / pitches must be multiples of 4");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_qact_bwd: logistic/tanh are not part of the QAT model"); return PQ_EUNSUPPORTED; }
     EwGeom g = ew_geom((long)a->rows, a->C);
-    hipLaunchKernelGGL(qact_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float), (hipStream_t)stream, *a);
+    PQ_LAUNCH(qact_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float), (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

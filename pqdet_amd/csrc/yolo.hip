@@ -493,7 +493,7 @@ static bool loss_launch_staged(const pq_yolo_loss_args* a, int nblk, hipStream_t
         if (hipFuncSetAttribute((const void*)yolo_loss_staged_kernel<GRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return false;
         raised = 96 * 1024;
     }
-    hipLaunchKernelGGL((yolo_loss_staged_kernel<GRAD>), dim3(nblk, a->B), dim3(256), bytes, st, *a, span_cap, lab_cap);
+    PQ_LAUNCH((yolo_loss_staged_kernel<GRAD>), dim3(nblk, a->B), dim3(256), bytes, st, *a, span_cap, lab_cap);
     return true;
 }
 
@@ -503,11 +503,11 @@ extern "C" int pq_yolo_loss_fwd(const pq_yolo_loss_args* a, void* stream) {
     const int nblk = pq_yolo_loss_blocks(a->H, a->W, a->A);
     hipStream_t st = (hipStream_t)stream;
     if (a->phase != 2) {
-        if (!loss_launch_staged<false>(a, nblk, st)) hipLaunchKernelGGL((yolo_loss_kernel<false>), dim3(nblk, a->B), dim3(256), 0, st, *a);
+        if (!loss_launch_staged<false>(a, nblk, st)) PQ_LAUNCH((yolo_loss_kernel<false>), dim3(nblk, a->B), dim3(256), 0, st, *a);
         PQ_CHECK_LAUNCH();
     }
     if (a->phase == 1) return PQ_OK;
-    hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)a->partial, a->B, nblk, a->losses, a->nan_flag,
+    PQ_LAUNCH(yolo_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)a->partial, a->B, nblk, a->losses, a->nan_flag,
                        a->totals, a->head_slot, a->n_heads);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
@@ -540,7 +540,7 @@ extern "C" int pq_yolo_loss_bwd(const pq_yolo_loss_args* a, void* stream) {
             m.a0 = *hd[0]; m.a1 = *hd[1]; m.a2 = *hd[nh - 1];
             m.blk1 = blk[0]; m.blk2 = blk[0] + blk[1];
             const int total = blk[0] + blk[1] + (nh == 3 ? blk[2] : 0);
-            hipLaunchKernelGGL(yolo_loss_bwd_multi_kernel, dim3(total, a->B), dim3(256), bytes, (hipStream_t)stream, m);
+            PQ_LAUNCH(yolo_loss_bwd_multi_kernel, dim3(total, a->B), dim3(256), bytes, (hipStream_t)stream, m);
             PQ_CHECK_LAUNCH();
             return PQ_OK;
         }
@@ -553,7 +553,7 @@ extern "C" int pq_yolo_loss_bwd(const pq_yolo_loss_args* a, void* stream) {
     }
     const int nblk = pq_yolo_loss_blocks(a->H, a->W, a->A);
     if (!loss_launch_staged<true>(a, nblk, (hipStream_t)stream))
-        hipLaunchKernelGGL((yolo_loss_kernel<true>), dim3(nblk, a->B), dim3(256), 0, (hipStream_t)stream, *a);
+        PQ_LAUNCH((yolo_loss_kernel<true>), dim3(nblk, a->B), dim3(256), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -564,7 +564,7 @@ extern "C" int pq_decode(const pq_decode_args* a, void* stream) {
     PQ_CHECK_ARG(a->row0 >= 0 && a->row0 + a->H * a->W * a->A <= a->rows_total, "rows out of range");
     long total = (long)a->B * a->H * a->W * a->A * (5 + a->C);
     long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_LAUNCH(decode_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -574,7 +574,7 @@ extern "C" int pq_decode_bwd(const pq_decode_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->A > 0 && a->C > 0, "bad shape");
     long total = (long)a->B * a->H * a->W * a->A * (5 + a->C);
     long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(decode_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    PQ_LAUNCH(decode_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }
@@ -582,7 +582,7 @@ extern "C" int pq_decode_bwd(const pq_decode_bwd_args* a, void* stream) {
 extern "C" int pq_iou_pairs(const float* b1, const float* b2, float* out, int32_t n, int32_t kind, void* stream) {
     PQ_CHECK_ARG(b1 && b2 && out && n > 0, "bad arguments");
     PQ_CHECK_ARG(kind >= PQ_BOX_GIOU && kind <= PQ_BOX_IOU, "kind must be giou/diou/ciou/iou");
-    hipLaunchKernelGGL(iou_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, b1, b2, out, n, kind);
+    PQ_LAUNCH(iou_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, b1, b2, out, n, kind);
     PQ_CHECK_LAUNCH();
     return PQ_OK;
 }

@@ -64,3 +64,32 @@ def golden_r3():
 def r3_names():
     with open(os.path.join(GOLDEN_DIR, 'g_r3_names.json')) as f:
         return json.load(f)
+
+
+# ---- launch log: which kernel instantiations do the KERNEL-LEVEL value tests launch?  (tests/test_zz_instantiations_gpu.py compares
+# that set with what the plans of the BASELINE nets launch.)  Recording is on only while a test of one of these modules runs.
+KERNEL_TEST_MODULES = {'test_kernels_gpu', 'test_irblock_gpu', 'test_gemm_variants_gpu', 'test_bn_handover_gpu', 'test_qat_gpu'}
+LAUNCHES_COVERED = set()
+
+
+def dump_launch_log():
+    import ctypes as C
+    from pqdet_amd import abi
+    l = abi.lib()
+    need = l.pq_launch_log_dump(None, 0)
+    buf = C.create_string_buffer(int(need) + 16)
+    l.pq_launch_log_dump(buf, need + 16)
+    return {e for e in buf.value.decode().split('\n') if e}
+
+
+@pytest.fixture(autouse=True)
+def _record_kernel_test_launches(request):
+    mod = request.module.__name__.split('.')[-1]
+    if mod not in KERNEL_TEST_MODULES or request.node.get_closest_marker('gpu') is None:
+        yield
+        return
+    from pqdet_amd import abi
+    abi.lib().pq_launch_log(1)
+    yield
+    LAUNCHES_COVERED.update(dump_launch_log())
+    abi.lib().pq_launch_log(0)

@@ -323,6 +323,9 @@ def test_backward_handover_equals_backward_finalize_launches(B, H, W, scope, mon
     from test_model_gpu import _targets
     from seedfill import seeded_images
     runs = {}
+    # (the fused inverted-residual kernels take no part in the hand-over: this test is about the producer / consumer roles of the
+    # unfused kernels; fused plans are checked against the CPU oracle by the full-size tests)
+    monkeypatch.setenv('PQ_IRFUSE', '0')
     for mode in ('1', '0', '1'):
         monkeypatch.setenv('PQ_BN_BWD_ATOMIC', scope if mode == '1' else '0')
         net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))

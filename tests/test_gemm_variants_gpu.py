@@ -59,6 +59,12 @@ FWD = [
     (65536, 24, 144, 0, True, False, True, (1, 128, 160, 1, 1, 1, 0)),
     (65536, 32, 192, 0, False, False, True, (1, 128, 192, 1, 0, 1, 0)),
     (65536, 32, 192, 0, True, False, True, (1, 128, 192, 1, 1, 1, 0)),
+    # ... and their plain-store flavours (inference plans: no statistics): found by tests/test_zz_instantiations_gpu.py
+    (65536, 24, 144, 0, False, False, False, (1, 128, 160, 1, 0, 0, 0)),
+    (65536, 24, 144, 0, True, False, False, (1, 128, 160, 1, 1, 0, 0)),
+    (65536, 32, 192, 0, False, False, False, (1, 128, 192, 1, 0, 0, 0)),
+    (65536, 32, 192, 0, True, False, False, (1, 128, 192, 1, 1, 0, 0)),
+    (65536, 32, 16, 2, True, False, False, (1, 128, 32, 1, 1, 0, 0)),
 ]
 # ---- strided (RegNet projection shortcuts): B, IH, IW, I, O, expected forward instantiation
 FWD_STRIDED = [

@@ -617,7 +617,10 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
 # ----------------------------------------------------------------------------------------------- grouped 3x3
 @pytest.mark.parametrize('B,H,W,Cc,gw,stride', [(2, 9, 13, 48, 24, 1), (2, 10, 14, 48, 24, 2), (1, 16, 32, 96, 24, 2),
                                                 (1, 7, 7, 80, 16, 1), (2, 12, 12, 96, 16, 2), (1, 17, 20, 32, 32, 1),
-                                                (1, 8, 8, 24, 12, 1), (1, 9, 9, 528, 24, 1), (2, 9, 11, 176, 16, 2)])
+                                                (1, 8, 8, 24, 12, 1), (1, 9, 9, 528, 24, 1), (2, 9, 11, 176, 16, 2),
+                                                # a big stride-2 layer: persistent workgroups in the forward (RegNetX stage 1 at the
+                                                # benchmark shape selects that flavour: tests/test_zz_instantiations_gpu.py)
+                                                (8, 256, 256, 48, 24, 2)])
 def test_gconv3x3_fwd_bwd(B, H, W, Cc, gw, stride):
     g = torch.Generator().manual_seed(B * H * W + Cc + gw)
     l = abi.lib()
@@ -688,7 +691,9 @@ def test_gconv3x3_fwd_bwd(B, H, W, Cc, gw, stride):
     wg.B, wg.IH, wg.IW, wg.OH, wg.OW, wg.C, wg.gw, wg.stride = B, H, W, OH, OW, Cc, gw, stride
     abi.check(l.pq_gconv3x3_wgrad(C.byref(wg), stream()))
     torch.cuda.synchronize()
-    close(dw, wr.grad, rt=1e-3, at=1e-3, what='gconv wgrad')
+    # (a weight gradient is a sum over every output pixel: the absolute floor grows with the plane -- 1e-7 x the sum of |terms| -- and
+    # the fp32 CPU reference carries the same error)
+    close(dw, wr.grad, rt=1e-3, at=max(1e-3, 1e-7 * B * OH * OW), what='gconv wgrad')
 
 
 @pytest.mark.parametrize('B,H,W,I,O,two', [(2, 10, 14, 32, 48, False), (2, 10, 14, 32, 48, True)])
