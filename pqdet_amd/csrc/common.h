@@ -565,6 +565,30 @@ void pq_note_launch(const char* kernel, const char* where);
             return PQ_EINVAL;                           \
         }                                               \
     } while (0)
+// A sink that carries statistics accumulators (pq_gsink.stat_acc): what every entry point that HONOURS them checks -- nblk = the
+// row blocks (workgroups) that will add into them.  Entry points whose kernels cannot honour them return PQ_EUNSUPPORTED through
+// PQ_SINK_ACC_UNSUPPORTED instead of silently writing `partial` rows (a reader with dy_stat would derive p / q / r from zeros).
+inline const char* sink_acc_check(const pq_gsink& s, int C, long nblk) {
+    if (!s.stat_acc) return nullptr;
+    if (!s.stat_bad) return "dx.stat_acc needs stat_bad";
+    if (!(s.finalize && s.mean && s.partial)) return "dx.stat_acc needs a finalising sink with statistics (mean and partial set)";
+    if (s.ldp < C) return "dx.stat_acc: statistics pitch smaller than the channel count";
+    if (s.stat_slots > 4) return "dx.stat_acc: at most 4 accumulator slots";
+    if (!pq::stat_adds_ok(nblk, s.stat_slots)) return "dx.stat_acc: more than 4096 row blocks per accumulator slot";
+    return nullptr;
+}
+#define PQ_SINK_ACC_CHECK(sink, C, nblk)                                    \
+    do {                                                                    \
+        const char* m_ = sink_acc_check(sink, C, nblk);                     \
+        if (m_) { pq_set_error("%s: %s", __func__, m_); return PQ_EINVAL; } \
+    } while (0)
+#define PQ_SINK_ACC_UNSUPPORTED(sink)                                                                              \
+    do {                                                                                                            \
+        if ((sink).stat_acc) {                                                                                      \
+            pq_set_error("%s: this entry does not add into dx.stat_acc (ask pq_bn_bstat_ok, role 0)", __func__);    \
+            return PQ_EUNSUPPORTED;                                                                                 \
+        }                                                                                                           \
+    } while (0)
 #define PQ_CHECK_LAUNCH()                                                   \
     do {                                                                    \
         hipError_t e_ = hipGetLastError();                                  \

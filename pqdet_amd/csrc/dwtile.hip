@@ -222,7 +222,8 @@ extern "C" int pq_dw3x3_fwd(const pq_dw3x3_fwd_args* a, void* stream) {
     return PQ_OK;
 }
 
-// pq_bn_stat_ok for PQ_OP_DW_FWD: producer and consumer roles both need the LDS-tiled kernel (planes up to 64 x 64)
+// pq_bn_stat_ok for PQ_OP_DW_FWD, both roles: every stride-1 plane (the walking kernel takes them all) and the stride-2 planes
+// the LDS-tiled kernel takes (outputs up to 64 x 64); the streaming stride-2 forward of the big planes has neither role
 int dw_fwd_stat_ok(const pq_dw3x3_fwd_args* a, int role) {
     (void)role;
     return a && !a->minmax && !a->in.qstate && (dw_fwd_use_walk(a->stride) || dw_fwd_use_tiled(a->OH, a->OW, a->stride));
@@ -251,6 +252,9 @@ extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
             PQ_CHECK_ARG(a->stride == 1 || ((a->IH & 1) == 0 && (a->IW & 1) == 0), "stride-2 backward needs even input sizes");
             PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->in.ld & 3) == 0 && (a->dx.ldg & 3) == 0 && (!a->dy.y || (a->dy.ldy & 3) == 0), "pitches must be multiples of 4");
             if (act_is_special(a->dx.act) || act_is_special(a->in.act)) { pq_set_error("pq_dw3x3_bwd: logistic/tanh are not supported"); return PQ_EUNSUPPORTED; }
+            const int nwalk = pq_dw3x3_bwd_walk_blocks(a->B, a->IH, a->IW, a->C, a->stride);
+            PQ_SINK_ACC_CHECK(a->dx, a->C, nwalk);
+            PQ_CHECK_ARG(nwalk <= 65535, "more than 65535 walkers (grid.y): split the batch");
         }
         const int rc = dw_walk_launch(a, stream);
         if (rc != PQ_OK) return rc;

@@ -874,6 +874,7 @@ int dw_fwd_walk_launch(const pq_dw3x3_fwd_args* a, void* stream) {
     p.strips = w.strips; p.segs = w.segs; p.seg_rows = w.seg_rows;
     p.minmax = (a->partial && a->minmax) ? 1 : 0;
     p.stat_acc = a->stat_acc; p.stat_bad = a->stat_bad; p.stat_slots = a->stat_slots > 0 ? a->stat_slots : 1;
+    if (w.nblk > 65535) { pq_set_error("pq_dw3x3_fwd: more than 65535 walkers (grid.y): split the batch"); return PQ_EUNSUPPORTED; }
     PQ_LAUNCH(dw_fwd_walk_s1_kernel, dim3(w.chunks, w.nblk), dim3(256), 0, (hipStream_t)stream, p);     // (see dw_walk_launch)
     return PQ_OK;
 }

@@ -611,6 +611,8 @@ extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     if (act_is_special(a->dx.act)) { pq_set_error("pq_route_bwd: logistic/tanh sinks are not supported yet"); return PQ_EUNSUPPORTED; }
     RouteP p{*a, (a->C + 3) / 4, ((a->C & 3) || (a->coff & 3)) ? 1 : 0};
     EwGeom g = ew_geom((long)a->B * a->H * a->W, a->C);
+    PQ_SINK_ACC_CHECK(a->dx, a->C, g.gx);
+    if (a->dx2.g) PQ_SINK_ACC_CHECK(a->dx2, a->C, g.gx);
     PQ_LAUNCH(route_bwd_kernel, dim3(g.gx, g.gy), dim3(g.cx, g.py), (size_t)g.cx * g.py * 8 * sizeof(float),
                        (hipStream_t)stream, p);
     PQ_CHECK_LAUNCH();

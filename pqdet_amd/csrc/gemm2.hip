@@ -72,7 +72,7 @@ struct G2P {
 // behind the ring -- nothing rides in the ring for them.   EMODE 0: store(+bias); 1: + statistics;
 // AMODE 4: as 2, but (c0, c1, c3) = p, q, r of the BatchNorm backward DERIVED in the prologue from the sink kernel's accumulators
 // (pq_bn_bstat: no finalize launch in between) into a [4][Kp] LDS table behind the ring together with c2 = mu.
-// 2: gradient sink (16-byte rows only: the host checks alignment).   K % 32 == 0, or K % 32 == 16 (RegNetX widths 48 / 80 /
+// 2: gradient sink (native-layout dword accesses, gemm_epi.h; the host still requires 16-byte aligned rows for the DMA operands).   K % 32 == 0, or K % 32 == 16 (RegNetX widths 48 / 80 /
 // 176 / 240 / 528): the last k-tile is then half valid -- its upper four chunks of B come from g2_zero, those of A and of the
 // coefficient vectors repeat the lower four (finite values times zero), so the loop itself is unchanged.
 template <int BM, int BN, int AMODE, int EMODE, int S>
@@ -549,6 +549,8 @@ static int g2_launch_nt(const G2P& p, hipStream_t st, pq_gemm_plan* plan) {
     const size_t ring = ring0 + (AMODE == 3 ? (size_t)2 * ((p.K + 31) / 32 * 32) * 4 : (AMODE == 4 ? (size_t)4 * ((p.K + 31) / 32 * 32) * 4 : 0));
     const size_t bytes = ring > epi ? ring : epi;
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+    // (BINDABLE: the fork event of a side-stream op behind this call is bound to THIS dispatch -- valid only while the op launches
+    // nothing after it: pq_conv1x1_fwd / _dgrad are single-kernel ops; a trailing kernel added to them must take the event instead)
     PQ_LAUNCH_BINDABLE((gemm2_nt_kernel<BM, BN, AMODE, EMODE, S>), grid, dim3(256), bytes, st, p);
     return PQ_OK;
 }
@@ -564,7 +566,9 @@ static int g2_pick_bn(int M, int N, int bm) {
 template <int AMODE, int EMODE>
 static int g2_dispatch_nt(const G2P& p, int bm, hipStream_t st, pq_gemm_plan* plan) {
     const int bn = g2_pick_bn(p.M, p.N, bm);
-    // ring depth by LDS budget: two workgroups per CU (<= 80 KB each)
+    // ring depth by LDS budget: two workgroups per CU (<= 80 KB each) -- except AMODE 4 (coefficients derived from accumulators, behind
+    // PQ_BN_BWD_ATOMIC=all): its 128 x 64 x 3 ring takes 120 KB + up to 20 KB of table, i.e. ONE workgroup per CU, part of why that
+    // scope measured slower (profiles/r4_bn_bwd_handover_scope.txt)
     if constexpr (EMODE == 2) {
         // gradient sink: tiles of at most two 32 x 32 blocks per wave (the sink's operands of a whole tile are prefetched into
         // registers; a 128 x 128 sink tile would need 288 of them: one wave per SIMD)

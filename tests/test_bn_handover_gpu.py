@@ -498,3 +498,28 @@ def test_stat_accumulator_image_at_the_limits(case):
         a = abi.Conv1x1Fwd(abi.Src(x.data_ptr(), None, None, I, 0), w.data_ptr(), None, y.data_ptr(), None, M, I, O, O, 16, 1, 0, 0, 0, 0, 0,
                            acc.data_ptr(), bad.data_ptr(), 1)
         assert l.pq_conv1x1_fwd(C.byref(a), K.stream()) != 0 and b'row blocks per accumulator slot' in l.pq_last_error()
+
+
+def test_sink_accumulators_are_validated_or_refused():
+    """pq_gsink.stat_acc: entries that honour it check the record (stat_bad, finalising sink with statistics, pitch, slots, adds per
+    slot); entries that do not add into it refuse the call instead of silently writing `partial` rows."""
+    l = abi.lib()
+    buf = torch.zeros(4096, device=DEV)
+    p = buf.data_ptr()
+
+    def sink(stat_bad=True, finalize=1, slots=1, ldp=64):
+        return abi.GSink(p, p, None, None, p, p, p, 32, 32, 0, 0, finalize, ldp, None, p, p if stat_bad else None, slots, 0)
+    gs = abi.GSrc(p, p, p, p, p, p, 32, 32)
+    # honouring entries: a malformed record is an argument error
+    for sk in (sink(stat_bad=False), sink(finalize=0), sink(slots=5), sink(ldp=16)):
+        r = abi.RouteBwd(p, sk, 1, 4, 4, 32, 32, 0, 1)
+        assert l.pq_route_bwd(C.byref(r), K.stream()) == -1 and b"stat_acc" in l.pq_last_error()
+        f5 = abi.DwBwd(gs, abi.Src(p, None, None, 32, 0), p, sk, None, p, 1, 8, 8, 8, 8, 32, 1, 5)
+        assert l.pq_dw3x3_bwd(C.byref(f5), K.stream()) == -1 and b"stat_acc" in l.pq_last_error()
+    # entries that cannot add into accumulators
+    d = abi.DwDgrad(gs, p, sink(), 1, 8, 8, 8, 8, 32, 1)
+    assert l.pq_dw3x3_dgrad(C.byref(d), K.stream()) == -3 and b"stat_acc" in l.pq_last_error()
+    gd = abi.GconvDgrad(gs, p, sink(), 1, 8, 8, 8, 8, 32, 16, 1)
+    assert l.pq_gconv3x3_dgrad(C.byref(gd), K.stream()) == -3 and b"stat_acc" in l.pq_last_error()
+    qb = abi.QactBwd(p, sink(), p, 16, 32, 32, 1)
+    assert l.pq_qact_bwd(C.byref(qb), K.stream()) == -3 and b"stat_acc" in l.pq_last_error()

@@ -38,3 +38,20 @@ def test_register_budgets_leave_the_occupancy_the_launch_bounds_promise():
             continue
         assert k.get('vgpr_count', 0) <= 512, k
         assert k.get("group_segment_fixed_size", 0) <= 160 * 1024, k
+
+
+def test_sgpr_spill_budget():
+    """Spilled SGPRs live in VGPR lanes (v_writelane / v_readlane: no memory, EXEC-independent), so they are legal -- but every spill
+    is VALU work inside the kernel.  Budget: what the library has today (172 in the 128 x 128 gradient-sink tile of the register-staged
+    GEMM family, two launches per step) as the ceiling for the old kernels, and a tight one for the kernels written since."""
+    worst = {}
+    for k in _kernels():
+        name = k['name']
+        if not name.startswith('_ZN2pq'):
+            continue
+        n = k.get('sgpr_spill_count', 0)
+        assert n <= 176, '%s spills %d SGPRs (budget 176)' % (name, n)
+        if any(t in name for t in ('xdw_fwd_kernel', 'xdwb_kernel', 'xgram_kernel', 'xstat_finalize', 'xfold_kernel', 'xfix_kernel', 'xslice')):
+            assert n <= 40, '%s spills %d SGPRs (budget 40 for the fused inverted-residual kernels)' % (name, n)
+        worst[name] = n
+    assert worst

@@ -27,12 +27,14 @@ def _iou_matrix(a, b):
     return inter / (aa[:, None] + ab[None, :] - inter)
 
 
-def test_train_step_512_batch16_is_deterministic_and_linear_in_the_upstream_gradient():
+@pytest.mark.parametrize('model_name,batch,size', [('mobilenetv2-fpn', 16, 512),        # BASELINE config 2
+                                                   ('regnetx-600m-fpn', 16, 512)])      # BASELINE config 3 (per-GPU shape)
+def test_train_step_512_batch16_is_deterministic_and_linear_in_the_upstream_gradient(model_name, batch, size):
     torch.manual_seed(0)
-    net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn'))).to(DEV)
+    net = DetectionModel(io.StringIO(zoo.cfg_text(model_name))).to(DEV)
     net.train()
-    x = torch.randn(16, 3, 512, 512, generator=torch.Generator().manual_seed(0)).to(DEV)
-    tgt = tuple(t.to(DEV) for t in labels.synthetic_targets(16, 512, 20, seed=1))
+    x = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(0)).to(DEV)
+    tgt = tuple(t.to(DEV) for t in labels.synthetic_targets(batch, size, 20, seed=1))
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
     runs = []
     for scale in (1.0, 1.0, 4.0):            # a power of two: scaling commutes with every fp32 rounding in a linear backward
