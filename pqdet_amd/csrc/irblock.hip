@@ -79,8 +79,10 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
 // (the ring holds R + TH rows), and the fragments of step k + 2 are in flight; expand and depthwise code of a step form ONE
 // basic block (tile numbers are compile-time constants, every load is unconditional at a clamped address), so the MFMA chains
 // of the five tiles and the depthwise stage's LDS reads / FMAs interleave.
-template <int S, int KS>
-__global__ __launch_bounds__(256, 2) void xdw_fwd_kernel(XdwP p) {
+// YE: also store the raw expanded tensor (a template flavour: the values to store stay live across the depthwise stage, 20 registers
+// the plain kernel does not have to keep; the 16 -> 96 stride-2 instantiation then fits three workgroups per CU = ONE round)
+template <int S, int KS, bool YE>
+__global__ __launch_bounds__(256, (S == 2 && !YE) ? 3 : 2) void xdw_fwd_kernel(XdwP p) {
     using G = XGeom<S>;
     constexpr int I = 4 * KS, TH = G::TH;
     constexpr int NT = TH * G::TPR + 1;                         // tiles of a step (the last one gathers the halo columns)
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void xdw_fwd_kernel(XdwP p) {
             if constexpr (T < NT) y1[decltype(i)::value] = expand_tile(G::RX, ic<TH>{}, ic<T>{}, xf[decltype(i)::value]); });
         static_for<NTW>([&](auto i) { constexpr int T = WH + 2 * decltype(i)::value;       // (past the segment: clamped rows, never used)
             if constexpr (T < NT) load_frag<KS>(frag_ptr(G::RX + TH, ic<TH>{}, ic<T>{}), xf[decltype(i)::value]); });
-        if (p.yexp != nullptr) {                                // uniform
+        if constexpr (YE) {
             static_for<NTW0>([&](auto i) { constexpr int T = WH + 2 * decltype(i)::value;
                 if constexpr (T < NT0) store_yexp(0, ic<G::RX>{}, ic<T>{}, y0[decltype(i)::value]); });
             static_for<NTW>([&](auto i) { constexpr int T = WH + 2 * decltype(i)::value;
@@ -280,8 +282,7 @@ __global__ __launch_bounds__(256, 2) void xdw_fwd_kernel(XdwP p) {
                 s2 = f4fma(acc[u], acc[u], s2);
             }
         }
-        if constexpr (EX) {
-            if (p.yexp != nullptr)                              // uniform
+        if constexpr (EX && YE) {
                 static_for<NTW>([&](auto i) { constexpr int T = WH + 2 * decltype(i)::value;
                     if constexpr (T < NT) store_yexp(l1, ic<TH>{}, ic<T>{}, yv[decltype(i)::value]); });
         }
@@ -500,11 +501,16 @@ static XdwPlan xdw_plan(int B, int IH, int IW, int E, int stride) {
     const int th = stride == 1 ? 8 : 4;
     const int steps_total = (IH + th - 1) / th;
     const long base = (long)B * w.strips * w.chunks;
-    long segs = (768 + base - 1) / base;                      // enough walkers for two to three workgroups per CU
+    // row segments per image column: the choice that costs the fewest (rounds of resident workgroups) x (steps per workgroup + ~2
+    // steps of prologue); 3 workgroups per CU at stride 2 (registers), 2 at stride 1
+    const long slots = 256L * (stride == 2 ? 3 : 2);
     const long maxsegs = steps_total / 2 > 0 ? steps_total / 2 : 1;
-    if (segs > maxsegs) segs = maxsegs;
-    if (segs > 4) segs = 4;
-    if (segs < 1) segs = 1;
+    long segs = 1, best = -1;
+    for (long sgs = 1; sgs <= 4 && sgs <= maxsegs; ++sgs) {
+        const long ss = (steps_total + sgs - 1) / sgs, real = (steps_total + ss - 1) / ss;
+        const long cost = ((base * real + slots - 1) / slots) * (ss + 2);
+        if (best < 0 || cost < best) { best = cost; segs = sgs; }
+    }
     const int seg_steps = (int)((steps_total + segs - 1) / segs);
     w.segs = (steps_total + seg_steps - 1) / seg_steps;
     w.seg_rows = seg_steps * th;
@@ -559,10 +565,10 @@ extern "C" int pq_xdw_fwd(const pq_xdw_fwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int key = a->stride * 100 + a->I;
     switch (key) {
-        case 116: PQ_LAUNCH((xdw_fwd_kernel<1, 4>), grid, blk, 0, st, p); break;
-        case 124: PQ_LAUNCH((xdw_fwd_kernel<1, 6>), grid, blk, 0, st, p); break;
-        case 216: PQ_LAUNCH((xdw_fwd_kernel<2, 4>), grid, blk, 0, st, p); break;
-        default: PQ_LAUNCH((xdw_fwd_kernel<2, 6>), grid, blk, 0, st, p); break;
+        case 116: if (a->yexp) PQ_LAUNCH((xdw_fwd_kernel<1, 4, true>), grid, blk, 0, st, p); else PQ_LAUNCH((xdw_fwd_kernel<1, 4, false>), grid, blk, 0, st, p); break;
+        case 124: if (a->yexp) PQ_LAUNCH((xdw_fwd_kernel<1, 6, true>), grid, blk, 0, st, p); else PQ_LAUNCH((xdw_fwd_kernel<1, 6, false>), grid, blk, 0, st, p); break;
+        case 216: if (a->yexp) PQ_LAUNCH((xdw_fwd_kernel<2, 4, true>), grid, blk, 0, st, p); else PQ_LAUNCH((xdw_fwd_kernel<2, 4, false>), grid, blk, 0, st, p); break;
+        default: if (a->yexp) PQ_LAUNCH((xdw_fwd_kernel<2, 6, true>), grid, blk, 0, st, p); else PQ_LAUNCH((xdw_fwd_kernel<2, 6, false>), grid, blk, 0, st, p); break;
     }
     PQ_CHECK_LAUNCH();
     return PQ_OK;

@@ -228,7 +228,14 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
     f32x4 g1[MUG];
 #pragma unroll
     for (int j = 0; j < MUG; ++j) g1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float4* wq = wtab + (dact ? qd : 0) * 9;              // the quad's taps (LDS: re-read per pixel, the registers go to the accumulators)
+    const float4* wq_l = wtab + (dact ? qd : 0) * 9;            // the quad's taps: LDS, re-read per pixel (the registers go to the accumulators) ...
+    constexpr bool WREG = NQ <= 24;                             // ... or registers where the budget allows (E = 96)
+    float4 wq_r[WREG ? 9 : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wq_r[k] = wq_l[k];
+    }
+    auto wq = [&](int k) -> float4 { if constexpr (WREG) return wq_r[k]; else return wq_l[k]; };
     const float4* ceq = ce + 4 * (dact ? qd : 0);
     __syncthreads();
 
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
                             const float4 d = ring[(slot * G::DC + c + 2 - kx) * NQ + qd];
-                            tt = f4fma(d, wq[ky * 3 + kx], tt);
+                            tt = f4fma(d, wq(ky * 3 + kx), tt);
                             dwacc[ky * 3 + kx] = f4fma(d, h4, dwacc[ky * 3 + kx]);
                         }
                     }
@@ -309,10 +316,10 @@ __global__ __launch_bounds__(512) void xdwb_kernel(XbwdP p) {
                     const float4 da0 = ring[(sa * G::DC + bx) * NQ + qd], da1 = ring[(sa * G::DC + bx + 1) * NQ + qd];
                     const float4 db0 = ring[(sb * G::DC + bx) * NQ + qd], db1 = ring[(sb * G::DC + bx + 1) * NQ + qd];
                     float4 tv4[4];
-                    tv4[0] = f4fma(da0, wq[4], f4zero());
-                    tv4[1] = f4fma(da1, wq[3], f4fma(da0, wq[5], f4zero()));
-                    tv4[2] = f4fma(db0, wq[1], f4fma(da0, wq[7], f4zero()));
-                    tv4[3] = f4fma(db1, wq[0], f4fma(db0, wq[2], f4fma(da1, wq[6], f4fma(da0, wq[8], f4zero()))));
+                    tv4[0] = f4fma(da0, wq(4), f4zero());
+                    tv4[1] = f4fma(da1, wq(3), f4fma(da0, wq(5), f4zero()));
+                    tv4[2] = f4fma(db0, wq(1), f4fma(da0, wq(7), f4zero()));
+                    tv4[3] = f4fma(db1, wq(0), f4fma(db0, wq(2), f4fma(da1, wq(6), f4fma(da0, wq(8), f4zero()))));
                     const float4 ces = ceq[0], cet = ceq[1], cem = ceq[2], cei = ceq[3], cpe = cp[qd];
                     float4 h4[4];
 #pragma unroll
