@@ -79,6 +79,12 @@ template <int BM, int BN, int AMODE, int EMODE, int S>
 __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two waves per SIMD: at most 256 registers
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
     constexpr bool PAIR = AMODE == 2 || AMODE == 4;                      // two-tensor gradient operand (g, y)
+    // AMODE 2: the staged pair is turned into dy' = p g + q (y - mu) + r IN PLACE, once per k-tile, by all 256 threads (8 floats
+    // each), instead of at every fragment read: a tile row is read by both column waves, and every wave read the four coefficient
+    // quads (p, q, mu, r) of a k-step as 1 KiB broadcasts -- per k-tile of a 64-row tile 32 KB of (g, y) + 64 KB of coefficients
+    // through the LDS return path against 32 KB of B: the read port, not the matrix pipe, set the k-tile time (round-4 stamps).
+    // Now: 24.5 KB for the pass + 16 KB of dy' fragments.  One more barrier per k-tile.
+    constexpr bool PREX = AMODE == 2;
     constexpr int NA = PAIR ? 2 : 1;
     constexpr int A_FL = BM * 32, B_FL = BN * 32;
     constexpr int CW = AMODE == 2 ? 128 : (AMODE == 1 ? 64 : 0);        // coefficient floats per wave per stage
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + 32 * i + lrow) * 32 + ch]);
-                if (PAIR) yf[i] = *reinterpret_cast<const float4*>(&As[A_FL + (wm * WM + 32 * i + lrow) * 32 + ch]);
+                if (PAIR && !PREX) yf[i] = *reinterpret_cast<const float4*>(&As[A_FL + (wm * WM + 32 * i + lrow) * 32 + ch]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + 32 * j + lrow) * 32 + ch]);
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) ak[i][q] = __builtin_amdgcn_fmed3f(fmaf(s4[q], ak[i][q], h4[q]), lo, hi);
-            } else if (PAIR) {
+            } else if (PAIR && !PREX) {
                 const float* T4 = &ctab[kt * 32 + ks * 8 + 4 * lh];
                 const float4 c0 = *reinterpret_cast<const float4*>(AMODE == 2 ? &Cs[ks * 8 + 4 * lh] : T4);
                 const float4 c1 = *reinterpret_cast<const float4*>(AMODE == 2 ? &Cs[32 + ks * 8 + 4 * lh] : T4 + Kp);
@@ -218,6 +224,23 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
         }
     };
 
+    // the in-place pass of AMODE 2: thread -> (chunk slot t & 7, rows t / 8 + 32 i); the slot of a row holds k-quad slot ^ swizzle(row),
+    // the same quad for all rows of a thread (32 rows apart), so its four coefficient quads are read once per k-tile
+    auto xform = [&](int s) {
+        float* As = lds + s * STAGE;
+        const float* Cw = As + NA * A_FL + B_FL + w * CW;
+        const int sl = t & 7, r0 = t >> 3;
+        const int c4 = (sl ^ ((r0 >> 1) & 7)) << 2;
+        const float4 cp = *reinterpret_cast<const float4*>(&Cw[c4]), cq = *reinterpret_cast<const float4*>(&Cw[32 + c4]);
+        const float4 cm = *reinterpret_cast<const float4*>(&Cw[64 + c4]), cr = *reinterpret_cast<const float4*>(&Cw[96 + c4]);
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            float* gp = &As[(r0 + 32 * i) * 32 + 4 * sl];
+            const float4 g4 = *reinterpret_cast<const float4*>(gp), y4 = *reinterpret_cast<const float4*>(gp + A_FL);
+            *reinterpret_cast<float4*>(gp) = make_float4(fmaf(cp.x, g4.x, fmaf(cq.x, y4.x - cm.x, cr.x)), fmaf(cp.y, g4.y, fmaf(cq.y, y4.y - cm.y, cr.y)),
+                                                         fmaf(cp.z, g4.z, fmaf(cq.z, y4.z - cm.z, cr.z)), fmaf(cp.w, g4.w, fmaf(cq.w, y4.w - cm.w, cr.w)));
+        }
+    };
     // ---- main loop: ring of S stages, D tiles in flight
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -251,11 +274,13 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
 #ifdef PQ_STAMPS
         if (kt == 0) PQ_STAMP(1);
 #endif
+        if (PREX) { xform(kt % S); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // (raw barrier: the LDS writes are drained by hand)
         if (kt + D < nk) issue((kt + D) % S, kt + D);
         compute(kt % S, kt);
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (PREX) { xform((nk - 1) % S); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #ifdef PQ_STAMPS
     if (nk == 1) PQ_STAMP(1);
 #endif
