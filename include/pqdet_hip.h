@@ -333,7 +333,8 @@ int32_t pq_xdw_fwd_blocks(int32_t B, int32_t IH, int32_t IW, int32_t I, int32_t 
  * model/parser.py:404-405): per expanded channel c, sum y_c = we_c . s and sum y_c^2 = we_c^T G we_c with s = sum x', G = sum x' x'^T
  * over the M pixels -- one pass over the I-channel input (workgroup partials added into exact fixed-point accumulators in `scratch`:
  * order independent, run-to-run deterministic), then a finalize that writes mean / invstd / scale / shift and the running statistics
- * exactly like pq_bn_fwd_finalize(train).  I in {16, 24}. */
+ * exactly like pq_bn_fwd_finalize(train).  I in {16, 24}.  in.stat is honoured (pq_bn_stat, consumer role): the block input's own
+ * BatchNorm may be handed over by its producer. */
 typedef struct pq_xstat_fwd_args {
     pq_src in;           /* block input, M rows of I channels */
     const float* we;     /* [E][I] */

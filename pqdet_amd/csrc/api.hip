@@ -337,6 +337,10 @@ extern "C" int32_t pq_bn_stat_ok(int32_t code, const void* args, int32_t role) {
             const pq_copy_args* c = (const pq_copy_args*)args;
             return role == 1 && !c->a.qstate && !c->b.qstate && (c->C & 3) == 0;
         }
+        case PQ_OP_XSTAT_FWD: {          // consumer only: the moments pass is the FIRST reader of a fused block's input
+            const pq_xstat_fwd_args* c = (const pq_xstat_fwd_args*)args;
+            return role == 1 && !c->in.qstate && (c->I == 16 || c->I == 24);
+        }
         default: return 0;
     }
 }

@@ -346,7 +346,12 @@ __global__ __launch_bounds__(256) void xgram_kernel(XgramP p) {
     const int i = lane & (NL - 1), kh = lane / NL;
     const bool iok = i < I;
     const int ic_ = iok ? i : 0;
-    const float ca = (p.in.scale && iok) ? p.in.scale[ic_] : 1.f, cb = (p.in.scale && iok) ? p.in.shift[ic_] : 0.f;
+    float ca = (p.in.scale && iok) ? p.in.scale[ic_] : 1.f, cb = (p.in.scale && iok) ? p.in.shift[ic_] : 0.f;
+    if (p.in.stat.acc != nullptr) {            // uniform: the operand's BatchNorm handed over by its producer (pq_bn_stat): every lane derives
+        ca = 1.f; cb = 0.f;                    // the coefficients of ITS channel; one lane per channel of workgroup 0 stores the vectors
+        bn_stat_coefs<1>(p.in.stat, ic_, 1, I, blockIdx.x == 0 && w == 0 && kh == 0 && iok,
+                         [&](int, const BnCoef& bc) { if (iok) { ca = bc.scale; cb = bc.shift; } });
+    }
     const ActParam act = act_param(p.in.act);
     const int m0 = blockIdx.x * p.rows_per_wg, m1 = min(m0 + p.rows_per_wg, p.M);
     float acc[NACC];
@@ -588,8 +593,8 @@ extern "C" int64_t pq_xstat_fwd_scratch_bytes(int32_t M, int32_t I) {
 extern "C" int pq_xstat_fwd(const pq_xstat_fwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->in.x && a->we && a->gamma && a->beta && a->mean && a->invstd && a->scale && a->shift && a->scratch, "null pointer");
     PQ_CHECK_ARG(a->M > 0 && a->E > 0 && a->in.ld >= a->I && (((uintptr_t)a->scratch) & 15) == 0, "bad shape / scratch alignment");
-    if (!(a->I == 16 || a->I == 24) || act_is_special(a->in.act) || a->in.qstate || a->in.stat.acc) {
-        pq_set_error("pq_xstat_fwd: I must be 16 / 24; logistic / tanh operands, QAT observers and in.stat are not supported");
+    if (!(a->I == 16 || a->I == 24) || act_is_special(a->in.act) || a->in.qstate) {
+        pq_set_error("pq_xstat_fwd: I must be 16 / 24; logistic / tanh operands and QAT observers are not supported");
         return PQ_EUNSUPPORTED;
     }
     int rows, nwg;

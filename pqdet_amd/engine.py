@@ -919,6 +919,8 @@ class Plan:
                 srcs = [cons.u.gcf.inp]
             elif cons.code == abi.OP_COPY_FWD:
                 srcs = [cons.u.cp.a, cons.u.cp.b]
+            elif cons.code == abi.OP_XSTAT_FWD:                # the moments pass of a fused block is the first reader of the block input
+                srcs = [cons.u.xsf.inp]
             else:
                 continue
             hit = [s_ for s_ in srcs if s_.x == pa.out and s_.scale == f.scale and not s_.qstate]

@@ -264,6 +264,55 @@ def test_xdw_bwd_matches_autograd_through_expand_batchnorm_relu6_depthwise(B, H,
         assert bool((err <= 1e-5 * terms.abs().sum((0, 1, 2)) + 1e-6).all()), '%s: max err %g' % (what, err.max().item())
 
 
+def test_xstat_fwd_takes_the_block_inputs_batchnorm_from_its_producers_accumulators():
+    """pq_conv1x1_fwd(stat_acc) -> pq_xstat_fwd(in.stat): the block input's own train-mode BatchNorm is handed over (no finalize launch);
+    the moments pass derives scale / shift per lane, its first workgroup stores the vectors and the running statistics."""
+    l = abi.lib()
+    g = torch.Generator().manual_seed(5)
+    M, C0, I, E = 6000, 32, 16, 96
+    x0, w0 = rnd(M, C0, g=g), rnd(I, C0, g=g, scale=0.2)
+    gam, bet = torch.rand(I, generator=g) + 0.5, rnd(I, g=g, scale=0.3)
+    we = rnd(E, I, g=g, scale=0.25)
+    ge, be = torch.rand(E, generator=g) + 0.5, rnd(E, g=g, scale=0.3)
+    y0 = x0.double() @ w0.double().t()
+    m0, v0 = y0.mean(0), y0.var(0, unbiased=False)
+    xin = (y0 - m0) / torch.sqrt(v0 + 1e-5) * gam.double() + bet.double()          # the block input x'
+    ye = xin @ we.double().t()
+    me, ve = ye.mean(0), ye.var(0, unbiased=False)
+    dev = [t.to(DEV) for t in (x0, w0, we)]
+    vec = [chan_vec(v) for v in (gam, bet, ge, be)]
+    ldp = 16
+    nb = l.pq_conv1x1_blocks_k(M, I, C0, 0)
+    slots = l.pq_bn_stat_slots(nb)
+    acc = torch.zeros(l.pq_bn_stat_bytes(ldp, slots) // 8, dtype=torch.int64, device=DEV)
+    bad = torch.zeros(16, dtype=torch.int32, device=DEV)
+    raw = torch.full((M, I), float('nan'), device=DEV)
+    f = abi.Conv1x1Fwd(abi.Src(dev[0].data_ptr(), None, None, C0, 0), dev[1].data_ptr(), None, raw.data_ptr(), None, M, C0, I, I, ldp, 1, 0, 0, 0, 0)
+    f.stat_acc, f.stat_bad, f.stat_slots = acc.data_ptr(), bad.data_ptr(), slots
+    abi.check(l.pq_conv1x1_fwd(C.byref(f), stream()))
+    rm, rv = torch.zeros(I, device=DEV), torch.ones(I, device=DEV)
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    inv = [torch.full((32,), float('nan'), device=DEV) for _ in range(4)]          # mean, invstd, scale, shift of the block input
+    outv = [torch.full((E + 16,), float('nan'), device=DEV) for _ in range(4)]
+    scratch = torch.zeros(l.pq_xstat_fwd_scratch_bytes(M, I) // 4, device=DEV)
+    a = abi.XstatFwd()
+    a.inp = abi.Src(raw.data_ptr(), inv[2].data_ptr(), inv[3].data_ptr(), I, 0)
+    a.inp.stat = abi.BnStat(acc.data_ptr(), bad.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(),
+                            *[v.data_ptr() for v in inv], slots, ldp, float(M), 1e-5, 0.1, 1.0 / M)
+    a.we, a.gamma, a.beta = dev[2].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr()
+    a.mean, a.invstd, a.scale, a.shift = [v.data_ptr() for v in outv]
+    a.scratch, a.M, a.I, a.E, a.eps, a.momentum = scratch.data_ptr(), M, I, E, 1e-5, 0.1
+    assert l.pq_bn_stat_ok(abi.OP_XSTAT_FWD, C.byref(a), 1) == 1
+    abi.check(l.pq_xstat_fwd(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    close(inv[0][:I], m0.float(), rt=1e-4, at=1e-5, what='block input mean')
+    close(inv[2][:I], (gam.double() / torch.sqrt(v0 + 1e-5)).float(), rt=1e-4, at=1e-5, what='block input scale')
+    close(rm, (0.1 * m0).float(), rt=1e-4, at=1e-5, what='running mean of the block input')
+    assert int(nbt[0]) == 1
+    close(outv[0][:E], me.float(), rt=1e-4, at=1e-4, what='expanded mean')
+    close(outv[1][:E], (1 / torch.sqrt(ve + 1e-5)).float(), rt=1e-4, at=1e-5, what='expanded invstd')
+
+
 def test_xdw_fwd_refuses_what_it_does_not_cover():
     l = abi.lib()
     assert l.pq_xdw_fwd_blocks(2, 16, 16, 64, 384, 1) == 0            # contraction outside {16, 24}
