@@ -3,7 +3,7 @@
 # (--kernel-trace only, as the pool requires).  Output: gpurun_out/prof/r2_mfma_summary.csv
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-export TAG=${TAG:-r3}
+export TAG=${TAG:-r5}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

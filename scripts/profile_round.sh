@@ -4,7 +4,7 @@
 # usage (from the repo root on the GPU box): bash scripts/profile_round.sh
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 # BENCH_ARGS: e.g. "--model regnetx-600m-fpn" or "--qat --batch 12"; SUFFIX names the summary (r4_pmc_summary$SUFFIX.csv)
 SUFFIX=${SUFFIX:-}
 OUT=$ROOT/gpurun_out/prof
