@@ -208,8 +208,8 @@ PMC_PATTERN = {
     'gconv3x3_wgrad (implicit GEMM, fp32 MFMA)': (r'gconv_wgrad_kernel<', r'gconv_wgrad_reduce|gconv_slab'),
 }
 # per (model, QAT plan): the PMC summary collected with scripts/profile_round.sh for exactly that plan (MODEL / BENCH_ARGS)
-PMC_FILES = {('mobilenetv2-fpn', False): 'r4_pmc_summary.csv', ('regnetx-600m-fpn', False): 'r4_pmc_summary_regnetx-600m-fpn.csv',
-             ('regnetx-600m-pan', False): 'r4_pmc_summary_regnetx-600m-pan.csv', ('mobilenetv2-fpn', True): 'r4_pmc_summary_qat.csv'}
+PMC_FILES = {('mobilenetv2-fpn', False): 'r5_pmc_summary.csv', ('regnetx-600m-fpn', False): 'r5_pmc_summary_regnetx-600m-fpn.csv',
+             ('regnetx-600m-pan', False): 'r5_pmc_summary_regnetx-600m-pan.csv', ('mobilenetv2-fpn', True): 'r5_pmc_summary_qat.csv'}
 
 
 def measured_traffic(kernel_class, model_name, qat=False):
