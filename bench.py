@@ -110,6 +110,7 @@ KERNEL_CLASS = {
     abi.OP_XSTAT_FWD: ('xstat_fwd (expanded-tensor BN statistics from input moments)', 'hbm'),
     abi.OP_XDW_FWD: ('xdw_fwd (fused expand 1x1 + BN + ReLU6 + dw3x3)', 'hbm'),
     abi.OP_XDW_BWD: ('xdw_bwd (fused dw3x3 + expand 1x1 backward, recompute)', 'hbm'),
+    abi.OP_REDUCE_BATCH: ('weight-gradient partial sums (batched reduce)', 'hbm'),
 }
 
 
@@ -201,7 +202,7 @@ PMC_PATTERN = {
     # gemm_nt template args: BM,BN,WM,WN,AMODE,BKN,EMODE,..;  gemm2_nt: BM,BN,AMODE,EMODE,S  (EMODE 2 = gradient sink)
     'conv1x1_dgrad (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, 2, |gemm2_nt_kernel<\d+, \d+, \d, 2, ', None),
     'conv1x1_fwd (gemm_nt, fp32 MFMA)': (r'gemm_nt_kernel<\d+, \d+, \d+, \d+, \d, \w+, [01], |gemm2_nt_kernel<\d+, \d+, \d, [01], ', None),
-    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<|gemm2_tn_kernel<', r'pq::slab_reduce'),
+    'conv1x1_wgrad (gemm_tn, fp32 MFMA)': (r'gemm_tn_kernel<|gemm2_tn_kernel<', r'pq::slab_reduce|pq::reduce_batch_kernel'),
     'conv1x1_bwd narrow layers (fused dgrad+wgrad, one pass over dy)': (r'pw_bwd_kernel<', r'pw_slab_reduce_kernel'),
     'gconv3x3_fwd (implicit GEMM, fp32 MFMA)': (r'gconv_kernel<[01], ', None),
     'gconv3x3_dgrad (implicit GEMM, fp32 MFMA)': (r'gconv_kernel<2, |gconv_dgrad_s2_kernel', None),

@@ -193,8 +193,8 @@ int pq_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, void* stream);
 typedef struct pq_conv1x1_wgrad_args {
     pq_gsrc dy;
     pq_src in;
-    float* dw;           /* [O][I] */
-    float* dbias;        /* [O] or NULL: column sums of dy' */
+    float* dw;           /* [O][I]; NULL: deferred reduction (pq_reduce_batch), the slabs stay in `scratch` */
+    float* dbias;        /* [O] or NULL: column sums of dy' (deferred form: non-NULL only says that the column is wanted) */
     float* scratch;      /* >= pq_conv1x1_wgrad_scratch_bytes(M,I,O) */
     int32_t M, I, O;
     int32_t sub, OH, OW, IH, IW;   /* sub>1: in' rows are gathered at (b,oy*sub,ox*sub) as in the forward */
@@ -213,7 +213,7 @@ typedef struct pq_conv1x1_bwd_args {
     const float* w;      /* [O][I] */
     pq_src in;
     pq_gsink dx;
-    float* dw;           /* [O][I] */
+    float* dw;           /* [O][I]; NULL: deferred reduction (pq_reduce_batch) */
     float* scratch;      /* >= pq_conv1x1_bwd_scratch_bytes(M,I,O) */
     int32_t M, I, O;
     pq_bn_bstat dy_stat; /* as in the data-gradient arguments above */
@@ -438,7 +438,7 @@ int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream);
 typedef struct pq_gconv3x3_wgrad_args {
     pq_gsrc dy;
     pq_src in;
-    float* dw;           /* [C][gw][3][3] */
+    float* dw;           /* [C][gw][3][3]; NULL: deferred reduction (pq_reduce_batch) */
     float* scratch;      /* >= pq_gconv3x3_wgrad_scratch_bytes(B, OH, OW, C, gw) */
     int32_t B, IH, IW, OH, OW, C, gw, stride;
 } pq_gconv3x3_wgrad_args;
@@ -793,6 +793,39 @@ typedef struct pq_transpose_args {
 } pq_transpose_args;
 int pq_transpose_batch(const pq_transpose_args* a, void* stream);
 
+/* ------------------------------------------------------------------ batched partial-sum reduction (weight gradients)
+ * Every weight-gradient entry splits its contraction over workgroups and leaves one partial slab per split in its `scratch`; the
+ * sum over the splits used to be a launch of its own per layer (83 launches per mobilenetv2-fpn step).  DEFERRED form: call the
+ * entry with dw == NULL (pq_conv1x1_wgrad, pq_conv1x1_bwd, pq_gconv3x3_wgrad; for the walking depthwise backward simply do not
+ * issue part 6) -- the slabs stay in `scratch` -- and sum the slabs of MANY layers with ONE pq_reduce_batch launch later (the
+ * engine: once per group of layers, in front of the gradient-ready mark of a DDP bucket).  pq_*_reduce_item(args with the real dw)
+ * describes the slabs the entry leaves behind (pure host function, no launch); pq_reduce_batch_plan assigns the workgroups.
+ * out[e] = sum_{s < splits} slab[(e / ng) * gstride + s * stride + e % ng]   in a FIXED order (bit-identical replays).
+ * Work mirrored: the weight gradients torch.autograd accumulates behind trainer.py:231-233. */
+typedef struct pq_reduce_item {
+    const float* slab;
+    float* out0;         /* columns [0, n0) */
+    float* out1;         /* columns [n0, n0 + n1) or NULL (bias gradient column of pq_conv1x1_wgrad) */
+    int64_t stride;      /* floats between the partial rows of one column group */
+    int64_t gstride;     /* floats between column groups (grouped 3x3: one group of gw output channels) */
+    int32_t splits, n0, n1;
+    int32_t ng;          /* columns per group (n0 + n1 when there is one group) */
+    int32_t perm_gw;     /* > 0: grouped-3x3 layout, column k = tap * gw + i of row o of its group -> out0[((g*gw + o) * gw + i) * 9 + tap] */
+    int32_t lanes;       /* split lanes per column, 4 or 16 (pq_reduce_batch_plan) */
+    int32_t block0;      /* first workgroup of the item (pq_reduce_batch_plan) */
+    int32_t pad_;        /* floats per column unit, 1 or 4 (pq_reduce_batch_plan) */
+} pq_reduce_item;
+typedef struct pq_reduce_batch_args {
+    const pq_reduce_item* items;      /* DEVICE copy of the planned table */
+    int32_t n_items, n_blocks;
+} pq_reduce_batch_args;
+int32_t pq_reduce_batch_plan(pq_reduce_item* host_items, int32_t n_items);     /* fills lanes / block0; returns n_blocks */
+int pq_reduce_batch(const pq_reduce_batch_args* a, void* stream);
+int pq_conv1x1_wgrad_reduce_item(const pq_conv1x1_wgrad_args* a, pq_reduce_item* out);
+int pq_conv1x1_bwd_reduce_item(const pq_conv1x1_bwd_args* a, pq_reduce_item* out);
+int pq_dw3x3_bwd_reduce_item(const pq_dw3x3_bwd_args* a, pq_reduce_item* out);         /* a: the part-6 arguments */
+int pq_gconv3x3_wgrad_reduce_item(const pq_gconv3x3_wgrad_args* a, pq_reduce_item* out);
+
 /* ------------------------------------------------------------------ batched executor
  * The engine compiles one training / inference step into an array of pq_op and replays it with ONE host call. */
 enum {
@@ -803,7 +836,8 @@ enum {
     PQ_OP_QAT_WPREP, PQ_OP_QAT_WGRAD, PQ_OP_QACT_FWD, PQ_OP_QACT_BWD, PQ_OP_POOL_REDUCE, PQ_OP_CONV1X1_BWD,
     PQ_OP_BN_EVAL,
     PQ_OP_LAYER_FWD,
-    PQ_OP_XDW_FWD, PQ_OP_XSTAT_FWD, PQ_OP_XDW_BWD
+    PQ_OP_XDW_FWD, PQ_OP_XSTAT_FWD, PQ_OP_XDW_BWD,
+    PQ_OP_REDUCE_BATCH
 };
 typedef struct pq_fill_args { float* dst; float value; int64_t n; } pq_fill_args;
 #define PQ_OPF_SIDE 1   /* op may run on the side stream of pq_run_ops2 (it only feeds the optimiser, e.g. weight gradients) */
@@ -828,6 +862,7 @@ typedef struct pq_op {
         pq_qat_weight_args qw; pq_qact_args qa; pq_qact_bwd_args qb; pq_pool_reduce_args pr; pq_conv1x1_bwd_args c1b; pq_bn_eval_args bne;
         pq_layer_fwd_args lay;
         pq_xdw_fwd_args xdf; pq_xstat_fwd_args xsf; pq_xdw_bwd_args xdb;
+        pq_reduce_batch_args red;
     } u;
 } pq_op;
 int pq_run_ops(const pq_op* ops, int32_t n, void* stream);

@@ -269,6 +269,15 @@ class XdwBwd(C.Structure):
                 ('B', i32), ('IH', i32), ('IW', i32), ('OH', i32), ('OW', i32), ('I', i32), ('E', i32), ('stride', i32)]
 
 
+class ReduceItem(C.Structure):
+    _fields_ = [('slab', c_fp), ('out0', c_fp), ('out1', c_fp), ('stride', i64), ('gstride', i64), ('splits', i32), ('n0', i32), ('n1', i32),
+                ('ng', i32), ('perm_gw', i32), ('lanes', i32), ('block0', i32), ('pad_', i32)]
+
+
+class ReduceBatch(C.Structure):
+    _fields_ = [('items', c_fp), ('n_items', i32), ('n_blocks', i32)]
+
+
 LAYER_MAXPOOL, LAYER_AVGPOOL, LAYER_IM2COL, LAYER_FC, LAYER_ACT, LAYER_PADROWS = range(6)
 
 
@@ -279,7 +288,7 @@ class _OpU(C.Union):
                 ('dec', Decode), ('loss', YoloLoss), ('adam', Adam), ('fill', Fill),
                 ('gcf', GconvFwd), ('gcd', GconvDgrad), ('gcw', GconvWgrad), ('tr', Transpose),
                 ('qw', QatWeight), ('qa', Qact), ('qb', QactBwd), ('pr', PoolReduce), ('c1b', Conv1x1Bwd), ('bne', BnEval),
-                ('lay', LayerFwd), ('xdf', XdwFwd), ('xsf', XstatFwd), ('xdb', XdwBwd)]
+                ('lay', LayerFwd), ('xdf', XdwFwd), ('xsf', XstatFwd), ('xdb', XdwBwd), ('red', ReduceBatch)]
 
 
 OPF_SIDE = 1
@@ -295,7 +304,8 @@ class Op(C.Structure):
 (OP_CONV1X1_FWD, OP_CONV1X1_DGRAD, OP_CONV1X1_WGRAD, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD,
  OP_BN_FWD_FIN, OP_BN_BWD_FIN, OP_COPY_FWD, OP_ROUTE_BWD, OP_DECODE, OP_LOSS_FWD, OP_LOSS_BWD, OP_ADAM, OP_FILL, OP_DW_BWD,
  OP_GCONV_FWD, OP_GCONV_DGRAD, OP_GCONV_WGRAD, OP_TRANSPOSE, OP_QAT_WPREP, OP_QAT_WGRAD, OP_QACT_FWD,
- OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL, OP_LAYER_FWD, OP_XDW_FWD, OP_XSTAT_FWD, OP_XDW_BWD) = range(1, 34)
+ OP_QACT_BWD, OP_POOL_REDUCE, OP_CONV1X1_BWD, OP_BN_EVAL, OP_LAYER_FWD, OP_XDW_FWD, OP_XSTAT_FWD, OP_XDW_BWD,
+ OP_REDUCE_BATCH) = range(1, 35)
 
 OP_FIELD = {
     OP_CONV1X1_FWD: 'c1f', OP_CONV1X1_DGRAD: 'c1d', OP_CONV1X1_WGRAD: 'c1w', OP_DW_FWD: 'dwf', OP_DW_DGRAD: 'dwd',
@@ -304,6 +314,7 @@ OP_FIELD = {
     OP_FILL: 'fill', OP_DW_BWD: 'dwb', OP_GCONV_FWD: 'gcf', OP_GCONV_DGRAD: 'gcd', OP_GCONV_WGRAD: 'gcw',
     OP_TRANSPOSE: 'tr', OP_QAT_WPREP: 'qw', OP_QAT_WGRAD: 'qw', OP_QACT_FWD: 'qa', OP_QACT_BWD: 'qb',
     OP_POOL_REDUCE: 'pr', OP_CONV1X1_BWD: 'c1b', OP_BN_EVAL: 'bne', OP_LAYER_FWD: 'lay', OP_XDW_FWD: 'xdf', OP_XSTAT_FWD: 'xsf', OP_XDW_BWD: 'xdb',
+    OP_REDUCE_BATCH: 'red',
 }
 
 # name -> (restype, argtypes); every symbol include/pqdet_hip.h declares
@@ -341,6 +352,12 @@ SIGNATURES = {
     'pq_xstat_fwd': (C.c_int, [C.POINTER(XstatFwd), C.c_void_p]),
     'pq_xstat_fwd_scratch_bytes': (i64, [i32, i32]),
     'pq_xdw_bwd': (C.c_int, [C.POINTER(XdwBwd), C.c_void_p]),
+    'pq_reduce_batch_plan': (i32, [C.POINTER(ReduceItem), i32]),
+    'pq_reduce_batch': (C.c_int, [C.POINTER(ReduceBatch), C.c_void_p]),
+    'pq_conv1x1_wgrad_reduce_item': (C.c_int, [C.POINTER(Conv1x1Wgrad), C.POINTER(ReduceItem)]),
+    'pq_conv1x1_bwd_reduce_item': (C.c_int, [C.POINTER(Conv1x1Bwd), C.POINTER(ReduceItem)]),
+    'pq_dw3x3_bwd_reduce_item': (C.c_int, [C.POINTER(DwBwd), C.POINTER(ReduceItem)]),
+    'pq_gconv3x3_wgrad_reduce_item': (C.c_int, [C.POINTER(GconvWgrad), C.POINTER(ReduceItem)]),
     'pq_xdw_bwd_blocks': (i32, [i32, i32, i32, i32, i32, i32]),
     'pq_xdw_bwd_fix_blocks': (i32, [i32, i32]),
     'pq_xdw_bwd_scratch_bytes': (i64, [i32, i32, i32, i32, i32, i32]),

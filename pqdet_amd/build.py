@@ -25,6 +25,7 @@ SOURCES = {            # file -> extra flags
     'pwbwd.hip': [],
     'irblock.hip': [],
     'irbwd.hip': [],
+    'reduce.hip': [],
     'qat.hip': ['-ffp-contract=off'],
     'ew.hip': [],
     'yolo.hip': [],

@@ -88,6 +88,7 @@ static int run_one(const pq_op& op, void* stream) {
         case PQ_OP_XDW_FWD: return pq_xdw_fwd(&op.u.xdf, stream);
         case PQ_OP_XSTAT_FWD: return pq_xstat_fwd(&op.u.xsf, stream);
         case PQ_OP_XDW_BWD: return pq_xdw_bwd(&op.u.xdb, stream);
+        case PQ_OP_REDUCE_BATCH: return pq_reduce_batch(&op.u.red, stream);
         default:
             pq_set_error("pq_run_ops: unknown op code %d", op.code);
             return PQ_EINVAL;
@@ -413,6 +414,8 @@ extern "C" int32_t pq_abi_sizeof(int32_t code) {
         case PQ_OP_XDW_FWD: return (int32_t)sizeof(pq_xdw_fwd_args);
         case PQ_OP_XSTAT_FWD: return (int32_t)sizeof(pq_xstat_fwd_args);
         case PQ_OP_XDW_BWD: return (int32_t)sizeof(pq_xdw_bwd_args);
+        case PQ_OP_REDUCE_BATCH: return (int32_t)sizeof(pq_reduce_batch_args);
+        case 110: return (int32_t)sizeof(pq_reduce_item);
         case PQ_OP_CONV1X1_BWD: return (int32_t)sizeof(pq_conv1x1_bwd_args);
         case PQ_OP_BN_EVAL: return (int32_t)sizeof(pq_bn_eval_args);
         case PQ_OP_LAYER_FWD: return (int32_t)sizeof(pq_layer_fwd_args);

@@ -829,6 +829,15 @@ static WalkPlan walk_plan(int B, int IH, int IW, int C, int stride) {
 }
 int dw_walk_blocks(int B, int IH, int IW, int C, int stride) { return walk_plan(B, IH, IW, C, stride).nblk; }
 
+extern "C" int pq_dw3x3_bwd_reduce_item(const pq_dw3x3_bwd_args* a, pq_reduce_item* out) {
+    PQ_CHECK_ARG(a && out && a->dw && a->scratch && a->part == 6, "part-6 arguments expected");
+    PQ_CHECK_ARG(a->B > 0 && a->IH > 0 && a->IW > 0 && a->C > 0 && (a->stride == 1 || a->stride == 2), "bad shape");
+    const WalkPlan w = walk_plan(a->B, a->IH, a->IW, a->C, a->stride);
+    const int n = a->C * 9;
+    *out = pq_reduce_item{a->scratch, a->dw, nullptr, (int64_t)n, 0, w.nblk, n, 0, n, 0, 0, 0, 0};
+    return PQ_OK;
+}
+
 // part 5 of pq_dw3x3_bwd (kernel; rows left in scratch) / part 6 (their reduction into dw); dwtile.hip checks the arguments
 int dw_walk_launch(const pq_dw3x3_bwd_args* a, void* stream) {
     const WalkPlan w = walk_plan(a->B, a->IH, a->IW, a->C, a->stride);

@@ -737,7 +737,7 @@ extern "C" int64_t pq_gconv3x3_wgrad_scratch_bytes(int32_t B, int32_t OH, int32_
 }
 
 extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) {
-    PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->dw && a->scratch, "null pointer");
+    PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->scratch, "null pointer");          // dw == NULL: deferred reduction
     PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape (group width multiple of 4 and <= 32, stride 1|2, pad 1)");
     if (act_is_special(a->in.act)) { pq_set_error("pq_gconv3x3_wgrad: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
     GcWP p{};
@@ -763,8 +763,19 @@ extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) 
     }
 #undef PQ_GCW_LAUNCH
     PQ_CHECK_LAUNCH();
+    if (!a->dw) return PQ_OK;          // the splits' slabs stay in `scratch` (pq_gconv3x3_wgrad_reduce_item / pq_reduce_batch)
     const int total = G * a->gw * 9 * a->gw;
     PQ_LAUNCH(gconv_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, G, p.nsplit, a->gw, a->dw);
     PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_gconv3x3_wgrad_reduce_item(const pq_gconv3x3_wgrad_args* a, pq_reduce_item* out) {
+    PQ_CHECK_ARG(a && out && a->dw && a->scratch, "null pointer");
+    PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape");
+    const int G = a->C / a->gw, ntiles = a->B * ((a->OH + GTH - 1) / GTH) * ((a->OW + GTW - 1) / GTW);
+    const int nsplit = gc_nsplit(ntiles, G), ng = a->gw * 9 * a->gw;
+    // partial[g][split][o][tap * gw + i] -> dw[g * gw + o][i][tap]
+    *out = pq_reduce_item{a->scratch, a->dw, nullptr, (int64_t)ng, (int64_t)nsplit * ng, nsplit, G * ng, 0, ng, a->gw, 0, 0, 0};
     return PQ_OK;
 }

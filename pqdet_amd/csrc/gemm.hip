@@ -888,8 +888,11 @@ extern "C" int64_t pq_conv1x1_wgrad_scratch_bytes(int32_t M, int32_t I, int32_t 
     return (int64_t)splits * ((int64_t)O * I + O) * 4;
 }
 
-static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_gemm_plan* plan) {
-    PQ_CHECK_ARG(a && a->dy.g && a->in.x && a->dw && (a->scratch || plan), "null pointer");
+// item != NULL: no launch, describe the slabs a deferred call (dw == NULL) leaves in `scratch` (pq_reduce_batch)
+static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_gemm_plan* plan, pq_reduce_item* item = nullptr) {
+    PQ_CHECK_ARG(a && a->dy.g && a->in.x && (a->scratch || plan), "null pointer");
+    PQ_CHECK_ARG(!item || a->dw, "the item query needs the gradient's address");
+    const bool deferred = a->dw == nullptr;
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->in.ld & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "pitches must be multiples of 4");
     if (act_is_special(a->in.act)) { pq_set_error("pq_conv1x1_wgrad: logistic/tanh operands must be materialised first"); return PQ_EUNSUPPORTED; }
@@ -904,9 +907,11 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
         const int rc = g2_conv1x1_wgrad(a, &s2, &stride2, st, plan);
         if (rc < 0) return rc;
         if (rc == 1) {
+            const int n0 = a->O * a->I;
+            if (item) *item = pq_reduce_item{a->scratch, a->dw, nullptr, (int64_t)stride2, 0, s2, n0, 0, n0, 0, 0, 0, 0};
             if (plan) return PQ_OK;
             PQ_CHECK_LAUNCH();
-            const int n0 = a->O * a->I;
+            if (deferred) return PQ_OK;
             if (s2 <= 64) PQ_LAUNCH(slab_reduce_cols_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
                                              stride2, s2, a->dw, n0, (float*)nullptr, 0);
             else PQ_LAUNCH(slab_reduce_kernel, dim3((n0 + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, stride2, s2,
@@ -916,6 +921,10 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
         }
     }
     wgrad_plan(a->M, a->I, a->O, tiles, splits, rows);
+    if (item) {
+        const int n0 = a->O * a->I, n1 = a->dbias ? a->O : 0;
+        *item = pq_reduce_item{a->scratch, a->dw, a->dbias, (int64_t)a->O * a->I + a->O, 0, splits, n0, n1, n0 + n1, 0, 0, 0, 0};
+    }
     if (plan) {
         *plan = pq_gemm_plan{1, 64, 64, 1, (a->dy.y ? 1 : 0) | ((a->in.scale || a->in.act != PQ_ACT_LINEAR) ? 2 : 0), 0, splits, 0};
         return PQ_OK;
@@ -934,6 +943,7 @@ static int conv1x1_wgrad_impl(const pq_conv1x1_wgrad_args* a, void* stream, pq_g
     dim3 grid(tiles, splits), blk(256);
     PQ_LAUNCH((gemm_tn_kernel<64, 64>), grid, blk, 0, st, p);
     PQ_CHECK_LAUNCH();
+    if (deferred) return PQ_OK;
     const int n0 = a->O * a->I, n1 = a->dbias ? a->O : 0;
     if (splits <= 64) {
         PQ_LAUNCH(slab_reduce_cols_kernel, dim3((n0 + n1 + 255) / 256), dim3(256), 0, st, (const float*)a->scratch,
@@ -951,4 +961,9 @@ extern "C" int pq_conv1x1_wgrad(const pq_conv1x1_wgrad_args* a, void* stream) { 
 extern "C" int pq_conv1x1_wgrad_plan(const pq_conv1x1_wgrad_args* a, pq_gemm_plan* out) {
     PQ_CHECK_ARG(out, "null pointer");
     return conv1x1_wgrad_impl(a, nullptr, out);
+}
+extern "C" int pq_conv1x1_wgrad_reduce_item(const pq_conv1x1_wgrad_args* a, pq_reduce_item* out) {
+    PQ_CHECK_ARG(out, "null pointer");
+    pq_gemm_plan pl{};
+    return conv1x1_wgrad_impl(a, nullptr, &pl, out);
 }

@@ -477,7 +477,7 @@ static int pw_launch(const PwP& p, const PwPlan& pl, hipStream_t st) {
 }
 
 extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
-    PQ_CHECK_ARG(a && a->dy.g && a->w && a->in.x && a->dx.g && a->dw && a->scratch, "null pointer");
+    PQ_CHECK_ARG(a && a->dy.g && a->w && a->in.x && a->dx.g && a->scratch, "null pointer");      // dw == NULL: deferred reduction
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0) && (a->in.ld & 3) == 0 &&
                  (a->dx.ldg & 3) == 0 && (a->dx.ldy & 3) == 0, "pitches must be multiples of 4");
@@ -532,9 +532,19 @@ extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
     else rc = pw_launch<12, 2, 13, 2>(p, pl, st);                      // I <= 192
     if (rc != PQ_OK) return rc;
     PQ_CHECK_LAUNCH();
+    if (!a->dw) return PQ_OK;          // the workgroups' slabs stay in `scratch` (pq_conv1x1_bwd_reduce_item / pq_reduce_batch)
     const int n = a->O * a->I;
     PQ_LAUNCH(pw_slab_reduce_kernel, dim3((n + 31) / 32), dim3(32, 32), 0, st, (const float*)a->scratch, n, pl.grid, a->dw);
     PQ_CHECK_LAUNCH();
+    return PQ_OK;
+}
+
+extern "C" int pq_conv1x1_bwd_reduce_item(const pq_conv1x1_bwd_args* a, pq_reduce_item* out) {
+    PQ_CHECK_ARG(a && out && a->dw && a->scratch, "null pointer");
+    const PwPlan pl = pw_plan(a->M, a->I, a->O);
+    if (!pl.ok) { pq_set_error("pq_conv1x1_bwd_reduce_item: shape outside the fused kernel's range"); return PQ_EUNSUPPORTED; }
+    const int n = a->O * a->I;
+    *out = pq_reduce_item{a->scratch, a->dw, nullptr, (int64_t)n, 0, pl.grid, n, 0, n, 0, 0, 0, 0};
     return PQ_OK;
 }
 

@@ -68,7 +68,7 @@ def r3_names():
 
 # ---- launch log: which kernel instantiations do the KERNEL-LEVEL value tests launch?  (tests/test_zz_instantiations_gpu.py compares
 # that set with what the plans of the BASELINE nets launch.)  Recording is on only while a test of one of these modules runs.
-KERNEL_TEST_MODULES = {'test_kernels_gpu', 'test_irblock_gpu', 'test_gemm_variants_gpu', 'test_bn_handover_gpu', 'test_qat_gpu'}
+KERNEL_TEST_MODULES = {'test_kernels_gpu', 'test_irblock_gpu', 'test_reduce_batch_gpu', 'test_gemm_variants_gpu', 'test_bn_handover_gpu', 'test_qat_gpu'}
 LAUNCHES_COVERED = set()
 
 

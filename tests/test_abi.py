@@ -38,7 +38,9 @@ def test_struct_layouts_match_the_compiler(lib):
              abi.OP_GCONV_DGRAD: abi.GconvDgrad, abi.OP_GCONV_WGRAD: abi.GconvWgrad, abi.OP_TRANSPOSE: abi.Transpose,
              103: abi.TransposeItem, 104: abi.CreateLabel, 105: abi.QatWeightItem, abi.OP_QAT_WPREP: abi.QatWeight,
              abi.OP_QACT_FWD: abi.Qact, abi.OP_QACT_BWD: abi.QactBwd, abi.OP_POOL_REDUCE: abi.PoolReduce,
-             abi.OP_CONV1X1_BWD: abi.Conv1x1Bwd, abi.OP_BN_EVAL: abi.BnEval, abi.OP_LAYER_FWD: abi.LayerFwd, 106: abi.BnEvalItem, 107: abi.BnStat, 108: abi.Src, 109: abi.BnBstat, 100: abi.Recover, 101: abi.Nms, 102: abi.DecodeBwd}
+             abi.OP_CONV1X1_BWD: abi.Conv1x1Bwd, abi.OP_BN_EVAL: abi.BnEval, abi.OP_LAYER_FWD: abi.LayerFwd, 106: abi.BnEvalItem, 107: abi.BnStat, 108: abi.Src, 109: abi.BnBstat, 100: abi.Recover, 101: abi.Nms, 102: abi.DecodeBwd,
+             abi.OP_XDW_FWD: abi.XdwFwd, abi.OP_XSTAT_FWD: abi.XstatFwd, abi.OP_XDW_BWD: abi.XdwBwd,
+             abi.OP_REDUCE_BATCH: abi.ReduceBatch, 110: abi.ReduceItem}
     for code, st in pairs.items():
         assert lib.pq_abi_sizeof(code) == C.sizeof(st), (code, st.__name__)
 
