@@ -139,6 +139,10 @@ typedef struct pq_gsink {
     uint32_t* stat_bad;
     int32_t stat_slots;
     int32_t pad_;
+    const float* addend; /* with accumulate: the running gradient is READ from here (same pitch ldg) instead of from g -- the first
+                            contribution may live in another tensor's gradient (a linear shortcut passes its output's gradient on
+                            unchanged, model/parser.py:149-156: no copy, no launch).  NULL: read g.  Honoured by every entry with a
+                            pq_gsink except pq_qact_bwd */
 } pq_gsink;
 
 /* ------------------------------------------------------------------ 1x1 convolution = fp32 MFMA GEMM

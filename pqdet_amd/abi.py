@@ -43,7 +43,7 @@ class GSrc(C.Structure):
 class GSink(C.Structure):
     _fields_ = [('g', c_fp), ('y', c_fp), ('scale', c_fp), ('shift', c_fp), ('mean', c_fp), ('invstd', c_fp),
                 ('partial', c_fp), ('ldg', i32), ('ldy', i32), ('act', i32), ('accumulate', i32), ('finalize', i32),
-                ('ldp', i32), ('qstate', c_fp), ('stat_acc', c_fp), ('stat_bad', c_fp), ('stat_slots', i32), ('pad_', i32)]
+                ('ldp', i32), ('qstate', c_fp), ('stat_acc', c_fp), ('stat_bad', c_fp), ('stat_slots', i32), ('pad_', i32), ('addend', c_fp)]
 
 
 class Conv1x1Fwd(C.Structure):

@@ -390,11 +390,13 @@ __device__ __forceinline__ float4 sink_apply4(const pq_gsink& s, const SinkCoef4
     }
     return dz;
 }
+// where an accumulating sink reads the running gradient (pq_gsink.addend: the first contribution may live in another tensor)
+__device__ __forceinline__ const float* sink_old(const pq_gsink& s) { return s.addend ? s.addend : s.g; }
 // Emit 4 channels of one row into the sink; accumulates the two statistics.
 __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k, size_t row, int c0, float4 dz,
                                            float4& s1, float4& s2) {
     float* gp = s.g + row * (size_t)s.ldg + c0;
-    if (s.accumulate) dz = f4add(dz, ldg4(gp));
+    if (s.accumulate) dz = f4add(dz, ldg4(sink_old(s) + row * (size_t)s.ldg + c0));
     float4 y4 = f4zero();
     if (sink_needs_y(s, k)) y4 = ldg4(s.y + row * (size_t)s.ldy + c0);
     stg4(gp, sink_apply4(s, k, dz, y4, s1, s2));
@@ -406,7 +408,7 @@ __device__ __forceinline__ void sink_emit4(const pq_gsink& s, const SinkCoef4& k
 struct SinkOps { float4 y, g; };
 __device__ __forceinline__ SinkOps sink_load4(const pq_gsink& s, const SinkCoef4& k, size_t row, int c0) {
     SinkOps o;
-    o.g = s.accumulate ? ldg4(s.g + row * (size_t)s.ldg + c0) : f4zero();
+    o.g = s.accumulate ? ldg4(sink_old(s) + row * (size_t)s.ldg + c0) : f4zero();
     o.y = sink_needs_y(s, k) ? ldg4(s.y + row * (size_t)s.ldy + c0) : f4zero();
     return o;
 }

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s2_kernel(DwWP p) {
                 if (cok && y < yend && x < p.IW) {
                     const size_t r = ximg + (size_t)y * p.IW + x;
                     float4 d = dxv[dyy][u];
-                    if (p.sink.accumulate) d = f4add(d, ldg4(p.sink.g + r * p.sink.ldg + c0));
+                    if (p.sink.accumulate) d = f4add(d, ldg4(sink_old(p.sink) + r * p.sink.ldg + c0));
                     stg4(p.sink.g + r * p.sink.ldg + c0, sink_apply4(p.sink, sk, d, raw, s1, s2));
                 }
             }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_walk_s1_kernel(DwWP p) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const size_t r = img + (size_t)min(y0 + 2 * rp + u, p.IH - 1) * p.IW + min(x0 + col, p.IW - 1);
-                dx[u] = f4add(dx[u], ldg4(p.sink.g + r * p.sink.ldg + cc));
+                dx[u] = f4add(dx[u], ldg4(sink_old(p.sink) + r * p.sink.ldg + cc));
             }
         }
         {

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GcP p) {
             const int oy = min(oy0 + (q >> 4), p.OH - 1), ox = min(ox0 + (q & 15), p.OW - 1);
             const size_t row = ((size_t)b * p.OH + oy) * p.OW + ox;
             yv[r] = need_y ? sk.y[row * sk.ldy + ch] : 0.f;
-            gv[r] = sk.accumulate ? sk.g[row * sk.ldg + ch] : 0.f;
+            gv[r] = sk.accumulate ? sink_old(sk)[row * sk.ldg + ch] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(GcP p) {
             const int iy = min(iy0 + 2 * (q >> 4) + pi, p.OH - 1), ix = min(ix0 + 2 * (q & 15) + pj, p.OW - 1);
             const size_t row = ((size_t)b * p.OH + iy) * p.OW + ix;
             yv[r] = need_y ? sk.y[row * sk.ldy + ch] : 0.f;
-            gv[r] = sk.accumulate ? sk.g[row * sk.ldg + ch] : 0.f;
+            gv[r] = sk.accumulate ? sink_old(sk)[row * sk.ldg + ch] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
                         srow[r] = ((size_t)bb * p.IH + (size_t)oy * p.sub) * p.IW + (size_t)ox * p.sub;
                     }
                     yv[r] = need_y ? sk.y[srow[r] * sk.ldy + nc] : 0.f;
-                    gv[r] = sk.accumulate ? sk.g[srow[r] * sk.ldg + nc] : 0.f;
+                    gv[r] = sk.accumulate ? sk.addend[srow[r] * sk.ldg + nc] : 0.f;      // (never NULL here: normalised by the host)
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -807,6 +807,7 @@ static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_g
     p.sub = a->sub > 1 ? a->sub : 1; p.OH = a->OH; p.OW = a->OW; p.IH = a->IH; p.IW = a->IW;
     p.b = a->w; p.ldb = a->I; p.M = a->M; p.N = a->I; p.K = a->O;
     p.sink = a->dx;
+    if (!p.sink.addend) p.sink.addend = p.sink.g;      // the kernels of THIS file read the running gradient through `addend` (no select: SGPRs)
     if (a->dy_stat.acc && !plan) {
         PQ_CHECK_ARG(a->dy.y && a->dy.mu && a->dy_stat.bad && a->dy_stat.gamma && a->dy_stat.invstd && a->dy_stat.dgamma && a->dy_stat.dbeta &&
                      a->dy_stat.p && a->dy_stat.q && a->dy_stat.r && a->dy_stat.count > 0.f && a->dy_stat.ldp >= a->O && a->dy_stat.slots <= 4,

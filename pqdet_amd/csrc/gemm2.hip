@@ -650,6 +650,7 @@ int g2_conv1x1_dgrad(const pq_conv1x1_dgrad_args* a, int bm, hipStream_t st, pq_
     p.c0 = a->dy.p; p.c1 = a->dy.q; p.c2 = a->dy.mu; p.c3 = a->dy.r;
     p.b = a->wt; p.ldb = a->O; p.M = a->M; p.N = a->I; p.K = a->O;      // O % 16 == 0: the transposed rows have no pad
     p.sink = a->dx;
+    if (!p.sink.addend) p.sink.addend = p.sink.g;      // gemm_epi.h reads the running gradient through `addend`
     p.stat_acc = a->dx.stat_acc; p.stat_bad = a->dx.stat_bad; p.stat_slots = a->dx.stat_slots > 0 ? a->dx.stat_slots : 1;   // (checked by the caller)
     const bool from_bstat = a->dy_stat.acc != nullptr;       // (the caller checked the record)
     if (from_bstat && (!a->dy.y || a->O > G2_STAT_KMAX)) return 0;

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, OCC) void pw_bwd_kernel(PwP p) {
                     const int u = min(u0 + v, NX - 1), r = min(iy + u * PYi, PW_BM - 1);
                     const size_t m = (size_t)min(m0 + r, p.M - 1);
                     go[v] = f4zero(); yv[v] = f4zero();
-                    if (p.dx.accumulate) go[v] = ldg4(p.dx.g + m * p.dx.ldg + 4 * ix);
+                    if (p.dx.accumulate) go[v] = ldg4(sink_old(p.dx) + m * p.dx.ldg + 4 * ix);
                     if (same_y) yv[v] = xraw[KEEP ? u : 0];
                     else if (need_y) yv[v] = ldg4(p.dx.y + m * p.dx.ldy + 4 * ix);
                 }

@@ -291,6 +291,7 @@ extern "C" int pq_qact_fwd(const pq_qact_args* a, void* stream) {
 extern "C" int pq_qact_bwd(const pq_qact_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->gq && a->dx.g && a->dx.y && a->state, "null pointer");
     PQ_SINK_ACC_UNSUPPORTED(a->dx);
+    PQ_CHECK_ARG(a->dx.addend == nullptr, "dx.addend is not supported by this entry");
     PQ_CHECK_ARG(a->rows > 0 && a->C > 0 && (a->C & 3) == 0 && (a->ldgq & 3) == 0 && (a->dx.ldg & 3) == 0 && (a->dx.ldy & 3) == 0,
                  "channels / pitches must be multiples of 4");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_qact_bwd: logistic/tanh are not part of the QAT model"); return PQ_EUNSUPPORTED; }

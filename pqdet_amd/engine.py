@@ -213,7 +213,7 @@ class Plan:
         lst.append(op)
         return len(lst) - 1
 
-    def _sink(self, t: TensorRef, nblk: int) -> abi.GSink:
+    def _sink(self, t: TensorRef, nblk: int, addend_ok: bool = True) -> abi.GSink:
         inner = getattr(t, 'fuse_inner', None)
         if inner is not None:
             # QAT, conv output consumed only through gradient sinks: the consumers write straight into the producer's
@@ -235,21 +235,44 @@ class Plan:
                              ptr(bn.mean) if stats else None, ptr(bn.invstd) if stats else None,
                              ptr(bn.bwd_partial) if stats else None, inner.ld, inner.ld, inner.act, int(accumulate),
                              int(finalize), bn.ldp if bn else 0, self._qstate(t.fuse_key) if self.q_quant else None)
+        pend = getattr(t, 'addend', None)
+        if pend is not None and not addend_ok:
+            self._flush_addend(t)
+            pend = None
         if t.grad is None:
             t.grad = self._new(t.rows, t.ld, fill=0.0) if t.ld != t.C else self._new(t.rows, t.ld)
         accumulate = t.received > 0
         finalize = (t.received + 1 == t.n_consumers)
         t.received += 1
-        stats = finalize and t.bn is not None           # frozen statistics still need the sums: they ARE dgamma / dbeta
+        # folded linear shortcut (see _fold_shortcuts): t = a' + b' with a = conv + BatchNorm, no activation.  dL/da' IS dL/dt, so a's
+        # gradient is t's buffer and the sink that finalises t emits a's BatchNorm-backward sums (y = a's raw output)
+        ys = getattr(t, 'fold_sa', None) or t
+        stats = finalize and ys.bn is not None          # frozen statistics still need the sums: they ARE dgamma / dbeta
         if stats:
-            b = t.bn
+            b = ys.bn
             b.bwd_nblk = nblk
             b.bwd_partial = self._new(nblk * 2 * b.ldp)
-        bn = t.bn
-        return abi.GSink(ptr(t.grad), ptr(t.raw), ptr(bn.scale) if bn else None, ptr(bn.shift) if bn else None,
-                         ptr(bn.mean) if stats else None, ptr(bn.invstd) if stats else None,
-                         ptr(bn.bwd_partial) if stats else None, t.ld, t.ld, t.act, int(accumulate), int(finalize),
-                         bn.ldp if bn else 0)
+        if ys is not t:
+            ys.grad = t.grad
+            if finalize:
+                ys.received = ys.n_consumers
+        bn = ys.bn
+        sk = abi.GSink(ptr(t.grad), ptr(ys.raw), ptr(bn.scale) if bn else None, ptr(bn.shift) if bn else None,
+                       ptr(bn.mean) if stats else None, ptr(bn.invstd) if stats else None,
+                       ptr(bn.bwd_partial) if stats else None, t.ld, ys.ld, ys.act, int(accumulate), int(finalize),
+                       bn.ldp if bn else 0)
+        if pend is not None:             # the first contribution lives in another tensor's gradient: read it there, write here
+            sk.addend = ptr(pend)
+            t.addend = None
+        return sk
+
+    def _flush_addend(self, t: TensorRef):
+        """A pending addend (folded shortcut) in front of a sink that cannot read it from another tensor: copy it."""
+        if t.grad is None:
+            t.grad = self._new(t.rows, t.ld, fill=0.0) if t.ld != t.C else self._new(t.rows, t.ld)
+        sk = abi.GSink(ptr(t.grad), ptr(t.raw), None, None, None, None, None, t.ld, t.ld, 0, 0, 0, 0)
+        self._op(self.bwd, abi.OP_ROUTE_BWD, abi.RouteBwd(ptr(t.addend), sk, t.B, t.H, t.W, t.C, t.ld, 0, 1))
+        t.addend = None
 
     # ------------------------------------------------------------------------------------------ build
     def _build(self):
@@ -575,6 +598,22 @@ class Plan:
         for i_, n_ in consumers.items():
             T[i_].n_consumers = n_
         self._consumers = dict(consumers)
+        # Folded backward of LINEAR shortcuts (mobilenetv2: t = a' + b', a = project conv + BatchNorm, no activation on either):
+        # dL/da' = dL/db' = dL/dt.  Instead of a pass that copies dL/dt into a's gradient (with a's BatchNorm-backward sums) and adds
+        # it to b's (pq_route_bwd with two sinks: four tensor passes and a launch per block on the main chain), a's gradient IS t's
+        # buffer -- the sink that finalises t emits a's sums (_sink) -- and b's finalising sink reads its first contribution from t's
+        # gradient (pq_gsink.addend).  PQ_SCFOLD=0 switches it off.
+        self.sc_folded = 0
+        if train_graph and not self.qat and os.environ.get('PQ_SCFOLD', '1') != '0':
+            for i_, m_ in enumerate(mods):
+                if m_._type != 'shortcut':
+                    continue
+                out_, sa_, sb_ = T[i_], T[resolve(i_ - 1, i_)], T[resolve(m_._from, i_)]
+                if out_.act == 0 and out_.bn is None and sa_ is not sb_ and sa_.bn is not None and sa_.act == 0 and \
+                        sa_.n_consumers == 1 and sa_.ld == out_.ld and sa_.C % 4 == 0 and out_.n_consumers > 0 and \
+                        mods[resolve(i_ - 1, i_)]._type == 'convolutional':
+                    out_.fold_sa = sa_
+                    self.sc_folded += 1
         if self.qat:
             # conv outputs that only feed other layers are never materialised in quantised form: consumers fake-quantise while
             # loading (pq_src.qstate) and their gradient sinks apply the straight-through mask (pq_gsink.qstate)
@@ -1175,7 +1214,7 @@ class Plan:
                                 # strided 1x1: dz only lands on every s-th pixel.  The GEMM accumulates into a (zeroed if it
                                 # is the first contribution) gradient plane; if it was the last contribution an in-place
                                 # element-wise pass finalises the whole plane (activation derivative + BN sums).
-                                sk = self._sink(src, l.pq_ew_blocks(src.rows, src.C))
+                                sk = self._sink(src, l.pq_ew_blocks(src.rows, src.C), addend_ok=False)
                                 if not sk.accumulate:
                                     self._op(self.bwd, abi.OP_FILL, abi.Fill(ptr(src.grad), 0.0, src.rows * src.ld))
                                 acc = abi.GSink(sk.g, sk.y, None, None, None, None, None, src.ld, src.ld, 0, 1, 0, 0)
@@ -1243,7 +1282,17 @@ class Plan:
                 if self.qat and out.grad is not None:
                     self._qact_bwd(out, self._inner[i], ('a', i))
                     out = self._inner[i]
-                if out.grad is not None:
+                if out.grad is not None and getattr(out, 'fold_sa', None) is not None:
+                    sa, sb = T[resolve(i - 1, i)], T[resolve(m._from, i)]
+                    if sa.grad is None or sa.received != sa.n_consumers:
+                        raise RuntimeError('internal: folded shortcut %d: the gradient of its conv branch was never finalised' % i)
+                    if sb.grad is None and sb.received == 0 and sb.n_consumers > 1 and getattr(sb, 'addend', None) is None:
+                        sb.addend = out.grad             # read by b's next sink (pq_gsink.addend): no launch here
+                        sb.received += 1
+                    else:
+                        r = abi.RouteBwd(ptr(out.grad), self._sink(sb, l.pq_ew_blocks(sb.rows, sb.C)), sb.B, sb.H, sb.W, sb.C, out.ld, 0, 1)
+                        self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+                elif out.grad is not None:
                     sa, sb = T[resolve(i - 1, i)], T[resolve(m._from, i)]
                     if sa is not sb and sa.C % 4 == 0 and not self.qat:
                         # both addends receive the sum's gradient: ONE pass over it feeds the two sinks (pq_route_bwd dx2)

@@ -184,6 +184,7 @@ def test_xstat_fwd_equals_batchnorm_statistics_of_the_expanded_tensor(M, I, E, x
 @pytest.mark.parametrize('B,H,W,I,E,stride,affine,accumulate', [
     (2, 16, 32, 24, 144, 1, True, 0),
     (1, 22, 24, 24, 144, 1, False, 1),      # rows that are not a whole number of steps; residual block: running gradient in the sink
+    (1, 22, 24, 24, 144, 1, True, 2),       # ... the running gradient lives in ANOTHER tensor (pq_gsink.addend: folded shortcut)
     (2, 16, 32, 16, 96, 2, True, 0),
     (1, 24, 40, 24, 144, 2, True, 0),
     (2, 34, 20, 24, 144, 1, True, 0),       # partial strip (20 columns), several segments
@@ -229,7 +230,8 @@ def test_xdw_bwd_matches_autograd_through_expand_batchnorm_relu6_depthwise(B, H,
     assert mom.dtype == torch.float64
     nfix = l.pq_xdw_bwd_fix_blocks(M, I)
     ldp = 32
-    gdst = prev.to(DEV).clone() if accumulate else torch.full((B, H, W, I), float('nan'), device=DEV)
+    gdst = prev.to(DEV).clone() if accumulate == 1 else torch.full((B, H, W, I), float('nan'), device=DEV)
+    addend = prev.to(DEV).clone() if accumulate == 2 else None
     partial = torch.full((nfix * 2 * ldp,), float('nan'), device=DEV)
     assert l.pq_xdw_bwd_blocks(B, H, W, I, E, stride) > 0
     scratch = torch.full((l.pq_xdw_bwd_scratch_bytes(B, H, W, I, E, stride) // 4,), float('nan'), device=DEV)
@@ -243,7 +245,8 @@ def test_xdw_bwd_matches_autograd_through_expand_batchnorm_relu6_depthwise(B, H,
     a.mid_act = 2
     a.dy = abi.GSrc(gdd.data_ptr(), ydd.data_ptr(), *[v.data_ptr() for v in v_d], E, E)
     a.dx = abi.GSink(gdst.data_ptr(), xd.data_ptr(), v_x[0].data_ptr() if affine else None, v_x[1].data_ptr() if affine else None,
-                     v_x[2].data_ptr(), v_x[3].data_ptr(), partial.data_ptr(), I, I, 0, accumulate, 1, ldp)
+                     v_x[2].data_ptr(), v_x[3].data_ptr(), partial.data_ptr(), I, I, 0, int(accumulate > 0), 1, ldp)
+    a.dx.addend = abi.ptr(addend)
     a.dwe, a.dwd, a.dgamma, a.dbeta = [o.data_ptr() for o in outs]
     a.moments, a.scratch, a.gexp, a.ldge = mom.data_ptr(), scratch.data_ptr(), gexp.data_ptr(), E
     a.B, a.IH, a.IW, a.OH, a.OW, a.I, a.E, a.stride = B, H, W, OH, OW, I, E, stride

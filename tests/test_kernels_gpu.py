@@ -60,6 +60,22 @@ def gemm_plan(kind, args, expect=None):
     return pl.key()
 
 
+ADDEND = [False]     # test_accumulating_sinks_read_their_addend: the accumulate cases once more, first contribution in another tensor
+
+
+def acc_dst(old_dev):
+    """(gradient buffer, address for pq_gsink.addend) of an accumulating sink: the running gradient in place (addend NULL) or, in
+    the addend variant, in a tensor of its own with the destination NaN-filled (it must not be read)."""
+    if ADDEND[0]:
+        dst = torch.full_like(old_dev, float('nan'))
+        ACC_KEEP.append(old_dev)
+        return dst, old_dev.data_ptr()
+    return old_dev, None
+
+
+ACC_KEEP = []
+
+
 def rnd(*shape, g, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
@@ -242,7 +258,7 @@ def check_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=
     youtd = torch.zeros(M, ldg, device=DEV)
     youtd[:, :O] = yout.to(DEV)
     wd, yind = w.to(DEV), yin.to(DEV)
-    gdst = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
+    gdst, addp = acc_dst(old.to(DEV).clone()) if accum else (torch.full((M, I), float('nan'), device=DEV), None)
     nblk = abi.lib().pq_conv1x1_blocks_k(M, I, O, 1)
     ldp = (I + 15) // 16 * 16
     partial = torch.zeros(nblk * 2 * ldp, device=DEV)
@@ -254,6 +270,7 @@ def check_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=
     a.dx = abi.GSink(gdst.data_ptr(), yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
                      sv[2].data_ptr() if stats else None, sv[3].data_ptr() if stats else None,
                      partial.data_ptr() if stats else None, I, I, act, int(accum), 1, ldp)
+    a.dx.addend = addp
     a.M, a.I, a.O = M, I, O
     plans = [gemm_plan('dgrad', a, expect)]
     abi.check(abi.lib().pq_conv1x1_dgrad(C.byref(a), stream()))
@@ -273,8 +290,9 @@ def check_conv1x1_dgrad(M, I, O, two, act, accum, stats, expect=None, expect_wt=
         abi.check(abi.lib().pq_transpose_batch(C.byref(tr), stream()))
         torch.cuda.synchronize()
         assert torch.equal(wt[:, :O], wd.t()) and bool((wt[:, O:] == 0).all())
-        g2 = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
+        g2, addp2 = acc_dst(old.to(DEV).clone()) if accum else (torch.full((M, I), float('nan'), device=DEV), None)
         a.dx.g = g2.data_ptr()
+        a.dx.addend = addp2
         a.wt = wt.data_ptr()
         partial.zero_()
         plans.append(gemm_plan('dgrad', a, expect_wt))
@@ -389,16 +407,18 @@ def test_conv1x1_bwd_fused_matches_the_two_kernel_backward(M, I, O, two, act, ac
     dyarg = abi.GSrc(gyd.data_ptr(), youtd.data_ptr() if two else None, *([v.data_ptr() for v in vecs] if two else [None] * 4), O, O)
     inarg = abi.Src(yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(), I, act)
 
-    def sink(gdst, partial):
-        return abi.GSink(gdst.data_ptr(), yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
-                         sv[2].data_ptr() if stats else None, sv[3].data_ptr() if stats else None,
-                         partial.data_ptr() if stats else None, I, I, act, int(accum), 1, ldp)
+    def sink(gdst, partial, addp=None):
+        k = abi.GSink(gdst.data_ptr(), yind.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
+                      sv[2].data_ptr() if stats else None, sv[3].data_ptr() if stats else None,
+                      partial.data_ptr() if stats else None, I, I, act, int(accum), 1, ldp)
+        k.addend = addp
+        return k
 
-    gdst = old.to(DEV).clone() if accum else torch.full((M, I), float('nan'), device=DEV)
+    gdst, addp = acc_dst(old.to(DEV).clone()) if accum else (torch.full((M, I), float('nan'), device=DEV), None)
     partial = torch.full((nblk * 2 * ldp,), float('nan'), device=DEV)
     dw = torch.full((O, I), float('nan'), device=DEV)
     scratch = torch.empty(l.pq_conv1x1_bwd_scratch_bytes(M, I, O) // 4, device=DEV)
-    a = abi.Conv1x1Bwd(dyarg, wd.data_ptr(), inarg, sink(gdst, partial), dw.data_ptr(), scratch.data_ptr(), M, I, O)
+    a = abi.Conv1x1Bwd(dyarg, wd.data_ptr(), inarg, sink(gdst, partial, addp), dw.data_ptr(), scratch.data_ptr(), M, I, O)
     abi.check(l.pq_conv1x1_bwd(C.byref(a), stream()))
     torch.cuda.synchronize()
     close(gdst, gout, what='fused dgrad sink')
@@ -588,8 +608,8 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
     assert nbw > 0
     prev = rnd(B, H, W, Cc, g=g)
     for accumulate in (0, 1):
-        gw_ = padc(prev) if accumulate else torch.full((B, H, W, P), float('nan'), device=DEV)
-        if not accumulate:
+        gw_, addp = acc_dst(padc(prev)) if accumulate else (torch.full((B, H, W, P), float('nan'), device=DEV), None)
+        if not accumulate or addp:
             gw_[..., Cc:] = 0                     # pad lanes are zero at allocation in the engine
         pw = torch.full((nbw * 2 * ldp,), float('nan'), device=DEV)
         scw = torch.full((nbw * Cc * 9 + 16,), float('nan'), device=DEV)
@@ -597,6 +617,7 @@ def test_dw3x3_fwd_bwd(B, H, W, Cc, stride):
         f5 = abi.DwBwd(d.dy, a.inp, wd.data_ptr(), abi.GSink(gw_.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(),
                                                               sv[1].data_ptr(), pw.data_ptr(), P, P, 2, accumulate, 1, ldp),
                        None, scw.data_ptr(), B, H, W, OH, OW, Cc, stride, 5)
+        f5.dx.addend = addp
         abi.check(l.pq_dw3x3_bwd(C.byref(f5), stream()))
         f6 = abi.DwBwd(abi.GSrc(), abi.Src(), None, abi.GSink(), dww.data_ptr(), scw.data_ptr(), B, H, W, OH, OW, Cc, stride, 6)
         abi.check(l.pq_dw3x3_bwd(C.byref(f6), stream()))
@@ -664,7 +685,7 @@ def test_gconv3x3_fwd_bwd(B, H, W, Cc, gw, stride):
     sv = [chan_vec(v) for v in (mean_in, inv_in)]
     for accumulate in (0, 1):
         prev = rnd(B, H, W, Cc, g=g) if accumulate else None
-        gdst = prev.to(DEV).clone() if accumulate else torch.full((B, H, W, Cc), float('nan'), device=DEV)
+        gdst, addp = acc_dst(prev.to(DEV).clone()) if accumulate else (torch.full((B, H, W, Cc), float('nan'), device=DEV), None)
         nb2 = l.pq_gconv3x3_blocks(B, H, W)
         part2 = torch.zeros(nb2 * 2 * ldp, device=DEV)
         d = abi.GconvDgrad()
@@ -672,6 +693,7 @@ def test_gconv3x3_fwd_bwd(B, H, W, Cc, gw, stride):
         d.w = wd.data_ptr()
         d.dx = abi.GSink(gdst.data_ptr(), xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), sv[0].data_ptr(), sv[1].data_ptr(),
                          part2.data_ptr(), Cc, Cc, 1, accumulate, 1, ldp)
+        d.dx.addend = addp
         d.B, d.IH, d.IW, d.OH, d.OW, d.C, d.gw, d.stride = B, H, W, OH, OW, Cc, gw, stride
         abi.check(l.pq_gconv3x3_dgrad(C.byref(d), stream()))
         torch.cuda.synchronize()
@@ -958,11 +980,12 @@ def test_route_bwd_two_sinks_equals_two_calls(B, H, W, Cc):
 
     def sinks():
         g1 = torch.full((rows, Cc), float('nan'), device=DEV)
-        g2 = old2.clone()
+        g2, addp = acc_dst(old2.clone())
         p1, p2 = torch.zeros(nblk * 2 * ldp, device=DEV), torch.zeros(nblk * 2 * ldp, device=DEV)
         k1 = abi.GSink(g1.data_ptr(), y1.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr(), p1.data_ptr(),
                        Cc, Cc, 2, 0, 1, ldp)
         k2 = abi.GSink(g2.data_ptr(), y2.data_ptr(), None, None, mean.data_ptr(), inv.data_ptr(), p2.data_ptr(), Cc, Cc, 0, 1, 1, ldp)
+        k2.addend = addp
         return g1, g2, p1, p2, k1, k2
     g1, g2, p1, p2, k1, k2 = sinks()
     for k in (k1, k2):
@@ -1423,3 +1446,30 @@ def test_layer_fwd_pools_im2col_fc_act(B, H, W, Cc, act):
     abi.check(l.pq_layer_fwd(C.byref(a), stream()))
     torch.cuda.synchronize()
     assert torch.equal(out[:, :147], wsrc) and bool((out[:, 147:] == 0).all())
+
+
+
+@pytest.mark.parametrize('case', [
+    ('dgrad', (1000, 144, 24, True, 0, True, True)),              # register-staged family
+    ('dgrad', (4000, 320, 1280, True, 0, True, True)),            # ring kernels, split-K shape
+    ('dgrad', (1000, 240, 80, True, 0, True, True)),
+    ('dgrad', (130, 96, 576, True, 0, True, False)),
+    ('pw', (33000, 32, 16, True, 0, True, True)), ('pw', (33000, 16, 144, True, 2, True, True)), ('pw', (33000, 176, 24, True, 2, True, True)),
+    ('dw', (2, 9, 13, 32, 1)), ('dw', (2, 40, 36, 48, 2)), ('dw', (2, 70, 66, 25, 1)),
+    ('gconv', (2, 9, 13, 48, 24, 1)), ('gconv', (2, 12, 12, 96, 16, 2)),
+    ('route', (2, 32, 32, 96)),
+], ids=lambda c: '%s-%s' % (c[0], '-'.join(str(v) for v in c[1])))
+def test_accumulating_sinks_read_their_addend(case):
+    """pq_gsink.addend: an accumulating sink reads the running gradient from ANOTHER tensor (a folded linear shortcut hands its
+    output's gradient on without a copy, reference model/parser.py:149-156) and writes its own.  The accumulate cases of the entries'
+    own tests once more with the first contribution in a separate tensor and the destination NaN-filled."""
+    kind, args = case
+    fn = {'dgrad': check_conv1x1_dgrad, 'pw': test_conv1x1_bwd_fused_matches_the_two_kernel_backward, 'dw': test_dw3x3_fwd_bwd,
+          'gconv': test_gconv3x3_fwd_bwd, 'route': test_route_bwd_two_sinks_equals_two_calls}[kind]
+    ADDEND[0] = True
+    try:
+        fn(*args)
+        assert ACC_KEEP, 'the case has no accumulating sink'
+    finally:
+        ADDEND[0] = False
+        ACC_KEEP.clear()
