@@ -127,7 +127,9 @@ typedef struct pq_gsink {
     int32_t ldy;
     int32_t act;
     int32_t accumulate;
-    int32_t finalize;
+    int32_t finalize;    /* 1: last contribution -- apply act'(y), emit the BatchNorm-backward sums; 3 (pq_route_bwd and the other
+                            element-wise sinks only): the same WITHOUT the store -- g already holds exactly this gradient (it is the call's
+                            gout: a shortcut whose conv branch uses the sum's gradient buffer as its own), only the sums are wanted */
     int32_t ldp;
     const float* qstate; /* QAT: T is consumed as fake_quant(act(...)) with this observer state {min,max,scale,zp}: finalize also
                             applies the straight-through mask (0 where the value falls outside [0,255] steps).  NULL otherwise */

@@ -355,7 +355,23 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteP p) {
         if (part2) block_reduce_store_stats<256>(t1, t2, part2, a.dx2.ldp, c0, a.C, lds, bx, 2, sink_acc(a.dx2));
         return;
     }
-    if (!a.bcast && a.up == 1 && !a.gate && !p.unal) {
+    if ((a.dx.finalize & 2) && !a.bcast && a.up == 1 && !a.gate && !p.unal) {
+        // statistics only (finalize = 3): g already holds this gradient (it IS gout: the conv branch of a shortcut with an activation
+        // uses the sum's gradient buffer), only the BatchNorm-backward sums over (gout, y) are wanted -- two reads per element, no store
+        constexpr int U = 4;
+        for (int r0 = bx * blockDim.y + threadIdx.y; r0 < rows && cok; r0 += U * stride) {
+            float4 dz[U], yv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t r = (size_t)min(r0 + u * stride, rows - 1);
+                dz[u] = ldg4(a.gout + r * a.ldgo + a.coff + c0);
+                yv[u] = ldg4(a.dx.y + r * (size_t)a.dx.ldy + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (r0 + u * stride < rows) (void)sink_apply4(a.dx, sk, dz[u], yv[u], s1, s2);
+        }
+    } else if (!a.bcast && a.up == 1 && !a.gate && !p.unal) {
         // the common case (shortcut / route / strided-projection finalize): four rows per step, the upstream gradient AND the
         // sink's operands of all four in flight before the first store
         constexpr int U = 4;
@@ -601,6 +617,12 @@ extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a->ldgo % 4 == 0 && a->dx.ldg % 4 == 0, "pitches must be multiples of 4");
     PQ_CHECK_ARG(!(a->gate || a->bcast) || (a->C % 4 == 0 && a->coff % 4 == 0), "gated / broadcast routing needs multiples of 4");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
+    if (a->dx.finalize & 2) {       // statistics only: dx.g already holds gout (the same buffer), nothing is stored
+        PQ_CHECK_ARG(a->dx.g == a->gout + a->coff && a->dx.ldg == a->ldgo && !a->dx.accumulate && a->dx.act == PQ_ACT_LINEAR && a->dx.mean &&
+                     a->dx.partial && a->dx.y && !a->dx2.g && a->up == 1 && !a->gate && !a->bcast && (a->C & 3) == 0 && (a->coff & 3) == 0 &&
+                     (a->dx.ldy & 3) == 0 && !a->dx.qstate,
+                     "finalize = 3 (statistics only): in-place linear sink with statistics, plain routing of a multiple of 4 channels");
+    }
     if (a->dx2.g) {
         PQ_CHECK_ARG(a->up == 1 && !a->gate && !a->bcast && (a->C & 3) == 0 && (a->coff & 3) == 0 && a->dx2.ldg % 4 == 0,
                      "two sinks: plain routing of a multiple of 4 channels only");

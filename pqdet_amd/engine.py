@@ -603,17 +603,25 @@ class Plan:
         # it to b's (pq_route_bwd with two sinks: four tensor passes and a launch per block on the main chain), a's gradient IS t's
         # buffer -- the sink that finalises t emits a's sums (_sink) -- and b's finalising sink reads its first contribution from t's
         # gradient (pq_gsink.addend).  PQ_SCFOLD=0 switches it off.
-        self.sc_folded = 0
+        self.sc_folded = self.sc_aliased = 0
         if train_graph and not self.qat and os.environ.get('PQ_SCFOLD', '1') != '0':
             for i_, m_ in enumerate(mods):
                 if m_._type != 'shortcut':
                     continue
                 out_, sa_, sb_ = T[i_], T[resolve(i_ - 1, i_)], T[resolve(m_._from, i_)]
-                if out_.act == 0 and out_.bn is None and sa_ is not sb_ and sa_.bn is not None and sa_.act == 0 and \
+                if out_.bn is None and sa_ is not sb_ and sa_.bn is not None and sa_.act == 0 and \
                         sa_.n_consumers == 1 and sa_.ld == out_.ld and sa_.C % 4 == 0 and out_.n_consumers > 0 and \
                         mods[resolve(i_ - 1, i_)]._type == 'convolutional':
-                    out_.fold_sa = sa_
-                    self.sc_folded += 1
+                    if out_.act == 0:
+                        out_.fold_sa = sa_
+                        self.sc_folded += 1
+                    elif out_.act in (1, 2, 3):
+                        # an activation behind the sum (RegNet: ReLU): the sum's sinks need the sum's own y for act', so they cannot
+                        # emit the conv branch's BatchNorm sums -- but the gradient w.r.t. the raw sum is still the gradient of both
+                        # addends: the conv branch uses the sum's buffer, ONE statistics-only pass (pq_route_bwd, finalize = 3: two
+                        # reads, no store) replaces the six tensor passes of the two-sink launch, the other addend reads it as addend
+                        out_.alias_sa = sa_
+                        self.sc_aliased += 1
         if self.qat:
             # conv outputs that only feed other layers are never materialised in quantised form: consumers fake-quantise while
             # loading (pq_src.qstate) and their gradient sinks apply the straight-through mask (pq_gsink.qstate)
@@ -1288,6 +1296,23 @@ class Plan:
                         raise RuntimeError('internal: folded shortcut %d: the gradient of its conv branch was never finalised' % i)
                     if sb.grad is None and sb.received == 0 and sb.n_consumers > 1 and getattr(sb, 'addend', None) is None:
                         sb.addend = out.grad             # read by b's next sink (pq_gsink.addend): no launch here
+                        sb.received += 1
+                    else:
+                        r = abi.RouteBwd(ptr(out.grad), self._sink(sb, l.pq_ew_blocks(sb.rows, sb.C)), sb.B, sb.H, sb.W, sb.C, out.ld, 0, 1)
+                        self._op(self.bwd, abi.OP_ROUTE_BWD, r)
+                elif out.grad is not None and getattr(out, 'alias_sa', None) is not None:
+                    sa, sb = T[resolve(i - 1, i)], T[resolve(m._from, i)]
+                    if sa.grad is not None or sa.received:
+                        raise RuntimeError('internal: aliased shortcut %d: its conv branch already has a gradient' % i)
+                    sa.grad, sa.received = out.grad, sa.n_consumers
+                    b = sa.bn
+                    b.bwd_nblk = l.pq_ew_blocks(sa.rows, sa.C)
+                    b.bwd_partial = self._new(b.bwd_nblk * 2 * b.ldp)
+                    sk = abi.GSink(ptr(out.grad), ptr(sa.raw), ptr(b.scale), ptr(b.shift), ptr(b.mean), ptr(b.invstd), ptr(b.bwd_partial),
+                                   out.ld, sa.ld, sa.act, 0, 3, b.ldp)
+                    self._op(self.bwd, abi.OP_ROUTE_BWD, abi.RouteBwd(ptr(out.grad), sk, sa.B, sa.H, sa.W, sa.C, out.ld, 0, 1))
+                    if sb.grad is None and sb.received == 0 and sb.n_consumers > 1 and getattr(sb, 'addend', None) is None:
+                        sb.addend = out.grad
                         sb.received += 1
                     else:
                         r = abi.RouteBwd(ptr(out.grad), self._sink(sb, l.pq_ew_blocks(sb.rows, sb.C)), sb.B, sb.H, sb.W, sb.C, out.ld, 0, 1)

@@ -1001,6 +1001,39 @@ def test_route_bwd_two_sinks_equals_two_calls(B, H, W, Cc):
     close(h2, old2.cpu() + gout.cpu(), what='two-sink route: accumulating sink')
 
 
+@pytest.mark.parametrize('B,H,W,Cc', [(2, 9, 13, 24), (2, 32, 32, 96), (4, 64, 64, 48)])
+def test_route_bwd_statistics_only_sink(B, H, W, Cc):
+    """finalize = 3: the sink's tensor already holds the gradient (it is gout itself -- the conv branch of a shortcut with an
+    activation behind the sum uses the sum's gradient buffer, reference model/parser.py:149-156): only the BatchNorm-backward sums
+    are produced, bit-identical to those of an ordinary finalising sink, and nothing is written."""
+    l = abi.lib()
+    g = torch.Generator().manual_seed(B * H * W + Cc + 3)
+    rows = B * H * W
+    gout = rnd(rows, Cc, g=g).to(DEV)
+    y = rnd(rows, Cc, g=g).to(DEV) * 2 + 1
+    sc, sh = chan_vec(torch.rand(Cc, generator=g) + 0.5), chan_vec(rnd(Cc, g=g, scale=0.5))
+    mean, inv = chan_vec(rnd(Cc, g=g)), chan_vec(torch.rand(Cc, generator=g) + 0.5)
+    nblk, ldp = l.pq_ew_blocks(rows, Cc), (Cc + 15) // 16 * 16
+    dst = torch.full((rows, Cc), float('nan'), device=DEV)
+    p1, p2 = torch.zeros(nblk * 2 * ldp, device=DEV), torch.zeros(nblk * 2 * ldp, device=DEV)
+    k1 = abi.GSink(dst.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr(), p1.data_ptr(), Cc, Cc, 0, 0, 1, ldp)
+    abi.check(l.pq_route_bwd(C.byref(abi.RouteBwd(gout.data_ptr(), k1, B, H, W, Cc, Cc, 0, 1)), stream()))
+    keep = gout.clone()
+    k2 = abi.GSink(gout.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr(), p2.data_ptr(), Cc, Cc, 0, 0, 3, ldp)
+    abi.check(l.pq_route_bwd(C.byref(abi.RouteBwd(gout.data_ptr(), k2, B, H, W, Cc, Cc, 0, 1)), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dst, keep) and torch.equal(gout, keep) and torch.equal(p1, p2)
+    s1, s2 = reduce_partial(p2, nblk, ldp, Cc)
+    xh = (y.cpu().double() - mean[:Cc].cpu().double()) * inv[:Cc].cpu().double()
+    close(s1.float(), keep.cpu().double().sum(0).float(), rt=1e-3, at=1e-2, what='sum g')
+    close(s2.float(), (keep.cpu().double() * xh).sum(0).float(), rt=1e-3, at=1e-2, what='sum g*xhat')
+    # not in place / with an activation: refused
+    k3 = abi.GSink(dst.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr(), p2.data_ptr(), Cc, Cc, 0, 0, 3, ldp)
+    assert l.pq_route_bwd(C.byref(abi.RouteBwd(gout.data_ptr(), k3, B, H, W, Cc, Cc, 0, 1)), stream()) == -1
+    k4 = abi.GSink(gout.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr(), p2.data_ptr(), Cc, Cc, 1, 0, 3, ldp)
+    assert l.pq_route_bwd(C.byref(abi.RouteBwd(gout.data_ptr(), k4, B, H, W, Cc, Cc, 0, 1)), stream()) == -1
+
+
 def test_copy_and_route_with_channel_counts_that_are_not_multiples_of_four():
     """Pruned nets concatenate e.g. 25 + 95 channels: the second slice starts at an unaligned offset and the first one ends
     inside a quad.  Pitches stay multiples of 4; pad lanes are never written."""

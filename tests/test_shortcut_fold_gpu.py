@@ -57,7 +57,22 @@ def test_folded_linear_shortcuts_give_the_gradients_of_the_route_backward_launch
         assert (da - db).norm().item() <= 1e-5 * db.norm().item() + 1e-7 * gmax, (o, (da - db).norm().item(), db.norm().item())
 
 
-def test_shortcuts_with_an_activation_are_not_folded(monkeypatch):
-    monkeypatch.setenv('PQ_SCFOLD', '1')
-    _, _, folded, n_route, _ = _step('regnetx-600m-fpn', 2, 256)        # ReLU behind every sum
-    assert folded == 0 and n_route > 16
+@pytest.mark.parametrize('model_name,B,S', [('regnetx-600m-fpn', 2, 256), ('regnetx-600m-pan', 2, 320)])
+def test_shortcuts_with_an_activation_share_the_gradient_buffer(model_name, B, S, monkeypatch):
+    """RegNet: ReLU behind the sum.  The sum's sinks need the sum's own y, so they cannot emit the conv branch's BatchNorm sums; the
+    gradient w.r.t. the raw sum is still the gradient of both addends: the conv branch uses the sum's buffer (one statistics-only
+    pq_route_bwd pass, finalize = 3), the other addend reads it as its sink's addend.  Same gradients as the two-sink launches."""
+    runs = {}
+    for mode in ('1', '0', '1'):
+        monkeypatch.setenv('PQ_SCFOLD', mode)
+        loss, grad, folded, n_route, net = _step(model_name, B, S)
+        plan = list(net._plans.values())[0]
+        runs.setdefault(mode, []).append((loss, grad, plan.sc_aliased, n_route, net))
+    on, off = runs['1'][0], runs['0'][0]
+    assert torch.equal(on[0], off[0]) and torch.equal(on[1], runs['1'][1][1])
+    assert on[2] >= 8 and off[2] == 0, (on[2], off[2])
+    flat = on[4]._flat
+    gmax = max(off[1][o:o + p.numel()].double().norm().item() for p, o in zip(flat.params, flat.offsets))
+    for p, o in zip(flat.params, flat.offsets):
+        da, db = on[1][o:o + p.numel()].double(), off[1][o:o + p.numel()].double()
+        assert (da - db).norm().item() <= 1e-5 * db.norm().item() + 1e-7 * gmax, (o, (da - db).norm().item(), db.norm().item())
