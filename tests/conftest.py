@@ -12,8 +12,24 @@ for p in (ROOT, GOLDEN_DIR):
         sys.path.insert(0, p)
 
 
+def _usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (bench.py::usable_cores)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle (PyTorch-CPU) sizes its thread pool by the HOST's core count; a GPU box hands a job 16 of 256 cores through a
+    # cgroup quota, and 128 threads on 16 cores run every oracle pass at half speed (measured: 252 -> 116 ms for a depthwise pass)
+    import torch
+    torch.set_num_threads(min(torch.get_num_threads(), _usable_cores()))
 
 
 @pytest.fixture(scope='session')

@@ -1305,6 +1305,35 @@ def test_nms_batch_is_bit_identical_to_one_call_per_image(B, n, ncls, cand, path
     assert total == k
 
 
+def test_nms_batch_with_one_image_beyond_the_per_image_capacity():
+    """The per-image LDS sort (path 1) holds 8192 candidates per image.  ONE image beyond that -- while the batch total is well inside
+    the capacity of the call -- must raise the documented overflow signal (count == -1, nothing else is valid), and the caller's
+    fallback (sort everything: the library path) then returns exactly the per-image results (round-4 review: this case had no test)."""
+    B, n, ncls = 4, 3000, 20
+    dets = [torch.as_tensor(_random_dets(n, ncls, 300 + b, hot=0.3 if b == 1 else 0.02)).clone() for b in range(B)]
+    batch = torch.stack(dets).to(DEV)
+    thr = 0.1
+    per_image = [int((d[:, 4:] > thr).sum()) for d in dets]
+    assert per_image[1] > 8192 and max(per_image[0], per_image[2], per_image[3]) < 2000 and sum(per_image) < B * 8192, per_image
+    out, img, cnt = ops.nms_batch(batch, thr, 0.45, cand_cap=B * 8192)
+    if os.environ.get('PQ_NMS_LIBSORT') != '1':
+        assert abi.lib().pq_nms_last_path() == 1
+        assert int(cnt.item()) == -1, 'one image holds %d candidates: the call must report the overflow' % per_image[1]
+    out, img, cnt = ops.nms_batch(batch, thr, 0.45, cand_cap=0)
+    assert abi.lib().pq_nms_last_path() == 2
+    k = int(cnt.item())
+    assert k > 0
+    out, img = out[:k], img[:k]
+    total = 0
+    for b in range(B):
+        d1, c1 = ops.nms(batch[b], thr, 0.45, cand_cap=0)
+        k1 = int(c1.item())
+        mine = out[img == b]
+        assert mine.shape[0] == k1 and torch.equal(mine, d1[:k1]), b
+        total += k1
+    assert total == k
+
+
 def test_nms_empty_and_ties():
     from oracle import postprocess as opost
     from pqdet_amd import tools
