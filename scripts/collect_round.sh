@@ -19,7 +19,10 @@ PER_OP=1 PER_OP_ALL=1 timeout -k 10 300 python scripts/phase_wall.py 16 512 20 >
 echo collected base
 # round 5: MFMA-pipe utilisation per kernel, class-removal sensitivities with the final code, the fused inverted-residual kernels alone
 bash scripts/profile_mfma.sh > $OUT/profile_mfma.log 2>&1 || true
+BENCH_ARGS="--model regnetx-600m-fpn" SUFFIX="_regnetx-600m-fpn" bash scripts/profile_mfma.sh > $OUT/profile_mfma_regnetx.log 2>&1 || true
 timeout -k 10 300 python scripts/critical_path.py 16 512 20 > $OUT/${TAG}_critical_path.txt 2>&1 || true
 timeout -k 10 300 python scripts/irblock_bench.py > $OUT/${TAG}_irblock_alone.txt 2>&1 || true
-PQ_IRFUSE=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_unfused.json 2>> $OUT/bench.err || true
+PQ_IRFUSE=0 PQ_SCFOLD=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_unfused.json 2>> $OUT/bench.err || true
+PQ_SCFOLD=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_nofold.json 2>> $OUT/bench.err || true
+PQ_REDUCE_BATCH=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_reduce_batch.json 2>> $OUT/bench.err || true
 echo collected round 5 extras

@@ -6,6 +6,8 @@ import torch
 from pqdet_amd import abi
 SHAPES = [(16, 256, 256, 32, 1), (16, 128, 128, 144, 1), (16, 64, 64, 192, 1), (16, 32, 32, 384, 1), (16, 32, 32, 576, 1),
           (16, 16, 16, 960, 1), (16, 64, 64, 128, 1), (16, 256, 256, 96, 2), (16, 128, 128, 144, 2)]
+if os.environ.get('SHAPES'):          # e.g. SHAPES='16,16,16,512,1;16,32,32,256,1'
+    SHAPES = [tuple(int(v) for v in it.split(',')) for it in os.environ['SHAPES'].split(';')]
 l = abi.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream); dev = 'cuda'
 def vec(n): return torch.rand(n + 32, device=dev) + 0.5
 def timeit(fn, reps=20):

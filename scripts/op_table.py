@@ -32,4 +32,11 @@ for arr, n, tag in ((plan.fwd_arr, len(plan.fwd), 'fwd'), (plan.bwd_arr, len(pla
                                                                             a.dx.finalize, a.dx.accumulate, a.dx.act, 1 if a.dx.mean else 0)
         elif code == abi.OP_COPY_FWD:
             desc = 'B%d %dx%d C%d up%d coff%d %s' % (a.B, a.H, a.W, a.C, a.up, a.coff, 'a+b' if a.b.x else 'a')
+        elif code in (abi.OP_DW_BWD, abi.OP_DW_FWD):
+            n_in, n_out = a.B * a.IH * a.IW * a.C, a.B * a.OH * a.OW * a.C
+            byt = 4.0 * (2 * n_in + 2 * n_out) if code == abi.OP_DW_BWD else 4.0 * (n_in + n_out)
+            desc = 'B%d %dx%d C%d s%d  %.0f MB minimal  %.2f TB/s' % (a.B, a.IH, a.IW, a.C, a.stride, byt / 1e6, byt / (tot[k] * 1e-3) / 1e12 if tot[k] > 0 else 0)
+        elif code in (abi.OP_CONV1X1_FWD, abi.OP_CONV1X1_DGRAD, abi.OP_CONV1X1_WGRAD):
+            fl = 2.0 * a.M * a.I * a.O
+            desc = 'M%d I%d O%d  %.1f TF/s' % (a.M, a.I, a.O, fl / (tot[k] * 1e-3) / 1e12 if tot[k] > 0 else 0)
         print('%s op %3d  %7.1f us  %s' % (tag, k, tot[k] * 1e3, desc))

@@ -4,11 +4,12 @@
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TAG=${TAG:-r5}
+export SUFFIX=${SUFFIX:-}          # BENCH_ARGS / SUFFIX as in profile_round.sh (e.g. "--model regnetx-600m-fpn" / "_regnetx-600m-fpn")
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/mfma
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2> $OUT/mfma.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o $TAG -- python3 $ROOT/bench.py --no-cpu-baseline $BENCH_ARGS --steps 4 --warmup 2 > /dev/null 2> $OUT/mfma.log
 cd $ROOT
 python3 - <<'PY'
 import csv, glob, collections, os
@@ -26,10 +27,10 @@ for k, c in acc.items():
     util = mf / (gui / 8 * 1024) if gui else 0.0
     rows.append((gui, k, n[k], mf, util))
 rows.sort(reverse=True)
-with open(os.path.join(root, 'gpurun_out/prof/%s_mfma_summary.csv' % os.environ['TAG']), 'w') as o:
+with open(os.path.join(root, 'gpurun_out/prof/%s_mfma_summary%s.csv' % (os.environ['TAG'], os.environ.get('SUFFIX', ''))), 'w') as o:
     o.write('kernel,launches,gui_active_cycles_total,mfma_busy_cycles_total,mfma_pipe_utilisation(busy/((gui/8 XCDs)*1024 SIMDs))\n')
     for gui, k, cnt, mf, util in rows[:40]:
         o.write('"%s",%d,%.0f,%.0f,%.3f\n' % (k, cnt, gui, mf, util))
-print(open(os.path.join(root, 'gpurun_out/prof/%s_mfma_summary.csv' % os.environ['TAG'])).read()[:3000])
+print(open(os.path.join(root, 'gpurun_out/prof/%s_mfma_summary%s.csv' % (os.environ['TAG'], os.environ.get('SUFFIX', '')))).read()[:3000])
 PY
 rm -rf $OUT/mfma
