@@ -594,15 +594,24 @@ static int g2_dispatch_nt(const G2P& p, int bm, hipStream_t st, pq_gemm_plan* pl
     // ring depth by LDS budget: two workgroups per CU (<= 80 KB each) -- except AMODE 4 (coefficients derived from accumulators, behind
     // PQ_BN_BWD_ATOMIC=all): its 128 x 64 x 3 ring takes 120 KB + up to 20 KB of table, i.e. ONE workgroup per CU, part of why that
     // scope measured slower (profiles/r4_bn_bwd_handover_scope.txt)
+    // Ring depth TWO everywhere (round 5).  Three stages are 1-3 % faster per launch ALONE, but a 64 x 64 pair-staging workgroup then
+    // holds 80 KB: two of them own a CU's whole LDS and no weight-gradient workgroup of the side stream can become resident beside
+    // them (nor can a second main workgroup start on a CU where a weight-gradient workgroup sits).  With <= 54 KB per workgroup the
+    // two streams interleave on every CU: 8.65 -> 8.55 ms per mobilenetv2-fpn step (-DPQ_G2_RING3 restores the old depth for A/B).
+#ifdef PQ_G2_RING3
+    constexpr int R3 = 3;
+#else
+    constexpr int R3 = 2;
+#endif
     if constexpr (EMODE == 2) {
         // gradient sink: tiles of at most two 32 x 32 blocks per wave (the sink's operands of a whole tile are prefetched into
         // registers; a 128 x 128 sink tile would need 288 of them: one wave per SIMD)
-        if (bm == 128) return g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
-        if (AMODE == 2 || AMODE == 4) return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
-        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
+        if (bm == 128) return g2_launch_nt<128, 64, AMODE, EMODE, R3>(p, st, plan);
+        if (AMODE == 2 || AMODE == 4) return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, R3>(p, st, plan);
+        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, R3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, R3>(p, st, plan);
     } else {
-        if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, 3>(p, st, plan);
-        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, 3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, 3>(p, st, plan);
+        if (bm == 128) return bn == 128 ? g2_launch_nt<128, 128, AMODE, EMODE, 2>(p, st, plan) : g2_launch_nt<128, 64, AMODE, EMODE, R3>(p, st, plan);
+        return bn == 128 ? g2_launch_nt<64, 128, AMODE, EMODE, R3>(p, st, plan) : g2_launch_nt<64, 64, AMODE, EMODE, R3>(p, st, plan);
     }
 }
 
@@ -666,7 +675,8 @@ struct G2WPlan { bool ok; int tiles, splits, rows; };
 static G2WPlan g2_wgrad_plan(int M, int I, int O) {
     G2WPlan pl{};
     // 128 x 128 tiles: shapes that would leave more than a third of a tile empty stay on the 64 x 64 gemm_tn kernel
-    pl.ok = g2_enabled() && (M % 32) == 0 && (I & 3) == 0 && (O & 3) == 0 &&
+    static const char* tn_env = getenv("PQ_G2_TN");                 // "0": every weight gradient on the 64 x 64 register-staged kernel (A/B)
+    pl.ok = g2_enabled() && !(tn_env && tn_env[0] == '0') && (M % 32) == 0 && (I & 3) == 0 && (O & 3) == 0 &&
             ((O - 1) % 128) >= 80 && ((I - 1) % 128) >= 80;
     if (!pl.ok) return pl;
     pl.tiles = ((O + 127) / 128) * ((I + 127) / 128);
@@ -688,9 +698,16 @@ int g2_wgrad_splits(int M, int I, int O) { const G2WPlan pl = g2_wgrad_plan(M, I
 
 template <bool TWO, bool XA, int NW>
 static int g2_launch_tn_nw(const G2TP& p, const G2WPlan& pl, hipStream_t st, pq_gemm_plan* plan) {
+    // two stages, 96 KiB (round 5): with three (144 KiB) a weight-gradient workgroup owned its CU -- no main-stream workgroup could
+    // start there for its whole ~80 us life; with two, one ring-GEMM / depthwise workgroup fits beside it: 8.55 -> 8.45 ms per step
+#ifdef PQ_G2_TN3
     constexpr int S = 3;
+#else
+    constexpr int S = 2;
+#endif
     if (plan) { *plan = pq_gemm_plan{2, 128, 128, S, (TWO ? 1 : 0) | (XA ? 2 : 0), 0, pl.splits, NW}; return PQ_OK; }
-    constexpr size_t bytes = (size_t)S * ((TWO ? 2 : 1) * 32 * 128 + 32 * 128) * 4;        // 144 / 96 KiB (>= the 64 KiB epilogue tile)
+    constexpr size_t ring_b = (size_t)S * ((TWO ? 2 : 1) * 32 * 128 + 32 * 128) * 4;        // 96 / 64 KiB
+    constexpr size_t bytes = ring_b > 65536 ? ring_b : 65536;                                // >= the 64 KiB epilogue tile
     static bool ok = g2_raise_lds((const void*)gemm2_tn_kernel<TWO, XA, S, NW>, bytes);
     if (!ok) { pq_set_error("gemm2: cannot raise the dynamic LDS limit"); return PQ_ELAUNCH; }
     PQ_LAUNCH((gemm2_tn_kernel<TWO, XA, S, NW>), dim3(pl.tiles, pl.splits), dim3(NW * 64), bytes, st, p);

@@ -26,25 +26,25 @@ FWD = [
     (65536, 128, 256, 2, True, False, True, (2, 128, 128, 2, 1, 1, 0)),      # FPN 64 x 64 level
     (65536, 256, 128, 2, True, False, True, (2, 128, 128, 2, 1, 1, 0)),
     (65536, 256, 75, 2, True, True, False, (2, 128, 128, 2, 1, 0, 0)),       # detection head (bias, no BatchNorm), ragged N
-    (16384, 512, 256, 2, True, False, True, (2, 128, 64, 3, 1, 1, 0)),
+    (16384, 512, 256, 2, True, False, True, (2, 128, 64, 2, 1, 1, 0)),
     (16384, 256, 512, 2, True, False, True, (2, 128, 128, 2, 1, 1, 0)),
-    (16384, 352, 256, 0, False, False, True, (2, 128, 64, 3, 0, 1, 0)),      # concatenated input: operand as stored
+    (16384, 352, 256, 0, False, False, True, (2, 128, 64, 2, 0, 1, 0)),      # concatenated input: operand as stored
     (65536, 160, 128, 0, False, False, True, (2, 128, 128, 2, 0, 1, 0)),
-    (4096, 512, 1024, 2, True, False, True, (2, 128, 64, 3, 1, 1, 0)),
-    (4096, 1024, 512, 2, True, False, True, (2, 64, 64, 3, 1, 1, 0)),
-    (16384, 256, 160, 1, True, False, True, (2, 64, 128, 3, 1, 1, 0)),       # 64-row blocks x 128 columns
-    (16390, 256, 150, 1, True, True, False, (2, 64, 128, 3, 1, 0, 0)),       # ... ragged in both directions, bias
+    (4096, 512, 1024, 2, True, False, True, (2, 128, 64, 2, 1, 1, 0)),
+    (4096, 1024, 512, 2, True, False, True, (2, 64, 64, 2, 1, 1, 0)),
+    (16384, 256, 160, 1, True, False, True, (2, 64, 128, 2, 1, 1, 0)),       # 64-row blocks x 128 columns
+    (16390, 256, 150, 1, True, True, False, (2, 64, 128, 2, 1, 0, 0)),       # ... ragged in both directions, bias
     (65500, 240, 240, 1, True, False, True, (2, 128, 128, 2, 1, 1, 0)),      # contraction 16 modulo 32 on 128-wide tiles, ragged M, N
     (16384, 528, 528, 1, True, False, True, (2, 128, 128, 2, 1, 1, 0)),      # RegNetX-600M last stage
     (32768, 176, 176, 0, False, False, True, (2, 128, 128, 2, 0, 1, 0)),     # ... half k-tile with the raw operand
-    (16384, 512, 128, 0, False, True, False, (2, 64, 64, 3, 0, 0, 0)),       # raw operand, plain store
+    (16384, 512, 128, 0, False, True, False, (2, 64, 64, 2, 0, 0, 0)),       # raw operand, plain store
     (65536, 128, 200, 0, False, True, False, (2, 128, 128, 2, 0, 0, 0)),
-    (16384, 512, 200, 0, False, True, False, (2, 128, 64, 3, 0, 0, 0)),
-    (16384, 256, 140, 0, False, True, False, (2, 64, 128, 3, 0, 0, 0)),
-    (16384, 512, 224, 2, True, True, False, (2, 128, 64, 3, 1, 0, 0)),
-    (4096, 512, 256, 2, True, True, False, (2, 64, 64, 3, 1, 0, 0)),
-    (16384, 256, 140, 0, False, False, True, (2, 64, 128, 3, 0, 1, 0)),
-    (4096, 512, 256, 0, False, False, True, (2, 64, 64, 3, 0, 1, 0)),
+    (16384, 512, 200, 0, False, True, False, (2, 128, 64, 2, 0, 0, 0)),
+    (16384, 256, 140, 0, False, True, False, (2, 64, 128, 2, 0, 0, 0)),
+    (16384, 512, 224, 2, True, True, False, (2, 128, 64, 2, 1, 0, 0)),
+    (4096, 512, 256, 2, True, True, False, (2, 64, 64, 2, 1, 0, 0)),
+    (16384, 256, 140, 0, False, False, True, (2, 64, 128, 2, 0, 1, 0)),
+    (4096, 512, 256, 0, False, False, True, (2, 64, 64, 2, 0, 1, 0)),
     # register-staged kernels (gemm.hip): short contractions on the big planes ("streaming" full-N tiles need >= 384 row blocks),
     # heads with 75 outputs
     (16384, 64, 384, 0, False, False, True, (1, 64, 64, 2, 0, 1, 0)),
@@ -84,24 +84,24 @@ DGRAD = [
     (16384, 512, 256, True, 2, False, True, (2, 64, 128, 2, 2, 2, 0)),
     (16384, 256, 512, True, 2, True, False, (2, 64, 128, 2, 2, 2, 0)),
     (4096, 1280, 512, True, 2, False, True, (2, 64, 128, 2, 2, 2, 0)),
-    (4096, 512, 1024, True, 2, False, True, (2, 64, 64, 3, 2, 2, 0)),
-    (131072, 64, 128, True, 2, False, True, (2, 64, 64, 3, 2, 2, 0)),
+    (4096, 512, 1024, True, 2, False, True, (2, 64, 64, 2, 2, 2, 0)),
+    (131072, 64, 128, True, 2, False, True, (2, 64, 64, 2, 2, 2, 0)),
     (65500, 252, 128, True, 1, True, True, (2, 64, 128, 2, 2, 2, 0)),        # ragged M, N
-    (4096, 160, 960, True, 2, False, True, (2, 64, 64, 3, 2, 2, 0)),         # 160 = 2.5 column tiles: a wave's whole block lies past N (its
+    (4096, 160, 960, True, 2, False, True, (2, 64, 64, 2, 2, 2, 0)),         # 160 = 2.5 column tiles: a wave's whole block lies past N (its
                                                                              # prefetched sink operands are clamped into the row, round 4)
     (65536, 240, 240, True, 1, False, True, (2, 64, 128, 2, 2, 2, 0)),       # contraction (O) 16 modulo 32
     (16384, 528, 528, True, 1, False, True, (2, 64, 128, 2, 2, 2, 0)),
-    (65536, 128, 256, False, 2, False, True, (2, 64, 128, 3, 0, 2, 0)),      # one-tensor gradient operand (conv without BatchNorm)
-    (65536, 256, 128, False, 0, True, True, (2, 64, 128, 3, 0, 2, 0)),
-    (131072, 64, 128, False, 2, False, True, (2, 64, 64, 3, 0, 2, 0)),
+    (65536, 128, 256, False, 2, False, True, (2, 64, 128, 2, 0, 2, 0)),      # one-tensor gradient operand (conv without BatchNorm)
+    (65536, 256, 128, False, 0, True, True, (2, 64, 128, 2, 0, 2, 0)),
+    (131072, 64, 128, False, 2, False, True, (2, 64, 64, 2, 0, 2, 0)),
     # 128-row data-gradient tiles: only from 2048 such tiles (round 3: 64-row tiles measured faster in the step below that); none of
     # the BASELINE nets reaches them any more, the instantiations stay for larger batches / planes
-    (131072, 256, 128, True, 0, True, True, (2, 128, 64, 3, 2, 2, 0)),       # (a sink tile has at most two blocks per wave: 128 x 64)
-    (131028, 252, 144, True, 1, False, True, (2, 128, 64, 3, 2, 2, 0)),      # ragged M, N; contraction 16 modulo 32
-    (262144, 64, 128, True, 2, False, True, (2, 128, 64, 3, 2, 2, 0)),
-    (131072, 256, 128, False, 0, True, True, (2, 128, 64, 3, 0, 2, 0)),
-    (262144, 64, 128, False, 2, False, True, (2, 128, 64, 3, 0, 2, 0)),
-    (4096, 512, 1024, False, 1, False, True, (2, 64, 64, 3, 0, 2, 0)),
+    (131072, 256, 128, True, 0, True, True, (2, 128, 64, 2, 2, 2, 0)),       # (a sink tile has at most two blocks per wave: 128 x 64)
+    (131028, 252, 144, True, 1, False, True, (2, 128, 64, 2, 2, 2, 0)),      # ragged M, N; contraction 16 modulo 32
+    (262144, 64, 128, True, 2, False, True, (2, 128, 64, 2, 2, 2, 0)),
+    (131072, 256, 128, False, 0, True, True, (2, 128, 64, 2, 0, 2, 0)),
+    (262144, 64, 128, False, 2, False, True, (2, 128, 64, 2, 0, 2, 0)),
+    (4096, 512, 1024, False, 1, False, True, (2, 64, 64, 2, 0, 2, 0)),
     # register-staged kernels
     (16384, 176, 75, False, 1, False, False, (1, 64, 64, 2, 0, 2, 0)),
     (65536, 32, 192, True, 0, True, False, (1, 128, 32, 1, 2, 2, 0)),
@@ -115,25 +115,25 @@ DGRAD = [
 
 # ---- weight gradient: M, I, O, two-tensor operand, transformed input operand, expected (bm, bn, stages, amode, waves), splits
 WGRAD = [
-    (65536, 128, 256, True, True, (2, 128, 128, 3, 3, 0, 4), 128),
-    (16384, 352, 256, True, False, (2, 128, 128, 3, 1, 0, 4), 40),           # concatenated input: operand as stored
-    (4096, 512, 1024, True, True, (2, 128, 128, 3, 3, 0, 4), 8),
-    (65536, 256, 128, False, True, (2, 128, 128, 3, 2, 0, 4), 128),           # one-tensor gradient operand
-    (65536, 224, 112, False, False, (2, 128, 128, 3, 0, 0, 4), 128),          # ... both operands as stored, ragged tiles both ways
-    (16416, 352, 224, True, True, (2, 128, 128, 3, 3, 0, 4), 40),            # ragged 128-tiles in O and I, uneven last split
-    (256, 2560, 1280, True, True, (2, 128, 128, 3, 3, 0, 4), 1),             # a single row split
+    (65536, 128, 256, True, True, (2, 128, 128, 2, 3, 0, 4), 128),
+    (16384, 352, 256, True, False, (2, 128, 128, 2, 1, 0, 4), 40),           # concatenated input: operand as stored
+    (4096, 512, 1024, True, True, (2, 128, 128, 2, 3, 0, 4), 8),
+    (65536, 256, 128, False, True, (2, 128, 128, 2, 2, 0, 4), 128),           # one-tensor gradient operand
+    (65536, 224, 112, False, False, (2, 128, 128, 2, 0, 0, 4), 128),          # ... both operands as stored, ragged tiles both ways
+    (16416, 352, 224, True, True, (2, 128, 128, 2, 3, 0, 4), 40),            # ragged 128-tiles in O and I, uneven last split
+    (256, 2560, 1280, True, True, (2, 128, 128, 2, 3, 0, 4), 1),             # a single row split
     (65536, 160, 128, True, False, (1, 64, 64, 1, 1, 0, 0), 86),             # 160 leaves a 128-tile 1/4 full: round-1 kernel
     (16384, 96, 576, True, True, (1, 64, 64, 1, 3, 0, 0), 29),
 ]
 # ---- forward with the operand's BatchNorm DERIVED from the producer's accumulators (AMODE 3, tests/test_bn_handover_gpu.py):
 # conv A (M, I -> O) feeds conv B (M, O -> C2): stats / bias of conv B, expected instantiation of conv B
 HANDOVER = [
-    (16384, 32, 192, 64, True, False, (2, 64, 64, 3, 3, 1, 0)),
-    (4096, 256, 160, 960, True, False, (2, 128, 64, 3, 3, 1, 0)),
+    (16384, 32, 192, 64, True, False, (2, 64, 64, 2, 3, 1, 0)),
+    (4096, 256, 160, 960, True, False, (2, 128, 64, 2, 3, 1, 0)),
     (65536, 128, 256, 75, False, True, (2, 128, 128, 2, 3, 0, 0)),
     (16384, 128, 256, 512, True, False, (2, 128, 128, 2, 3, 1, 0)),
-    (7200, 128, 352, 75, False, True, (2, 64, 64, 3, 3, 0, 0)),
-    (16384, 128, 176, 176, True, False, (2, 64, 128, 3, 3, 1, 0)),            # RegNetX neck: behind a grouped 3x3 that hands its statistics over
+    (7200, 128, 352, 75, False, True, (2, 64, 64, 2, 3, 0, 0)),
+    (16384, 128, 176, 176, True, False, (2, 64, 128, 2, 3, 1, 0)),            # RegNetX neck: behind a grouped 3x3 that hands its statistics over
 ]
 WGRAD_BIAS = [(65536, 256, 75, False, (1, 64, 64, 1, 2, 0, 0))]                  # detection head: bias gradient in the same pass
 
