@@ -872,7 +872,8 @@ static void wgrad_plan(int M, int I, int O, int& tiles, int& splits, int& rows) 
     // or faster on every layer shape of the nets
     const int b = 64;
     tiles = ((O + b - 1) / b) * ((I + b - 1) / b);
-    const int target = 512;
+    static const char* tg_env = getenv("PQ_TN_TARGET");             // A/B only
+    const int target = tg_env ? atoi(tg_env) : 512;
     int want = (target + tiles - 1) / tiles;
     int maxs = (M + 255) / 256;
     splits = want < 1 ? 1 : (want > maxs ? maxs : want);

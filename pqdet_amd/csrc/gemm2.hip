@@ -291,7 +291,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_nt_kernel(G2P p) {     // two wa
     // sink) and its coefficients are requested HERE, in front of the last k-tile's MFMAs, so that their HBM round trip does not
     // open the epilogue -- where every co-resident workgroup of a single-round grid would wait for the same burst at once.
     constexpr int NB = TI * TJ;
+#ifdef PQ_G2_NOHOIST
+    constexpr bool HOIST = false;
+#else
     constexpr bool HOIST = EMODE == 2 && NB <= 2;
+#endif
     EpiGeom eg;
     eg.m0w = m0 + __builtin_amdgcn_readfirstlane(wm) * WM; eg.n0w = n0 + __builtin_amdgcn_readfirstlane(wn) * WN;
     eg.lrow = lrow; eg.lh = lh; eg.M = M; eg.N = N;
@@ -685,7 +689,8 @@ static G2WPlan g2_wgrad_plan(int M, int I, int O) {
     // on gemm_tn
     // (re-measured in round 3 with the main chain as the limiter: 128 workgroups, half the CUs, 10.08-10.11 ms against 10.09-10.11;
     // 96 / 64: 10.2-10.26 / 10.41-10.46)
-    const int target = 256;
+    static const char* tg_env = getenv("PQ_G2_TN_TARGET");          // A/B only
+    const int target = tg_env ? atoi(tg_env) : 256;
     int splits = target / pl.tiles;
     const int maxs = M / 256;
     if (splits > maxs) splits = maxs;
