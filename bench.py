@@ -301,6 +301,8 @@ def main(args, world, rank, local):
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
+    if os.environ.get('PQ_MAIN_PRIO') == '1':                   # A/B only: the step on a high-priority stream (weight gradients stay normal)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     torch.manual_seed(0)
     model = DetectionModel(io.StringIO(zoo.cfg_text(args.model)), quant=args.qat).to(dev)
     model.train()

@@ -37,7 +37,7 @@ __device__ __forceinline__ f32x16 gmfma(float a, float b, f32x16 c) { return __b
 // ---- operand tile staging.  A thread owns ONE channel quad (coefficients live in registers) and walks pixels; the loads
 // of four pixels are issued back to back at clamped (always valid) coordinates and masked afterwards -- a load inside an
 // `if` per element made the staging loop one memory latency per iteration, which dominated the stride-2 layers.
-constexpr int GUB = 4;
+constexpr int GUB = 4;            // weight-image staging: loads in flight per thread (14 -- two batches instead of seven for K = 216 -- measured: no change in the step, the co-resident workgroups hide it)
 // operand-tile staging: pixels a thread keeps in flight per batch.  A batch = one exposed memory round trip (its LDS stores sit
 // between it and the next batch's loads), so the 10 x 18 tile of the stride-1 kernels (at most 6 pixels per thread with >= 32
 // pixel lanes) goes in ONE batch; the 17 x 33 tile of the stride-2 kernels in batches of 8
@@ -497,9 +497,13 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GcWP p) {
     const int gw = p.gw, gq = gw >> 2, pitch = gq + 1;
     const int K = 9 * gw, NCH = (K + 31) / 32;
     constexpr int ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3;
-    float* Xt = smem;                                            // [ITH*ITW][pitch*4]
-    float* Yt = Xt + (size_t)ITH * ITW * pitch * 4;              // [128][32]  dy' (o padded to 32)
-    float* red = Yt + 128 * 32;                                  // [4][32*32]
+    // x' tile [ITH*ITW][pitch*4] (at least 4096 floats: the region doubles as the [4][32*32] scratch of the final reduction over the
+    // four waves -- a weight-gradient workgroup lives for the whole launch on the side stream, and every KB of LDS it holds is a KB the
+    // main stream's workgroups on that CU cannot have), then dy' [128][32] (o padded to 32)
+    float* Xt = smem;
+    const int xfl = ITH * ITW * pitch * 4;
+    float* Yt = Xt + (xfl > 4096 ? xfl : 4096);
+    float* red = smem;
     const int g = blockIdx.x, split = blockIdx.y;
     const int cbase = g * gw;
     const int ntiles = p.B * p.tilesH * p.tilesW;
@@ -747,7 +751,8 @@ extern "C" int pq_gconv3x3_wgrad(const pq_gconv3x3_wgrad_args* a, void* stream) 
     const int G = a->C / a->gw, ntiles = a->B * p.tilesH * p.tilesW;
     p.nsplit = gc_nsplit(ntiles, G);
     const int S = a->stride, ITH = (GTH - 1) * S + 3, ITW = (GTW - 1) * S + 3, pitch = a->gw / 4 + 1;
-    const size_t lds = ((size_t)ITH * ITW * pitch * 4 + 128 * 32 + 4 * 1024) * sizeof(float);
+    const size_t xfl = (size_t)ITH * ITW * pitch * 4;
+    const size_t lds = ((xfl > 4096 ? xfl : 4096) + 128 * 32) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int nch = (9 * a->gw + 31) / 32;
     const dim3 wgrid(G, p.nsplit);
