@@ -584,6 +584,14 @@ inline const char* sink_acc_check(const pq_gsink& s, int C, long nblk) {
         const char* m_ = sink_acc_check(sink, C, nblk);                     \
         if (m_) { pq_set_error("%s: %s", __func__, m_); return PQ_EINVAL; } \
     } while (0)
+// pq_gsink.addend: only read by an accumulating sink, through float4 loads in most kernels
+#define PQ_SINK_ADDEND_CHECK(sink)                                                                                              \
+    do {                                                                                                                        \
+        if ((sink).addend && (!(sink).accumulate || (((uintptr_t)(sink).addend) & 15))) {                                       \
+            pq_set_error("%s: dx.addend needs accumulate = 1 and a 16-byte aligned address (pitch ldg)", __func__);             \
+            return PQ_EINVAL;                                                                                                   \
+        }                                                                                                                       \
+    } while (0)
 #define PQ_SINK_ACC_UNSUPPORTED(sink)                                                                              \
     do {                                                                                                            \
         if ((sink).stat_acc) {                                                                                      \

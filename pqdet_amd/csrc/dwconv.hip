@@ -804,6 +804,7 @@ int pq_dw_fwd_stream(const pq_dw3x3_fwd_args* a, void* stream) {
 extern "C" int pq_dw3x3_dgrad(const pq_dw3x3_dgrad_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->dy.g && a->w && a->dx.g, "null pointer");
     PQ_SINK_ACC_UNSUPPORTED(a->dx);
+    PQ_SINK_ADDEND_CHECK(a->dx);
     PQ_CHECK_ARG(check_dw_common(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->stride), "bad shape (need stride 1|2, pad 1, pitches that are multiples of 4)");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_dw3x3_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }

@@ -236,6 +236,7 @@ extern "C" int32_t pq_dw3x3_bwd_walk_blocks(int32_t B, int32_t IH, int32_t IW, i
 
 extern "C" int pq_dw3x3_bwd(const pq_dw3x3_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->part >= 0 && a->part <= 6, "null pointer / bad part");
+    if (a->part == 5) PQ_SINK_ADDEND_CHECK(a->dx);
     if (a->dy_stat.acc) {     // BatchNorm-backward sums handed over by the sink kernel: only the walking kernel derives from them
         PQ_CHECK_ARG(a->part == 5 && a->dy.y && a->dy.mu, "dy_stat: part 5 with a two-tensor gradient operand only");
         PQ_CHECK_ARG(a->dy_stat.bad && a->dy_stat.gamma && a->dy_stat.invstd && a->dy_stat.dgamma && a->dy_stat.dbeta && a->dy_stat.p &&

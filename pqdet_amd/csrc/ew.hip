@@ -613,6 +613,8 @@ extern "C" int pq_copy_fwd(const pq_copy_args* a, void* stream) {
 
 extern "C" int pq_route_bwd(const pq_route_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->gout && a->dx.g, "null pointer");
+    PQ_SINK_ADDEND_CHECK(a->dx);
+    if (a->dx2.g) PQ_SINK_ADDEND_CHECK(a->dx2);
     PQ_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->up >= 1, "bad shape");
     PQ_CHECK_ARG(a->ldgo % 4 == 0 && a->dx.ldg % 4 == 0, "pitches must be multiples of 4");
     PQ_CHECK_ARG(!(a->gate || a->bcast) || (a->C % 4 == 0 && a->coff % 4 == 0), "gated / broadcast routing needs multiples of 4");

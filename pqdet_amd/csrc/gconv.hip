@@ -694,6 +694,7 @@ extern "C" int pq_gconv3x3_fwd(const pq_gconv3x3_fwd_args* a, void* stream) {
 extern "C" int pq_gconv3x3_dgrad(const pq_gconv3x3_dgrad_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->dy.g && a->w && a->dx.g, "null pointer");
     PQ_SINK_ACC_UNSUPPORTED(a->dx);
+    PQ_SINK_ADDEND_CHECK(a->dx);
     PQ_CHECK_ARG(gc_check(a->B, a->IH, a->IW, a->OH, a->OW, a->C, a->gw, a->stride), "bad shape (group width multiple of 4 and <= 32, stride 1|2, pad 1)");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");
     if (act_is_special(a->dx.act)) { pq_set_error("pq_gconv3x3_dgrad: logistic/tanh sinks are not supported"); return PQ_EUNSUPPORTED; }

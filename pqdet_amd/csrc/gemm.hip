@@ -792,6 +792,7 @@ int conv1x1_fwd_stat_ok(const pq_conv1x1_fwd_args* a, int role) {
 
 static int conv1x1_dgrad_impl(const pq_conv1x1_dgrad_args* a, void* stream, pq_gemm_plan* plan) {
     PQ_CHECK_ARG(a && a->dy.g && a->w && a->dx.g, "null pointer");
+    PQ_SINK_ADDEND_CHECK(a->dx);
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0), "gradient pitch must be a multiple of 4");
     PQ_CHECK_ARG(!(a->dx.finalize && (a->dx.act != PQ_ACT_LINEAR || a->dx.mean)) || a->dx.y, "sink needs y to finalize");

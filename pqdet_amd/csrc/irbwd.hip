@@ -681,6 +681,7 @@ static int xb_launch(const XbwdP& p, const XbPlan& w, hipStream_t st) {
 
 extern "C" int pq_xdw_bwd(const pq_xdw_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->in.x && a->we && a->wd && a->dy.g && a->dx.g && a->scratch && a->moments, "null pointer");
+    PQ_SINK_ADDEND_CHECK(a->dx);
     PQ_CHECK_ARG(a->mid_scale && a->mid_shift && a->mid_mean && a->mid_invstd && a->mid_gamma && a->dwe && a->dwd && a->dgamma && a->dbeta,
                  "null pointer (BatchNorm of the expanded tensor / parameter gradients)");
     PQ_CHECK_ARG(a->B > 0 && a->IH > 0 && a->IW > 0, "empty shape");

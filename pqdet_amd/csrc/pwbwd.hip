@@ -478,6 +478,7 @@ static int pw_launch(const PwP& p, const PwPlan& pl, hipStream_t st) {
 
 extern "C" int pq_conv1x1_bwd(const pq_conv1x1_bwd_args* a, void* stream) {
     PQ_CHECK_ARG(a && a->dy.g && a->w && a->in.x && a->dx.g && a->scratch, "null pointer");      // dw == NULL: deferred reduction
+    PQ_SINK_ADDEND_CHECK(a->dx);
     PQ_CHECK_ARG(a->M > 0 && a->I > 0 && a->O > 0, "empty shape");
     PQ_CHECK_ARG((a->dy.ldg & 3) == 0 && (a->dy.y == nullptr || (a->dy.ldy & 3) == 0) && (a->in.ld & 3) == 0 &&
                  (a->dx.ldg & 3) == 0 && (a->dx.ldy & 3) == 0, "pitches must be multiples of 4");

@@ -55,3 +55,17 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.pq_conv1x1_bwd_blocks(1 << 20, 16, 96) > 0 and lib.pq_conv1x1_bwd_blocks(4096, 160, 960) == 0
     assert lib.pq_conv1x1_bwd_pays(1 << 20, 16, 96) == 1 and lib.pq_conv1x1_bwd_pays(4096, 16, 96) == 0
     assert lib.pq_nms_scratch_bytes(16128, 20) > 16128 * 20 * 56
+
+
+def test_sink_addend_is_validated_without_a_gpu(lib):
+    """pq_gsink.addend (folded shortcuts): read through float4 loads by an ACCUMULATING sink only -- a misaligned address or a
+    non-accumulating sink is refused by the entry point, before any launch."""
+    import torch
+    buf = torch.zeros(64)
+    base = buf.data_ptr()
+    for addend, acc in ((base + 4, 1), (base, 0)):
+        sk = abi.GSink(base, base, None, None, None, None, None, 4, 4, 0, acc, 0, 0)
+        sk.addend = addend
+        r = abi.RouteBwd(base, sk, 1, 1, 4, 4, 4, 0, 1)
+        assert lib.pq_route_bwd(C.byref(r), None) == -1
+        assert b'addend' in lib.pq_last_error()
