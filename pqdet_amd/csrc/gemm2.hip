@@ -684,7 +684,7 @@ static G2WPlan g2_wgrad_plan(int M, int I, int O) {
             ((O - 1) % 128) >= 80 && ((I - 1) % 128) >= 80;
     if (!pl.ok) return pl;
     pl.tiles = ((O + 127) / 128) * ((I + 127) / 128);
-    // one workgroup per CU (144 KiB of LDS): tiles x splits <= 256 in ONE round, and every workgroup must get a contraction
+    // one workgroup per CU (96 KiB of LDS, 272 registers): tiles x splits <= 256 in ONE round, and every workgroup must get a contraction
     // of at least 256 rows (8 k-tiles) or the fixed costs (ring fill, row-group reduction, slab) dominate: shorter ones stay
     // on gemm_tn
     // (re-measured in round 3 with the main chain as the limiter: 128 workgroups, half the CUs, 10.08-10.11 ms against 10.09-10.11;
