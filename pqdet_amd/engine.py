@@ -1245,7 +1245,9 @@ class Plan:
                                                    B, src.H, src.W, out.H, out.W, out.C, gw, s)
                                 self._op(self.bwd, abi.OP_GCONV_DGRAD, d)
                         else:
-                            walk = src.needs_grad and \
+                            # (a folded shortcut's output is finalised through its conv branch's y: the walking kernel reads ONE tensor as
+                            # the conv's input and the sink's y, so such an input takes the separate data / weight gradient kernels)
+                            walk = src.needs_grad and getattr(src, 'fold_sa', None) is None and \
                                 (s == 1 or (src.H % 2 == 0 and src.W % 2 == 0))
                             if walk:
                                 nblk = l.pq_dw3x3_bwd_walk_blocks(B, src.H, src.W, out.C, s)

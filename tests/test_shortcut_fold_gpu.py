@@ -76,3 +76,136 @@ def test_shortcuts_with_an_activation_share_the_gradient_buffer(model_name, B, S
     for p, o in zip(flat.params, flat.offsets):
         da, db = on[1][o:o + p.numel()].double(), off[1][o:o + p.numel()].double()
         assert (da - db).norm().item() <= 1e-5 * db.norm().item() + 1e-7 * gmax, (o, (da - db).norm().item(), db.norm().item())
+
+
+FLUSH_CFG = """[net]
+channels=3
+
+[convolutional]
+filters=16
+size=3
+stride=2
+pad=1
+batch_normalize=1
+activation=relu6
+
+[convolutional]
+filters=16
+size=3
+stride=2
+pad=1
+groups=16
+batch_normalize=1
+activation=relu6
+
+[convolutional]
+filters=16
+size=1
+stride=1
+pad=1
+batch_normalize=1
+activation=linear
+
+[convolutional]
+filters=16
+size=1
+stride=1
+pad=1
+batch_normalize=1
+activation=linear
+
+[route]
+layers=-2
+
+[convolutional]
+filters=24
+size=1
+stride=2
+pad=1
+batch_normalize=1
+activation=relu6
+
+[convolutional]
+filters=75
+size=1
+stride=1
+pad=1
+activation=linear
+
+[yolo]
+classes=20
+ignore_thresh=0.5
+bbox_loss=l1
+l1_loss_gain=0.05
+
+[route]
+layers=3
+
+[shortcut]
+from=2
+activation=linear
+
+[convolutional]
+filters=16
+size=3
+stride=2
+pad=1
+groups=16
+batch_normalize=1
+activation=relu6
+
+[convolutional]
+filters=16
+size=3
+stride=2
+pad=1
+groups=16
+batch_normalize=1
+activation=relu6
+
+[convolutional]
+filters=75
+size=1
+stride=1
+pad=1
+activation=linear
+
+[yolo]
+classes=20
+ignore_thresh=0.5
+bbox_loss=l1
+l1_loss_gain=0.05
+"""
+
+
+def test_pending_addend_in_front_of_a_sink_that_cannot_read_it_is_copied():
+    """A tensor whose first gradient contribution is a folded shortcut's (pending pq_gsink.addend) and whose NEXT consumer in the
+    backward is a strided 1x1 conv -- the one sink path that is assembled by hand and cannot read an addend: the engine materialises
+    the addend with one pq_route_bwd copy (Plan._flush_addend) and carries on.  No BASELINE net has this topology; the gradients are
+    checked against the CPU oracle with frozen BatchNorm statistics (well conditioned), 5e-3 norm-wise like the pruned-net test."""
+    from oracle.net import OracleNet
+    from pqdet_amd import tools
+    from test_model_gpu import _targets, _relerr
+    net = DetectionModel(io.StringIO(FLUSH_CFG))
+    seeded_fill(net, 31)
+    ref = OracleNet(io.StringIO(FLUSH_CFG))
+    ref.load_state_dict(net.state_dict())
+    net = net.to(DEV)
+    x = seeded_images(2, 128, 160, 6)
+    tgt = _targets(2, 128, 160, 20, seed=4)
+    net.train(), ref.eval()
+    tools.freeze_bn_stats(net)
+    out = net(x.to(DEV), tuple(t.to(DEV) for t in tgt))
+    out['loss'].mean().backward()
+    net.check_nan()
+    plan = list(net._plans.values())[0]
+    assert plan.sc_folded == 1
+    copies = [op for op in plan.bwd if op.code == abi.OP_ROUTE_BWD and not op.u.rb.dx.accumulate and not op.u.rb.dx.finalize and not op.u.rb.dx.addend]
+    assert len(copies) == 1, 'expected exactly one materialising copy of a pending addend'
+    want = ref(x, tgt)
+    want['loss'].mean().backward()
+    for k in ('loss', 'giou_loss', 'conf_loss', 'class_loss'):
+        assert abs(out[k].item() - want[k].item()) <= 1e-3 * abs(want[k].item()) + 1e-5, k
+    for (n1, p1), (_, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        if p2.grad.norm().item() > 1e-6:
+            assert _relerr(p1.grad, p2.grad) < 5e-3, n1
