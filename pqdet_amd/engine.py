@@ -605,10 +605,13 @@ class Plan:
         # gradient (pq_gsink.addend).  PQ_SCFOLD=0 switches it off.
         self.sc_folded = self.sc_aliased = 0
         if train_graph and not self.qat and os.environ.get('PQ_SCFOLD', '1') != '0':
+            head_in = {id(a_) for _, _, a_ in heads}             # (a loss layer writes its input's gradient itself, not through a sink)
             for i_, m_ in enumerate(mods):
                 if m_._type != 'shortcut':
                     continue
                 out_, sa_, sb_ = T[i_], T[resolve(i_ - 1, i_)], T[resolve(m_._from, i_)]
+                if id(out_) in head_in or id(sa_) in head_in or id(sb_) in head_in:
+                    continue
                 if out_.bn is None and sa_ is not sb_ and sa_.bn is not None and sa_.act == 0 and \
                         sa_.n_consumers == 1 and sa_.ld == out_.ld and sa_.C % 4 == 0 and out_.n_consumers > 0 and \
                         mods[resolve(i_ - 1, i_)]._type == 'convolutional':
