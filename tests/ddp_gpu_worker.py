@@ -19,7 +19,7 @@ from seedfill import seeded_fill, seeded_images  # noqa: E402
 
 
 def fresh(seed):
-    net = DetectionModel(io.StringIO(zoo.cfg_text('mobilenetv2-fpn')))
+    net = DetectionModel(io.StringIO(zoo.cfg_text(os.environ.get('PQ_TEST_MODEL', 'mobilenetv2-fpn'))))
     seeded_fill(net, seed)
     return net.cuda().train()
 

@@ -18,11 +18,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_step_on_one_gpu():
+@pytest.mark.parametrize('model_name', ['mobilenetv2-fpn', 'regnetx-600m-fpn'])     # folded linear shortcuts / aliased ReLU shortcuts + grouped 3x3
+def test_two_rank_step_on_one_gpu(model_name):
     port = _free_port()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PQ_TEST_MODEL=model_name)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'ddp_gpu_worker.py')], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
